@@ -1,0 +1,13 @@
+"""MI355X-native differentiable 3D-Gaussian rasterizer for ExAvatar's ``GaussianRenderer``.
+
+Public surface (drop-in for ``diff_gaussian_rasterization_depth`` as used at reference
+``avatar/common/nets/module.py:11,609-640``):
+
+    from exavatar_release_amd import GaussianRasterizationSettings, GaussianRasterizer
+"""
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, check_overflow, config,
+                         rasterize_gaussians)
+from .renderer import GaussianRenderer
+
+__all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
+           'config', 'check_overflow']

@@ -1,0 +1,98 @@
+"""ctypes binding of ``libexa_raster.so`` (C ABI declared in ``include/exa_raster.h``).
+
+The library is the product: if it is missing or fails to load this module raises -- there is no
+CPU / PyTorch fallback path anywhere in the package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libexa_raster.so')
+
+c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
+c_void_p = ctypes.c_void_p
+
+
+class ExaRasterSettings(ctypes.Structure):
+    _fields_ = [
+        ('image_height', ctypes.c_int32),
+        ('image_width', ctypes.c_int32),
+        ('tanfovx', ctypes.c_float),
+        ('tanfovy', ctypes.c_float),
+        ('bg', c_void_p),
+        ('scale_modifier', ctypes.c_float),
+        ('viewmatrix', c_void_p),
+        ('projmatrix', c_void_p),
+        ('sh_degree', ctypes.c_int32),
+        ('campos', c_void_p),
+        ('prefiltered', ctypes.c_int32),
+        ('debug', ctypes.c_int32),
+    ]
+
+
+class ExaRasterWorkspaceSizes(ctypes.Structure):
+    _fields_ = [
+        ('geom_bytes', ctypes.c_uint64),
+        ('tile_bytes', ctypes.c_uint64),
+        ('bin_bytes', ctypes.c_uint64),
+        ('img_bytes', ctypes.c_uint64),
+        ('grad_bytes', ctypes.c_uint64),
+    ]
+
+
+# symbol -> (restype, argtypes); must list every function include/exa_raster.h declares
+_I32 = ctypes.c_int32
+_U64 = ctypes.c_uint64
+_SP = ctypes.POINTER(ExaRasterSettings)
+SIGNATURES = {
+    'exa_raster_version': (ctypes.c_int, []),
+    'exa_raster_last_error': (ctypes.c_char_p, []),
+    'exa_raster_workspace_sizes': (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.POINTER(ExaRasterWorkspaceSizes)]),
+    'exa_raster_forward_bin': (ctypes.c_int, [_SP, _I32, _I32] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exa_raster_forward_render': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p, _U64, c_void_p,
+                                                 c_void_p, c_void_p, c_void_p, _I32, c_void_p]),
+    'exa_raster_forward': (ctypes.c_int, [_SP, _I32, _I32] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p,
+                                                                                 _U64, c_void_p, c_void_p, c_void_p,
+                                                                                 c_void_p, _I32, c_void_p]),
+    'exa_raster_backward': (ctypes.c_int, [_SP, _I32, _I32] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p,
+                                                                                  _U64, c_void_p, c_void_p, c_void_p,
+                                                                                  c_void_p, c_void_p] + [c_void_p] * 8
+                            + [c_void_p]),
+    'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once). ``torch`` must be imported first so that the HIP runtime that
+    torch bundles (SONAME libamdhip64.so.7) is the one the library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (ensures torch's libamdhip64 is already mapped)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            'exavatar_release_amd: %s is missing. Build it with `python -m exavatar_release_amd.build` '
+            '(hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.exa_raster_version() < 100:
+        raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().exa_raster_last_error()
+        raise RuntimeError('%s (status %d)' % (msg.decode() if msg else 'exa_raster error', rc))
+
+
+def workspace_sizes(P, W, H, capacity):
+    out = ExaRasterWorkspaceSizes()
+    check(load().exa_raster_workspace_sizes(P, W, H, capacity, ctypes.byref(out)))
+    return out

@@ -1,0 +1,207 @@
+// C ABI of the rasterizer (include/exa_raster.h): argument validation, workspace carving, kernel
+// sequencing.  No torch types, no allocation, no hidden synchronisation (unless settings->debug).
+#include <stdio.h>
+#include <string.h>
+
+#include "common.h"
+
+using namespace exa;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* what) {
+    snprintf(g_err, sizeof(g_err), "exa_raster: %s", what);
+    return code;
+}
+int fail_hip(hipError_t e, const char* where) {
+    snprintf(g_err, sizeof(g_err), "exa_raster: HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), where);
+    return (int)e;
+}
+
+#define EXA_HIP(expr, where)                                   \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return fail_hip(e_, where);      \
+    } while (0)
+
+int debug_sync(const ExaRasterSettings* s, hipStream_t st, const char* where) {
+    if (!s->debug) return 0;
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, where);
+    return 0;
+}
+
+int check_settings(const ExaRasterSettings* s) {
+    if (!s) return fail(EXA_RASTER_E_NULLPTR, "settings is NULL");
+    if (s->image_height < 0 || s->image_width < 0) return fail(EXA_RASTER_E_INVALID, "negative image size");
+    if ((s->image_width + TILE - 1) / TILE > 65535 || (s->image_height + TILE - 1) / TILE > 65535)
+        return fail(EXA_RASTER_E_INVALID, "image too large (tile coordinates are 16-bit)");
+    if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
+        return fail(EXA_RASTER_E_NULLPTR, "settings bg/viewmatrix/projmatrix/campos must be device pointers");
+    if (!(s->tanfovx > 0.f) || !(s->tanfovy > 0.f)) return fail(EXA_RASTER_E_INVALID, "tanfov must be > 0");
+    if (s->sh_degree < 0 || s->sh_degree > 3) return fail(EXA_RASTER_E_INVALID, "sh_degree must be 0..3");
+    return 0;
+}
+
+int check_inputs(int32_t P, int32_t sh_M, const float* means3D, const float* shs, const float* colors_precomp,
+                 const float* opacities, const float* scales, const float* rotations, const float* cov3D_precomp,
+                 int sh_degree) {
+    if (P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
+    if (P == 0) return 0;
+    if (!means3D || !opacities) return fail(EXA_RASTER_E_NULLPTR, "means3D / opacities is NULL");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(EXA_RASTER_E_INVALID, "provide exactly one of shs / colors_precomp");
+    const bool has_sr = scales != nullptr && rotations != nullptr;
+    if ((scales != nullptr) != (rotations != nullptr) || has_sr == (cov3D_precomp != nullptr))
+        return fail(EXA_RASTER_E_INVALID, "provide exactly one of (scales + rotations) / cov3D_precomp");
+    if (shs && sh_M < (sh_degree + 1) * (sh_degree + 1))
+        return fail(EXA_RASTER_E_INVALID, "sh_M smaller than (sh_degree + 1)^2");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int exa_raster_version(void) { return EXA_RASTER_VERSION; }
+
+const char* exa_raster_last_error(void) { return g_err; }
+
+int exa_raster_workspace_sizes(int32_t P, int32_t W, int32_t H, uint64_t capacity, ExaRasterWorkspaceSizes* out) {
+    if (!out) return fail(EXA_RASTER_E_NULLPTR, "out is NULL");
+    if (P < 0 || W < 0 || H < 0) return fail(EXA_RASTER_E_INVALID, "negative size");
+    const Grid g = make_grid(W, H);
+    out->geom_bytes = align256(uint64_t(P) * sizeof(Splat));
+    out->tile_bytes = tile_ws_bytes(g.tiles);
+    out->bin_bytes = bin_ws_bytes(capacity);
+    out->img_bytes = img_ws_bytes(W, H);
+    out->grad_bytes = align256(uint64_t(P) * sizeof(GradAcc));
+    return 0;
+}
+
+int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D,
+                           const float* shs, const float* colors_precomp, const float* opacities,
+                           const float* scales, const float* rotations, const float* cov3D_precomp,
+                           int32_t* radii, void* geom_ws, void* tile_ws, void* stream) {
+    int rc = check_settings(s);
+    if (rc) return rc;
+    rc = check_inputs(P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s->sh_degree);
+    if (rc) return rc;
+    if (!tile_ws || (P > 0 && (!geom_ws || !radii))) return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Grid g = make_grid(s->image_width, s->image_height);
+    TileWs tw = carve_tile_ws(tile_ws, g.tiles);
+    // header + counts are contiguous: one memset node
+    EXA_HIP(hipMemsetAsync(tile_ws, 0, HEADER_BYTES + align256(uint64_t(NSUB) * g.tiles * 4), st), "memset(tile counts)");
+    PreprocessArgs a;
+    a.P = P; a.sh_M = sh_M; a.sh_degree = s->sh_degree; a.grid = g;
+    a.tanfovx = s->tanfovx; a.tanfovy = s->tanfovy;
+    a.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
+    a.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
+    a.scale_modifier = s->scale_modifier;
+    a.viewmatrix = s->viewmatrix; a.projmatrix = s->projmatrix; a.campos = s->campos;
+    a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
+    a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
+    a.radii = radii; a.splats = static_cast<Splat*>(geom_ws); a.counts = tw.counts; a.header = tw.header;
+    EXA_HIP(launch_preprocess_fwd(a, st), "preprocess_fwd");
+    if ((rc = debug_sync(s, st, "preprocess_fwd"))) return rc;
+    EXA_HIP(launch_tile_scan(tw, g.tiles, st), "tile_scan");
+    if ((rc = debug_sync(s, st, "tile_scan"))) return rc;
+    return 0;
+}
+
+int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void* geom_ws, void* tile_ws, void* bin_ws,
+                              uint64_t capacity, void* img_ws, float* out_color, float* out_depth, float* out_alpha,
+                              int32_t store_ctx, void* stream) {
+    int rc = check_settings(s);
+    if (rc) return rc;
+    if (P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
+    if (!tile_ws || (P > 0 && !geom_ws) || (capacity > 0 && !bin_ws) || (store_ctx && !img_ws))
+        return fail(EXA_RASTER_E_WORKSPACE, "workspace is NULL");
+    if (!out_color || !out_depth || !out_alpha) return fail(EXA_RASTER_E_NULLPTR, "output image is NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Grid g = make_grid(s->image_width, s->image_height);
+    TileWs tw = carve_tile_ws(tile_ws, g.tiles);
+    BinWs bw = carve_bin_ws(bin_ws, capacity);
+    EXA_HIP(launch_scatter(P, static_cast<const Splat*>(geom_ws), tw, g.tiles, g.gx, bw, capacity, st), "scatter");
+    if ((rc = debug_sync(s, st, "scatter"))) return rc;
+    RenderFwdArgs r;
+    r.grid = g; r.splats = static_cast<const Splat*>(geom_ws); r.tw = tw; r.bw = bw; r.capacity = capacity;
+    r.iw = carve_img_ws(img_ws, g.W, g.H);
+    r.bg = s->bg; r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha; r.store_ctx = store_ctx;
+    EXA_HIP(launch_render_fwd(r, st), "render_fwd");
+    if ((rc = debug_sync(s, st, "render_fwd"))) return rc;
+    return 0;
+}
+
+int exa_raster_forward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* opacities, const float* scales,
+                       const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_ws,
+                       void* tile_ws, void* bin_ws, uint64_t capacity, void* img_ws, float* out_color,
+                       float* out_depth, float* out_alpha, int32_t store_ctx, void* stream) {
+    int rc = exa_raster_forward_bin(s, P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                    cov3D_precomp, radii, geom_ws, tile_ws, stream);
+    if (rc) return rc;
+    return exa_raster_forward_render(s, P, geom_ws, tile_ws, bin_ws, capacity, img_ws, out_color, out_depth,
+                                     out_alpha, store_ctx, stream);
+}
+
+int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* opacities, const float* scales,
+                        const float* rotations, const float* cov3D_precomp, const int32_t* radii,
+                        const void* geom_ws, const void* tile_ws, const void* bin_ws, uint64_t capacity,
+                        const void* img_ws, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                        void* grad_ws, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity,
+                        float* dL_dscales, float* dL_drotations, float* dL_dsh, float* dL_dcov3D, void* stream) {
+    int rc = check_settings(s);
+    if (rc) return rc;
+    rc = check_inputs(P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s->sh_degree);
+    if (rc) return rc;
+    if (P == 0) return 0;
+    if (!geom_ws || !tile_ws || (capacity > 0 && !bin_ws) || !img_ws || !grad_ws || !radii)
+        return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
+    if (!dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Grid g = make_grid(s->image_width, s->image_height);
+    EXA_HIP(hipMemsetAsync(grad_ws, 0, uint64_t(P) * sizeof(GradAcc), st), "memset(grad accumulators)");
+    RenderBwdArgs r;
+    r.grid = g; r.splats = static_cast<const Splat*>(geom_ws);
+    r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.tiles);
+    r.bw = carve_bin_ws(const_cast<void*>(bin_ws), capacity);
+    r.iw = carve_img_ws(const_cast<void*>(img_ws), g.W, g.H);
+    r.bg = s->bg; r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
+    r.acc = static_cast<GradAcc*>(grad_ws);
+    EXA_HIP(launch_render_bwd(r, st), "render_bwd");
+    if ((rc = debug_sync(s, st, "render_bwd"))) return rc;
+    PreprocessBwdArgs b;
+    b.P = P; b.sh_M = sh_M; b.sh_degree = s->sh_degree; b.grid = g;
+    b.tanfovx = s->tanfovx; b.tanfovy = s->tanfovy;
+    b.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
+    b.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
+    b.scale_modifier = s->scale_modifier;
+    b.viewmatrix = s->viewmatrix; b.projmatrix = s->projmatrix; b.campos = s->campos;
+    b.means3D = means3D; b.shs = shs; b.opacities = opacities; b.scales = scales; b.rotations = rotations;
+    b.cov3D_precomp = cov3D_precomp; b.radii = radii; b.splats = static_cast<const Splat*>(geom_ws);
+    b.acc = static_cast<const GradAcc*>(grad_ws);
+    b.dL_dmeans2D = dL_dmeans2D; b.dL_dmeans3D = dL_dmeans3D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
+    b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations; b.dL_dsh = dL_dsh; b.dL_dcov3D = dL_dcov3D;
+    EXA_HIP(launch_preprocess_bwd(b, st), "preprocess_bwd");
+    if ((rc = debug_sync(s, st, "preprocess_bwd"))) return rc;
+    return 0;
+}
+
+int exa_raster_mark_visible(const ExaRasterSettings* s, int32_t P, const float* means3D, uint8_t* present,
+                            void* stream) {
+    int rc = check_settings(s);
+    if (rc) return rc;
+    if (P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
+    if (P > 0 && (!means3D || !present)) return fail(EXA_RASTER_E_NULLPTR, "means3D / present is NULL");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    EXA_HIP(launch_mark_visible(P, means3D, s->viewmatrix, present, st), "mark_visible");
+    return debug_sync(s, st, "mark_visible");
+}
+
+}  // extern "C"

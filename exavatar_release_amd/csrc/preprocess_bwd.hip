@@ -1,0 +1,257 @@
+// Per-Gaussian backward for gfx950: screen-space accumulators -> dL/d{means3D, means2D, scales,
+// rotations, opacities, colours | SH, cov3D}.
+//
+// Replaces upstream computeCov2DCUDA (backward) + preprocessCUDA (backward) of the rasterizer behind
+// reference avatar/common/nets/module.py:632-640.  The chain rule is derived from the forward in
+// oracle/raster_oracle.py::preprocess (same symbols: pv*, h*, S**, T**, J**, a/b/c, conic) and checked
+// against its autograd.  Semantics kept from upstream: the +-1.3 tanfov clamp blocks the gradient
+// through t.x / t.y when active; quaternions are not normalised; dL/dmeans2D is reported in NDC units
+// (pixel gradient * (W/2, H/2), z = 0), which is what the reference's densification reads
+// (avatar/main/train.py:51).
+//
+// HBM traffic per Gaussian: reads 64 B accumulator + 16 B of the splat record + 44 B inputs,
+// writes 68 B of gradients (SH: + 12 * M B).
+#include "common.h"
+
+namespace exa {
+
+__global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs a) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    const bool vis = a.radii[idx] > 0;
+
+    float dmean[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
+    float dq[4] = {0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
+
+    const float* __restrict__ v = a.viewmatrix;
+    const float* __restrict__ p = a.projmatrix;
+    const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
+
+    if (vis) {
+        const float4* accp = reinterpret_cast<const float4*>(a.acc + idx);
+        const float4 a0 = accp[0], a1 = accp[1], a2 = accp[2];
+        const float dpx = a0.x, dpy = a0.y, dA = a0.z, dB = a0.w, dC = a1.x;
+        dop = a1.y;
+        dcol[0] = a1.z; dcol[1] = a1.w; dcol[2] = a2.x;
+        const float dz_view = a2.y;
+
+        // ---- recompute the forward quantities ---------------------------------------------------
+        const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
+        const float pvy = ((v[1] * x + v[5] * y) + v[9] * z) + v[13];
+        const float pvz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
+        const float hx = ((p[0] * x + p[4] * y) + p[8] * z) + p[12];
+        const float hy = ((p[1] * x + p[5] * y) + p[9] * z) + p[13];
+        const float hw = ((p[3] * x + p[7] * y) + p[11] * z) + p[15];
+        const float pw = 1.0f / (hw + 1e-7f);
+
+        float S00, S01, S02, S11, S12, S22;
+        float R[9], sc[3];
+        float qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        if (a.cov3D_precomp) {
+            const float* c6 = a.cov3D_precomp + idx * 6;
+            S00 = c6[0]; S01 = c6[1]; S02 = c6[2]; S11 = c6[3]; S12 = c6[4]; S22 = c6[5];
+        } else {
+            sc[0] = a.scale_modifier * a.scales[idx * 3 + 0];
+            sc[1] = a.scale_modifier * a.scales[idx * 3 + 1];
+            sc[2] = a.scale_modifier * a.scales[idx * 3 + 2];
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            R[0] = 1.0f - 2.0f * (qy * qy + qz * qz); R[1] = 2.0f * (qx * qy - qr * qz); R[2] = 2.0f * (qx * qz + qr * qy);
+            R[3] = 2.0f * (qx * qy + qr * qz); R[4] = 1.0f - 2.0f * (qx * qx + qz * qz); R[5] = 2.0f * (qy * qz - qr * qx);
+            R[6] = 2.0f * (qx * qz - qr * qy); R[7] = 2.0f * (qy * qz + qr * qx); R[8] = 1.0f - 2.0f * (qx * qx + qy * qy);
+            float M[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) M[i * 3 + j] = R[i * 3 + j] * sc[j];
+            S00 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2];
+            S01 = M[0] * M[3] + M[1] * M[4] + M[2] * M[5];
+            S02 = M[0] * M[6] + M[1] * M[7] + M[2] * M[8];
+            S11 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5];
+            S12 = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
+            S22 = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+        }
+        const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+        const float tz = pvz;
+        const float txtz = pvx / tz, tytz = pvy / tz;
+        const bool clamp_x = txtz < -limx || txtz > limx;
+        const bool clamp_y = tytz < -limy || tytz > limy;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float itz = 1.0f / tz, itz2 = itz * itz;
+        const float J00 = a.focal_x * itz, J02 = -(a.focal_x * tx) * itz2;
+        const float J11 = a.focal_y * itz, J12 = -(a.focal_y * ty) * itz2;
+        // Rv[i][j] = v[j*4+i]
+        const float T0[3] = {J00 * v[0] + J02 * v[2], J00 * v[4] + J02 * v[6], J00 * v[8] + J02 * v[10]};
+        const float T1[3] = {J11 * v[1] + J12 * v[2], J11 * v[5] + J12 * v[6], J11 * v[9] + J12 * v[10]};
+        const float ST0[3] = {S00 * T0[0] + S01 * T0[1] + S02 * T0[2], S01 * T0[0] + S11 * T0[1] + S12 * T0[2],
+                              S02 * T0[0] + S12 * T0[1] + S22 * T0[2]};
+        const float ST1[3] = {S00 * T1[0] + S01 * T1[1] + S02 * T1[2], S01 * T1[0] + S11 * T1[1] + S12 * T1[2],
+                              S02 * T1[0] + S12 * T1[1] + S22 * T1[2]};
+        const float ca2 = (T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2]) + LOWPASS;
+        const float cb2 = T0[0] * ST1[0] + T0[1] * ST1[1] + T0[2] * ST1[2];
+        const float cc2 = (T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2]) + LOWPASS;
+        const float det = ca2 * cc2 - cb2 * cb2;
+        const float idet = 1.0f / det, idet2 = idet * idet;
+
+        // ---- conic (A, B, C) = (c, -b, a) / det  ->  cov2D (a, b, c) -----------------------------
+        const float da = idet2 * (-cc2 * cc2 * dA + cb2 * cc2 * dB - cb2 * cb2 * dC);
+        const float dc = idet2 * (-cb2 * cb2 * dA + cb2 * ca2 * dB - ca2 * ca2 * dC);
+        const float db = idet2 * (2.0f * cb2 * cc2 * dA - (det + 2.0f * cb2 * cb2) * dB + 2.0f * ca2 * cb2 * dC);
+
+        // ---- cov2D -> Sigma3 (full, unsymmetrised gradient G) and -> T ----------------------------
+        // G_jk = da T0j T0k + db T0j T1k + dc T1j T1k
+        float G[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G[j * 3 + k] = da * T0[j] * T0[k] + db * T0[j] * T1[k] + dc * T1[j] * T1[k];
+        float dT0[3], dT1[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            dT0[j] = 2.0f * da * ST0[j] + db * ST1[j];
+            dT1[j] = 2.0f * dc * ST1[j] + db * ST0[j];
+        }
+        if (a.cov3D_precomp) {
+            dcov[0] = G[0]; dcov[1] = G[1] + G[3]; dcov[2] = G[2] + G[6];
+            dcov[3] = G[4]; dcov[4] = G[5] + G[7]; dcov[5] = G[8];
+        } else {
+            // Sigma = M M^T, M = R diag(s):  dL/dM = (G + G^T) M
+            float M[9], dM[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) M[i * 3 + j] = R[i * 3 + j] * sc[j];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc += (G[i * 3 + k] + G[k * 3 + i]) * M[k * 3 + j];
+                    dM[i * 3 + j] = acc;
+                }
+            float dR[9];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dscale[j] = a.scale_modifier * (dM[0 * 3 + j] * R[0 * 3 + j] + dM[1 * 3 + j] * R[1 * 3 + j] + dM[2 * 3 + j] * R[2 * 3 + j]);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dR[i * 3 + j] = dM[i * 3 + j] * sc[j];
+            }
+            dq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+            dq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - qr * dR[5] + qz * dR[6] + qr * dR[7] - 2.0f * qx * dR[8]);
+            dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + qr * dR[2] + qx * dR[3] + qz * dR[5] - qr * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
+            dq[3] = 2.0f * (-2.0f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+        }
+
+        // ---- T = J Rv -> J -> view-space t ---------------------------------------------------------
+        const float dJ00 = dT0[0] * v[0] + dT0[1] * v[4] + dT0[2] * v[8];
+        const float dJ02 = dT0[0] * v[2] + dT0[1] * v[6] + dT0[2] * v[10];
+        const float dJ11 = dT1[0] * v[1] + dT1[1] * v[5] + dT1[2] * v[9];
+        const float dJ12 = dT1[0] * v[2] + dT1[1] * v[6] + dT1[2] * v[10];
+        const float itz3 = itz2 * itz;
+        const float dtx = clamp_x ? 0.f : -a.focal_x * itz2 * dJ02;
+        const float dty = clamp_y ? 0.f : -a.focal_y * itz2 * dJ12;
+        const float dtz = -a.focal_x * itz2 * dJ00 - a.focal_y * itz2 * dJ11 +
+                          2.0f * a.focal_x * tx * itz3 * dJ02 + 2.0f * a.focal_y * ty * itz3 * dJ12 + dz_view;
+        // t = [mu, 1] @ viewmatrix[:, :3]
+        dmean[0] = dtx * v[0] + dty * v[1] + dtz * v[2];
+        dmean[1] = dtx * v[4] + dty * v[5] + dtz * v[6];
+        dmean[2] = dtx * v[8] + dty * v[9] + dtz * v[10];
+
+        // ---- pixel centre -> NDC -> clip -> mean ---------------------------------------------------
+        dm2[0] = dpx * 0.5f * a.grid.W;
+        dm2[1] = dpy * 0.5f * a.grid.H;
+        const float dhx = dm2[0] * pw, dhy = dm2[1] * pw;
+        const float dhw = -(dm2[0] * hx + dm2[1] * hy) * pw * pw;
+        dmean[0] += dhx * p[0] + dhy * p[1] + dhw * p[3];
+        dmean[1] += dhx * p[4] + dhy * p[5] + dhw * p[7];
+        dmean[2] += dhx * p[8] + dhy * p[9] + dhw * p[11];
+
+        // ---- SH colour ---------------------------------------------------------------------------
+        if (a.shs) {
+            const uint32_t flags = reinterpret_cast<const uint4*>(a.splats + idx)[2].w;
+            const float g[3] = {(flags & 1u) ? 0.f : dcol[0], (flags & 2u) ? 0.f : dcol[1], (flags & 4u) ? 0.f : dcol[2]};
+            const float* cp = a.campos;
+            const float ux = x - cp[0], uy = y - cp[1], uz = z - cp[2];
+            const float inv = 1.0f / sqrtf(ux * ux + uy * uy + uz * uz);
+            const float X = ux * inv, Y = uy * inv, Z = uz * inv;
+            const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+            const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                        C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+            const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                        C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                        C3_6 = -0.5900435899266435f;
+            const int deg = a.sh_degree;
+            const float xx = X * X, yy = Y * Y, zz = Z * Z, xy = X * Y, yz = Y * Z, xz = X * Z;
+            float basis[16], bdx[16], bdy[16], bdz[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { basis[i] = 0.f; bdx[i] = 0.f; bdy[i] = 0.f; bdz[i] = 0.f; }
+            basis[0] = C0;
+            if (deg > 0) {
+                basis[1] = -C1 * Y; bdy[1] = -C1;
+                basis[2] = C1 * Z;  bdz[2] = C1;
+                basis[3] = -C1 * X; bdx[3] = -C1;
+                if (deg > 1) {
+                    basis[4] = C2_0 * xy; bdx[4] = C2_0 * Y; bdy[4] = C2_0 * X;
+                    basis[5] = C2_1 * yz; bdy[5] = C2_1 * Z; bdz[5] = C2_1 * Y;
+                    basis[6] = C2_2 * (2.0f * zz - xx - yy); bdx[6] = -2.0f * C2_2 * X; bdy[6] = -2.0f * C2_2 * Y; bdz[6] = 4.0f * C2_2 * Z;
+                    basis[7] = C2_3 * xz; bdx[7] = C2_3 * Z; bdz[7] = C2_3 * X;
+                    basis[8] = C2_4 * (xx - yy); bdx[8] = 2.0f * C2_4 * X; bdy[8] = -2.0f * C2_4 * Y;
+                    if (deg > 2) {
+                        basis[9] = C3_0 * Y * (3.0f * xx - yy); bdx[9] = C3_0 * 6.0f * xy; bdy[9] = C3_0 * (3.0f * xx - 3.0f * yy);
+                        basis[10] = C3_1 * xy * Z; bdx[10] = C3_1 * yz; bdy[10] = C3_1 * xz; bdz[10] = C3_1 * xy;
+                        basis[11] = C3_2 * Y * (4.0f * zz - xx - yy); bdx[11] = C3_2 * (-2.0f * xy); bdy[11] = C3_2 * (4.0f * zz - xx - 3.0f * yy); bdz[11] = C3_2 * 8.0f * yz;
+                        basis[12] = C3_3 * Z * (2.0f * zz - 3.0f * xx - 3.0f * yy); bdx[12] = C3_3 * (-6.0f * xz); bdy[12] = C3_3 * (-6.0f * yz); bdz[12] = C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+                        basis[13] = C3_4 * X * (4.0f * zz - xx - yy); bdx[13] = C3_4 * (4.0f * zz - 3.0f * xx - yy); bdy[13] = C3_4 * (-2.0f * xy); bdz[13] = C3_4 * 8.0f * xz;
+                        basis[14] = C3_5 * Z * (xx - yy); bdx[14] = C3_5 * 2.0f * xz; bdy[14] = C3_5 * (-2.0f * yz); bdz[14] = C3_5 * (xx - yy);
+                        basis[15] = C3_6 * X * (xx - 3.0f * yy); bdx[15] = C3_6 * (3.0f * xx - 3.0f * yy); bdy[15] = C3_6 * (-6.0f * xy);
+                    }
+                }
+            }
+            const int ncoef = (deg + 1) * (deg + 1);
+            const float* sh = a.shs + (size_t)idx * a.sh_M * 3;
+            float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * a.sh_M * 3 : nullptr;
+            float ddirx = 0.f, ddiry = 0.f, ddirz = 0.f;
+            for (int k = 0; k < a.sh_M; ++k) {
+                const bool on = k < ncoef && k < 16;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (dsh) dsh[k * 3 + c] = on ? basis[k] * g[c] : 0.f;
+                    if (on) {
+                        const float w = sh[k * 3 + c] * g[c];
+                        ddirx += bdx[k] * w; ddiry += bdy[k] * w; ddirz += bdz[k] * w;
+                    }
+                }
+            }
+            // dir = u / |u|
+            const float dot = X * ddirx + Y * ddiry + Z * ddirz;
+            dmean[0] += (ddirx - X * dot) * inv;
+            dmean[1] += (ddiry - Y * dot) * inv;
+            dmean[2] += (ddirz - Z * dot) * inv;
+        }
+    } else if (a.shs && a.dL_dsh) {
+        float* dsh = a.dL_dsh + (size_t)idx * a.sh_M * 3;
+        for (int k = 0; k < a.sh_M * 3; ++k) dsh[k] = 0.f;
+    }
+
+    if (a.dL_dmeans3D) { a.dL_dmeans3D[idx * 3 + 0] = dmean[0]; a.dL_dmeans3D[idx * 3 + 1] = dmean[1]; a.dL_dmeans3D[idx * 3 + 2] = dmean[2]; }
+    if (a.dL_dmeans2D) { a.dL_dmeans2D[idx * 3 + 0] = dm2[0]; a.dL_dmeans2D[idx * 3 + 1] = dm2[1]; a.dL_dmeans2D[idx * 3 + 2] = 0.f; }
+    if (a.dL_dopacity) a.dL_dopacity[idx] = dop;
+    if (a.dL_dcolors) { a.dL_dcolors[idx * 3 + 0] = dcol[0]; a.dL_dcolors[idx * 3 + 1] = dcol[1]; a.dL_dcolors[idx * 3 + 2] = dcol[2]; }
+    if (a.dL_dscales) { a.dL_dscales[idx * 3 + 0] = dscale[0]; a.dL_dscales[idx * 3 + 1] = dscale[1]; a.dL_dscales[idx * 3 + 2] = dscale[2]; }
+    if (a.dL_drotations) reinterpret_cast<float4*>(a.dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    if (a.dL_dcov3D) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.dL_dcov3D[idx * 6 + i] = dcov[i];
+    }
+}
+
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
+    if (a.P == 0) return hipSuccess;
+    preprocess_bwd_kernel<<<(a.P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace exa

@@ -1,0 +1,207 @@
+// Forward per-Gaussian stage for gfx950: cull, EWA projection, conic, radius, tile rect, optional SH
+// colour, splat record, per-tile instance counting.
+//
+// Replaces upstream `preprocessCUDA` of the third-party rasterizer the reference calls at
+// avatar/common/nets/module.py:632-640.  The arithmetic follows
+// oracle/raster_oracle.py::preprocess TERM BY TERM and this file is compiled with
+// -ffp-contract=off, so px/py/conic/radius/rect are bit-identical to the float32 oracle.
+//
+// HBM traffic per Gaussian: reads mean 12 + scale 12 + quat 16 + opacity 4 + colour 12 = 56 B,
+// writes radius 4 + one 64-byte splat record (one line, later gathered whole by the tile kernels).
+#include "common.h"
+
+namespace exa {
+
+__device__ __forceinline__ float sh_channel(int deg, const float* __restrict__ sh, int c,
+                                            float x, float y, float z) {
+    // reference avatar/common/utils/transforms.py:112-167 (polynomials), coefficients [M][3]
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+    const float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                C3_6 = -0.5900435899266435f;
+    float res = C0 * sh[0 * 3 + c];
+    if (deg > 0) {
+        res = res - C1 * y * sh[1 * 3 + c] + C1 * z * sh[2 * 3 + c] - C1 * x * sh[3 * 3 + c];
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + C2_0 * xy * sh[4 * 3 + c] + C2_1 * yz * sh[5 * 3 + c] +
+                  C2_2 * (2.0f * zz - xx - yy) * sh[6 * 3 + c] + C2_3 * xz * sh[7 * 3 + c] +
+                  C2_4 * (xx - yy) * sh[8 * 3 + c];
+            if (deg > 2) {
+                res = res + C3_0 * y * (3.0f * xx - yy) * sh[9 * 3 + c] + C3_1 * xy * z * sh[10 * 3 + c] +
+                      C3_2 * y * (4.0f * zz - xx - yy) * sh[11 * 3 + c] +
+                      C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[12 * 3 + c] +
+                      C3_4 * x * (4.0f * zz - xx - yy) * sh[13 * 3 + c] + C3_5 * z * (xx - yy) * sh[14 * 3 + c] +
+                      C3_6 * x * (xx - 3.0f * yy) * sh[15 * 3 + c];
+            }
+        }
+    }
+    return res;
+}
+
+__global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    const float* __restrict__ v = a.viewmatrix;
+    const float* __restrict__ p = a.projmatrix;
+    const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
+
+    // 1. view space
+    const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
+    const float pvy = ((v[1] * x + v[5] * y) + v[9] * z) + v[13];
+    const float pvz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
+
+    uint4* rec = reinterpret_cast<uint4*>(a.splats + idx);
+    bool visible = pvz > NEAR_CULL;
+    float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    int radius = 0;
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+    if (visible) {
+        // 2. clip space, perspective divide
+        const float hx = ((p[0] * x + p[4] * y) + p[8] * z) + p[12];
+        const float hy = ((p[1] * x + p[5] * y) + p[9] * z) + p[13];
+        const float hw = ((p[3] * x + p[7] * y) + p[11] * z) + p[15];
+        const float pw = 1.0f / (hw + 1e-7f);
+        const float ndcx = hx * pw, ndcy = hy * pw;
+        // 3. 3D covariance
+        float S00, S01, S02, S11, S12, S22;
+        if (a.cov3D_precomp) {
+            const float* c6 = a.cov3D_precomp + idx * 6;
+            S00 = c6[0]; S01 = c6[1]; S02 = c6[2]; S11 = c6[3]; S12 = c6[4]; S22 = c6[5];
+        } else {
+            const float s0 = a.scale_modifier * a.scales[idx * 3 + 0];
+            const float s1 = a.scale_modifier * a.scales[idx * 3 + 1];
+            const float s2 = a.scale_modifier * a.scales[idx * 3 + 2];
+            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
+            const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz), R01 = 2.0f * (qx * qy - qr * qz),
+                        R02 = 2.0f * (qx * qz + qr * qy);
+            const float R10 = 2.0f * (qx * qy + qr * qz), R11 = 1.0f - 2.0f * (qx * qx + qz * qz),
+                        R12 = 2.0f * (qy * qz - qr * qx);
+            const float R20 = 2.0f * (qx * qz - qr * qy), R21 = 2.0f * (qy * qz + qr * qx),
+                        R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+            const float M00 = R00 * s0, M01 = R01 * s1, M02 = R02 * s2;
+            const float M10 = R10 * s0, M11 = R11 * s1, M12 = R12 * s2;
+            const float M20 = R20 * s0, M21 = R21 * s1, M22 = R22 * s2;
+            S00 = (M00 * M00 + M01 * M01) + M02 * M02;
+            S01 = (M00 * M10 + M01 * M11) + M02 * M12;
+            S02 = (M00 * M20 + M01 * M21) + M02 * M22;
+            S11 = (M10 * M10 + M11 * M11) + M12 * M12;
+            S12 = (M10 * M20 + M11 * M21) + M12 * M22;
+            S22 = (M20 * M20 + M21 * M21) + M22 * M22;
+        }
+        // 4. EWA projection
+        const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+        const float tz = pvz;
+        const float tx = fminf(limx, fmaxf(-limx, pvx / tz)) * tz;
+        const float ty = fminf(limy, fmaxf(-limy, pvy / tz)) * tz;
+        const float J00 = a.focal_x / tz, J02 = -(a.focal_x * tx) / (tz * tz);
+        const float J11 = a.focal_y / tz, J12 = -(a.focal_y * ty) / (tz * tz);
+        const float T00 = J00 * v[0] + J02 * v[2], T01 = J00 * v[4] + J02 * v[6], T02 = J00 * v[8] + J02 * v[10];
+        const float T10 = J11 * v[1] + J12 * v[2], T11 = J11 * v[5] + J12 * v[6], T12 = J11 * v[9] + J12 * v[10];
+        const float U00 = (T00 * S00 + T01 * S01) + T02 * S02;
+        const float U01 = (T00 * S01 + T01 * S11) + T02 * S12;
+        const float U02 = (T00 * S02 + T01 * S12) + T02 * S22;
+        const float U10 = (T10 * S00 + T11 * S01) + T12 * S02;
+        const float U11 = (T10 * S01 + T11 * S11) + T12 * S12;
+        const float U12 = (T10 * S02 + T11 * S12) + T12 * S22;
+        const float ca2 = ((U00 * T00 + U01 * T01) + U02 * T02) + LOWPASS;
+        const float cb2 = (U00 * T10 + U01 * T11) + U02 * T12;
+        const float cc2 = ((U10 * T10 + U11 * T11) + U12 * T12) + LOWPASS;
+        const float det = ca2 * cc2 - cb2 * cb2;
+        if (det == 0.0f) {
+            visible = false;
+        } else {
+            const float det_inv = 1.0f / det;
+            ca = cc2 * det_inv; cb = -cb2 * det_inv; cc = ca2 * det_inv;
+            // 5. radius
+            const float mid = 0.5f * (ca2 + cc2);
+            const float lam = mid + sqrtf(fmaxf(mid * mid - det, 0.1f));
+            const float rf = ceilf(3.0f * sqrtf(lam));
+            // 6. pixel centre
+            px = ((ndcx + 1.0f) * a.grid.W - 1.0f) * 0.5f;
+            py = ((ndcy + 1.0f) * a.grid.H - 1.0f) * 0.5f;
+            // 7. tile rect (C float->int truncation, clamped to the grid)
+            const float big = 1048576.0f;
+            auto tr = [&](float t) -> int {
+                t = (t != t) ? 0.0f : fminf(fmaxf(t, -big), big);
+                return (int)t;
+            };
+            x0 = min(a.grid.gx, max(0, tr((px - rf) / TILE)));
+            x1 = min(a.grid.gx, max(0, tr(((px + rf) + (TILE - 1)) / TILE)));
+            y0 = min(a.grid.gy, max(0, tr((py - rf) / TILE)));
+            y1 = min(a.grid.gy, max(0, tr(((py + rf) + (TILE - 1)) / TILE)));
+            radius = (int)fminf(rf, 2147483520.0f);
+            if ((x1 - x0) * (y1 - y0) == 0) visible = false;
+        }
+    }
+    if (!visible) {
+        a.radii[idx] = 0;
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
+    } else {
+        a.radii[idx] = radius;
+        // colour: precomputed, or SH evaluated here (reference module.py:258-266 semantics)
+        float cr, cg, cbl;
+        uint32_t flags = 0;
+        if (a.shs) {
+            const float* cp = a.campos;
+            float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+            const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            dx *= inv; dy *= inv; dz *= inv;
+            const float* sh = a.shs + (size_t)idx * a.sh_M * 3;
+            cr = sh_channel(a.sh_degree, sh, 0, dx, dy, dz) + 0.5f;
+            cg = sh_channel(a.sh_degree, sh, 1, dx, dy, dz) + 0.5f;
+            cbl = sh_channel(a.sh_degree, sh, 2, dx, dy, dz) + 0.5f;
+            if (cr < 0.f) { cr = 0.f; flags |= 1u; }
+            if (cg < 0.f) { cg = 0.f; flags |= 2u; }
+            if (cbl < 0.f) { cbl = 0.f; flags |= 4u; }
+        } else {
+            cr = a.colors_precomp[idx * 3 + 0];
+            cg = a.colors_precomp[idx * 3 + 1];
+            cbl = a.colors_precomp[idx * 3 + 2];
+        }
+        const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
+        rec[0] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pvz), (uint32_t)radius);
+        rec[1] = make_uint4(__float_as_uint(ca), __float_as_uint(cb), __float_as_uint(cc),
+                            __float_as_uint(a.opacities[idx]));
+        rec[2] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cbl), flags);
+        rec[3] = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), tiles, 0u);
+        // per-tile instance counting (first half of the counting sort on the tile digit)
+        uint32_t* cnt = a.counts + (size_t)sub_of(idx) * a.grid.tiles;
+        for (int ty_ = y0; ty_ < y1; ++ty_)
+            for (int tx_ = x0; tx_ < x1; ++tx_)
+                __hip_atomic_fetch_add(cnt + ty_ * a.grid.gx + tx_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // V = number of visible Gaussians: one atomic per wave
+    const unsigned long long m = __ballot(visible);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m))
+        __hip_atomic_fetch_add(&a.header->num_visible, (uint32_t)__popcll(m), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                             const float* __restrict__ v, uint8_t* present) {
+    const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    const float x = means3D[idx * 3 + 0], y = means3D[idx * 3 + 1], z = means3D[idx * 3 + 2];
+    const float pvz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
+    present[idx] = pvz > NEAR_CULL ? 1 : 0;
+}
+
+hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
+    if (a.P == 0) return hipSuccess;
+    preprocess_fwd_kernel<<<(a.P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present,
+                               hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    mark_visible_kernel<<<(P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(P, means3D, viewmatrix, present);
+    return hipGetLastError();
+}
+
+}  // namespace exa

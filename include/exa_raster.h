@@ -1,0 +1,155 @@
+/*
+ * exa_raster.h -- C ABI of the MI355X-native differentiable 3D-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the one native component on ExAvatar's render path: the
+ * third-party CUDA extension `diff_gaussian_rasterization_depth` that the reference imports at
+ * avatar/common/nets/module.py:11 and calls at module.py:623-640 (forward) and through autograd
+ * from avatar/main/train.py:46 (backward).  Upstream binds three C++ entry points through pybind
+ * (`rasterize_gaussians`, `rasterize_gaussians_backward`, `mark_visible`); the functions below are
+ * what a ctypes / cffi / pybind stub binds instead.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, sizes, a `hipStream_t` passed as `void*`.
+ *   - every pointer marked [dev] is a device pointer owned by the caller (PyTorch's caching
+ *     allocator in the Python binding); the library allocates nothing and keeps no state between
+ *     calls, so any number of forward contexts may be live before their backward runs
+ *     (ExAvatar keeps five, avatar/main/model.py:130-162).
+ *   - all floating point is fp32, indices int32/uint32, contiguous row-major tensors with the
+ *     shapes the reference passes (module.py:632-640): means3D[P,3], opacities[P,1], scales[P,3],
+ *     rotations[P,4] (w,x,y,z), colors_precomp[P,3], shs[P,M,3], cov3D_precomp[P,6].
+ *   - work is enqueued on `stream`; no call synchronises the device unless `settings->debug != 0`.
+ *   - return value: 0 = ok; < 0 = invalid argument; > 0 = HIP error code (hipError_t);
+ *     EXA_RASTER_E_OVERFLOW is never returned synchronously -- instance-buffer overflow is
+ *     reported through the device-side header (see exa_raster_forward_render).
+ */
+#ifndef EXA_RASTER_H
+#define EXA_RASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXA_RASTER_VERSION 100          /* 0.1.0 */
+#define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
+
+#define EXA_RASTER_E_INVALID (-1)
+#define EXA_RASTER_E_NULLPTR (-2)
+#define EXA_RASTER_E_WORKSPACE (-3)
+
+/* Mirrors the 12-field `GaussianRasterizationSettings` NamedTuple built at module.py:609-622.
+ * The four tensor-valued fields stay on the device (the reference builds them with torch ops on
+ * the GPU, module.py:604-608), so no host read-back is needed to fill this struct. */
+typedef struct ExaRasterSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    const float* bg;          /* [dev] float[3] */
+    float scale_modifier;
+    const float* viewmatrix;  /* [dev] float[16], row-major of the [4,4] tensor (= world->camera, transposed) */
+    const float* projmatrix;  /* [dev] float[16], row-major of view^T @ proj^T */
+    int32_t sh_degree;
+    const float* campos;      /* [dev] float[3] */
+    int32_t prefiltered;
+    int32_t debug;            /* != 0: hipStreamSynchronize + error check after every kernel */
+} ExaRasterSettings;
+
+/* Byte sizes of the caller-allocated workspaces. */
+typedef struct ExaRasterWorkspaceSizes {
+    uint64_t geom_bytes;   /* per-Gaussian splat records, 64 B * P                         */
+    uint64_t tile_bytes;   /* per-tile counters, cursors, ranges + the device header        */
+    uint64_t bin_bytes;    /* per-instance keys + sorted ids, 12 B * capacity               */
+    uint64_t img_bytes;    /* per-pixel final_T + n_contrib, 8 B * W * H                    */
+    uint64_t grad_bytes;   /* backward scratch: per-Gaussian screen-space accumulators      */
+} ExaRasterWorkspaceSizes;
+
+/* Device-side header at the start of the tile workspace (readable with a 16-byte D2H copy). */
+typedef struct ExaRasterHeader {
+    uint32_t num_rendered;   /* D = sum of tiles touched ("num_rendered" upstream)           */
+    uint32_t overflow;       /* != 0: D exceeded bin capacity, outputs of this call invalid  */
+    uint32_t max_tile_list;  /* longest per-tile list                                        */
+    uint32_t num_visible;    /* V = Gaussians with radius > 0                                */
+} ExaRasterHeader;
+
+int exa_raster_version(void);
+
+/* Thread-local description of the last non-zero status returned on this thread. */
+const char* exa_raster_last_error(void);
+
+/* Sizes for P Gaussians, a W x H image and room for `capacity` tile instances. */
+int exa_raster_workspace_sizes(int32_t P, int32_t W, int32_t H, uint64_t capacity,
+                               ExaRasterWorkspaceSizes* out);
+
+/*
+ * Forward, stage 1 (replaces upstream preprocessCUDA + InclusiveSum): per-Gaussian cull, EWA
+ * projection, radius, tile rect, optional SH colour; per-tile instance counts and their prefix.
+ * After it completes, the header in `tile_ws` holds num_rendered so the caller can size `bin_ws`
+ * (upstream reads the same number back to the host at this point).
+ * Exactly one of shs / colors_precomp and one of (scales+rotations) / cov3D_precomp is non-NULL.
+ */
+int exa_raster_forward_bin(const ExaRasterSettings* settings, int32_t P, int32_t sh_M,
+                           const float* means3D, const float* shs, const float* colors_precomp,
+                           const float* opacities, const float* scales, const float* rotations,
+                           const float* cov3D_precomp,
+                           int32_t* radii,          /* [dev] out int32[P] */
+                           void* geom_ws, void* tile_ws, void* stream);
+
+/*
+ * Forward, stage 2 (replaces duplicateWithKeys + SortPairs + identifyTileRanges + renderCUDA):
+ * scatter instances into per-tile buckets, depth-sort every bucket in LDS, blend front to back.
+ * If the header's num_rendered > capacity nothing is rendered and header.overflow is set.
+ * `store_ctx` != 0 additionally writes what the backward pass needs (sorted ids, final_T,
+ * n_contrib); pass 0 for inference.
+ */
+int exa_raster_forward_render(const ExaRasterSettings* settings, int32_t P,
+                              const void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity,
+                              void* img_ws,
+                              float* out_color,   /* [dev] float[3,H,W] */
+                              float* out_depth,   /* [dev] float[1,H,W] */
+                              float* out_alpha,   /* [dev] float[1,H,W] */
+                              int32_t store_ctx, void* stream);
+
+/* Stage 1 + stage 2 back to back with a fixed capacity: no host round trip, hipGraph-capturable. */
+int exa_raster_forward(const ExaRasterSettings* settings, int32_t P, int32_t sh_M,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, const float* rotations,
+                       const float* cov3D_precomp, int32_t* radii,
+                       void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity, void* img_ws,
+                       float* out_color, float* out_depth, float* out_alpha,
+                       int32_t store_ctx, void* stream);
+
+/*
+ * Backward (replaces upstream BACKWARD::render + BACKWARD::preprocess).  Consumes the workspaces
+ * a forward call with store_ctx != 0 filled.  dL_ddepth / dL_dalpha may be NULL (= zeros; the
+ * ExAvatar training case).  Gradient outputs that do not apply
+ * (dL_dsh without shs, dL_dcov3D without cov3D_precomp, ...) may be NULL.  All non-NULL outputs
+ * are fully written (zeros for culled Gaussians).
+ * dL_dmeans2D[P,3]: (x, y) = dL/dpix * (W/2, H/2), z = 0 -- the densification signal the reference
+ * reads at avatar/main/train.py:51.
+ */
+int exa_raster_backward(const ExaRasterSettings* settings, int32_t P, int32_t sh_M,
+                        const float* means3D, const float* shs, const float* colors_precomp,
+                        const float* opacities, const float* scales, const float* rotations,
+                        const float* cov3D_precomp, const int32_t* radii,
+                        const void* geom_ws, const void* tile_ws, const void* bin_ws,
+                        uint64_t capacity,        /* the capacity bin_ws was carved with in forward */
+                        const void* img_ws,
+                        const float* dL_dcolor,   /* [dev] float[3,H,W] */
+                        const float* dL_ddepth,   /* [dev] float[1,H,W] or NULL */
+                        const float* dL_dalpha,   /* [dev] float[1,H,W] or NULL */
+                        void* grad_ws,
+                        float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity,
+                        float* dL_dscales, float* dL_drotations, float* dL_dsh, float* dL_dcov3D,
+                        void* stream);
+
+/* upstream markVisible: present[i] = (view-space z of means3D[i] > 0.2). */
+int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const float* means3D,
+                            uint8_t* present, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXA_RASTER_H */
