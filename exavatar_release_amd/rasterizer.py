@@ -141,9 +141,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rotations = _f32c(rotations, 'rotations', device)
         cov3Ds_precomp = _f32c(cov3Ds_precomp, 'cov3D_precomp', device)
         sh_M = int(sh.shape[1]) if sh is not None else 0
-        need_ctx = any(t is not None and t.requires_grad for t in
-                       (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
-        need_ctx = need_ctx and torch.is_grad_enabled()
+        need_ctx = any(ctx.needs_input_grad)
 
         keep = []
         with torch.cuda.device(device):
