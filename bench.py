@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path BASELINE.json names: forward + backward differentiable Gaussian
+rasterize at 1024x1024 with ~150 k avatar-like Gaussians (config C3), view-sharded over N GPUs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one `GaussianRasterizer` forward + its backward for one training view with a dense
+dL/dimage (inputs already resident in HBM), followed for N > 1 by the RCCL all-reduce of the
+Gaussian gradients (14 floats x P = 8.4 MB).  Views: the 200 ring cameras of config C4 dealt
+round-robin to the ranks; every rank cycles through its shard, so per-GPU work is fixed as N grows
+(weak scaling) and `value` = views rasterized fwd+bwd per second over all ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+`roofline` (dominant kernel, HIP-event timed inside this script) and `cpu_baseline` (the CPU oracle
+timed on a bounded sample of the same workload, rank 0 at N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_VIEWS = 200
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--config', default='c3', choices=['c3', 'c2', 'c1'])
+    ap.add_argument('--launch', default='graph', choices=['graph', 'eager'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def build_scene(name):
+    from exavatar_release_amd import scenes
+    if name == 'c3':
+        return scenes.dist_b_avatar(150_000, seed=0), (1024, 1024), 'c3: 150k avatar-like Gaussians (Dist-B), 1024x1024'
+    if name == 'c2':
+        return scenes.dist_b_avatar(120_000, seed=0), (960, 540), 'c2: 120k avatar-like Gaussians (Dist-B), 540x960 (WxH)'
+    return scenes.dist_a_random(10_000, 256, 256, seed=0), (256, 256), 'c1: 10k random Gaussians (Dist-A), 256x256'
+
+
+def view_settings(k, shape, device, cfg_name):
+    """GaussianRasterizationSettings of ring view k, built like GaussianRenderer.forward does."""
+    from exavatar_release_amd import scenes
+    from exavatar_release_amd.camera import make_raster_matrices
+    H, W = shape
+    focal = 1500.0 * (H / 1024.0) if cfg_name != 'c2' else 1500.0 * 960 / 1024
+    if cfg_name == 'c1':
+        cam = scenes.neutral_camera(H, W)
+    else:
+        cam = scenes.ring_camera(H, W, k, N_VIEWS, focal=focal)
+    tanx, tany, view, proj, campos = make_raster_matrices(cam, shape)
+    return dict(tanfovx=tanx, tanfovy=tany, view=view, proj=proj, campos=campos)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print('bench.py: --gpus %d needs a torch.distributed.run launch with that many ranks' % args.gpus,
+                  file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=device)
+
+    import exavatar_release_amd as exa
+    from exavatar_release_amd import _lib
+    from exavatar_release_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians
+
+    assets, shape, workload = build_scene(args.config)
+    H, W = shape
+    P = assets['mean_3d'].shape[0]
+
+    # ---- parameters: contiguous leaves; for N > 1 their gradients are packed into ONE flat buffer ----
+    names = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
+    params = [assets[k].to(device).contiguous().requires_grad_(True) for k in names]
+    n_float = sum(p.numel() for p in params)
+    flat_grad = torch.zeros(n_float, device=device)
+    offs, o = [], 0
+    for p_ in params:
+        offs.append((o, o + p_.numel()))
+        o += p_.numel()
+    grad_views = [flat_grad[a_:b_].view_as(p_) for (a_, b_), p_ in zip(offs, params)]
+
+    g = torch.Generator().manual_seed(1)
+    dL_dimg = torch.randn(3, H, W, generator=g).to(device)
+    bg = torch.ones(3, device=device)
+
+    # ---- this rank's shard of the ring views ------------------------------------------------------
+    my_views = list(range(rank, N_VIEWS, world)) if args.config != 'c1' else [0]
+    vs = [view_settings(k, shape, device, args.config) for k in my_views]
+    view_tab = torch.stack([v['view'] for v in vs]).to(device)
+    proj_tab = torch.stack([v['proj'] for v in vs]).to(device)
+    cpos_tab = torch.stack([v['campos'] for v in vs]).to(device)
+    view_s = view_tab[0].clone()
+    proj_s = proj_tab[0].clone()
+    cpos_s = cpos_tab[0].clone()
+    settings = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'], bg=bg,
+        scale_modifier=1.0, viewmatrix=view_s, projmatrix=proj_s, sh_degree=0, campos=cpos_s,
+        prefiltered=False, debug=False)
+    mean_2d = torch.zeros(P, 3, device=device, requires_grad=True)
+
+    def set_view(i):
+        view_s.copy_(view_tab[i])
+        proj_s.copy_(proj_tab[i])
+        cpos_s.copy_(cpos_tab[i])
+
+    def raster_step():
+        """forward + backward of the rasterizer; for N > 1 the gradients are packed for the all-reduce."""
+        m3, sc, rot, op, rgb = params
+        color, radii, depth, alpha = rasterize_gaussians(m3, mean_2d, None, rgb, op, sc, rot, None, settings)
+        grads = torch.autograd.grad([color], params + [mean_2d], grad_outputs=[dL_dimg])
+        if world > 1:
+            torch._foreach_copy_(grad_views, list(grads[:5]))
+        return grads
+
+    # ---- calibrate the instance-buffer capacity over this rank's views (exact mode, untimed) -------
+    probe = range(len(my_views))        # every view of the shard: the capacity below provably covers them
+    # read D and V for every probed view through the C ABI header of a fresh forward_bin
+    D_list, V_list = [], []
+    import ctypes
+    lib = _lib.load()
+    from exavatar_release_amd.rasterizer import _make_settings, _ptr, _stream_ptr
+    sz = _lib.workspace_sizes(P, W, H, 0)
+    geom = torch.empty(int(sz.geom_bytes), dtype=torch.uint8, device=device)
+    tile = torch.empty(int(sz.tile_bytes), dtype=torch.uint8, device=device)
+    radii = torch.empty(P, dtype=torch.int32, device=device)
+    for i in probe:
+        set_view(i)
+        keep = []
+        st = _make_settings(settings, device, keep)
+        m3, sc, rot, op, rgb = [t.detach() for t in params]
+        _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, 0, _ptr(m3), None, _ptr(rgb), _ptr(op), _ptr(sc),
+                                              _ptr(rot), None, _ptr(radii), _ptr(geom), _ptr(tile), _stream_ptr(device)))
+        hdr = tile[:16].view(torch.int32).cpu()
+        D_list.append(int(hdr[0]))
+        V_list.append(int(hdr[3]))
+    D_max, D_mean, V_mean = max(D_list), sum(D_list) / len(D_list), sum(V_list) / len(V_list)
+    exa.config.mode = 'capacity'
+    exa.config.fixed_capacity = int(D_max * 1.3) + 1024
+
+    # ---- optional hipGraph capture of the raster step --------------------------------------------------
+    launch = args.launch
+    graph = None
+    set_view(0)
+    for _ in range(3):
+        raster_step()
+    torch.cuda.synchronize()
+    exa.check_overflow()
+    if launch == 'graph':
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    raster_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            exa.check_overflow()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                raster_step()
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so in the result
+            print('bench.py: hipGraph capture failed (%s); using eager launches' % e, file=sys.stderr)
+            graph = None
+            launch = 'eager'
+
+    pending = [None]
+
+    def step(i):
+        set_view(i % len(my_views))
+        if graph is not None:
+            graph.replay()
+        else:
+            raster_step()
+        if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+
+    def finish():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
+
+    for i in range(args.warmup):
+        step(i)
+    finish()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    finish()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    exa.check_overflow()
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        result = {
+            'metric': 'train iters/sec (fwd+bwd raster) at 1024x1024 / ~150k Gaussians',
+            'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': workload + ', %d ring views sharded round-robin' % N_VIEWS,
+                       'P': P, 'W': W, 'H': H, 'views_per_rank': len(my_views), 'launch': launch,
+                       'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads' % (world, n_float * 4),
+                       'mean_instances_D': D_mean, 'mean_visible_V': V_mean},
+        }
+
+    # ---- per-kernel HIP-event timing (eager, on torch's stream = the stream the kernels run on) -----
+    if rank == 0 and not args.no_kernel_timing:
+        _lib.timing_enable(True)
+        acc = {}
+        reps = 0
+        n_t = min(len(my_views), 20)
+        for i in range(n_t + 2):
+            set_view(i % len(my_views))
+            raster_step()
+            torch.cuda.synchronize()
+            tm = _lib.timing_read()
+            if i >= 2:
+                reps += 1
+                for k, v in tm.items():
+                    acc[k] = acc.get(k, 0.0) + v
+        _lib.timing_enable(False)
+        avg_us = {k: v / reps * 1e3 for k, v in acc.items()}
+        V, D, WH = V_mean, D_mean, W * H
+        alg = {   # algorithmic bytes per launch (DESIGN.md section "Kernels")
+            'preprocess_fwd': 60 * P + 64 * V,
+            'tile_scan': 0,
+            'scatter': 32 * V + 8 * D,
+            'render_fwd': 12 * D + 40 * V + 28 * WH,
+            'render_bwd': 4 * D + 80 * V + 28 * WH,
+            'preprocess_bwd': 64 * V + 60 * V + 68 * P,
+        }
+        dom = max((k for k in avg_us if k in alg and alg[k] > 0), key=lambda k: avg_us[k])
+        achieved = alg[dom] / (avg_us[dom] * 1e-6) / 1e9
+        total_bytes = 128 * P + 252 * V + 44 * D + 56 * WH
+        result['roofline'] = {
+            'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
+            'kernel_avg_us': avg_us,
+            'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),
+                     'achieved_GBs_at_measured_step': total_bytes / (ms_per_step * 1e-3) / 1e9,
+                     'frac_at_measured_step': total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+
+    # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1) ---------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args.config, assets, shape)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg_name, assets, shape, target_instances=40_000, max_threads=16):
+    """Times oracle/raster_oracle.py (fwd + autograd bwd, float32) on a bounded sample: the full
+    per-Gaussian stage plus the tiles nearest the image centre holding ~``target_instances`` tile
+    instances; the per-tile part is scaled by the instance fraction.  Threads are capped at
+    ``max_threads`` (hundreds of OpenMP threads make the oracle's many small tensor ops far slower)."""
+    from exavatar_release_amd import scenes
+    from oracle import raster_oracle as ro
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    H, W = shape
+    focal = 1500.0 * (H / 1024.0) if cfg_name != 'c2' else 1500.0 * 960 / 1024
+    cam = scenes.neutral_camera(H, W) if cfg_name == 'c1' else scenes.ring_camera(H, W, 0, N_VIEWS, focal=focal)
+    g = torch.Generator().manual_seed(1)
+    G = torch.randn(3, H, W, generator=g)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+
+    def run(sub):
+        a = {k: v.clone().requires_grad_(True) for k, v in assets.items()}
+        t0 = time.perf_counter()
+        out = ro.render(a, shape, cam, torch.ones(3), return_aux=True, tile_subset=sub)
+        if out['img'].requires_grad:
+            (out['img'] * G).sum().backward()
+        return time.perf_counter() - t0, out['aux']
+
+    t_pre, aux = run([])                       # per-Gaussian stage + list building only
+    ranges = aux['ranges']
+    counts = (ranges[:, 1] - ranges[:, 0]).tolist()
+    D_total = sum(counts)
+    order = sorted(range(gx * gy), key=lambda t: ((t % gx) - gx / 2 + 0.5) ** 2 + ((t // gx) - gy / 2 + 0.5) ** 2)
+    subset, D_sub = [], 0
+    for t in order:
+        if D_sub >= min(target_instances, D_total):
+            break
+        if counts[t]:
+            subset.append(t)
+            D_sub += counts[t]
+    t_sub, _ = run(subset)
+    frac = D_sub / max(D_total, 1)
+    t_full = t_pre + max(t_sub - t_pre, 0.0) / max(frac, 1e-9)
+    return {'value': 1.0 / t_full, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+            'sample': 'PyTorch CPU oracle fwd+autograd-bwd of view 0 on %d of %d host threads: full per-Gaussian '
+                      'stage (%.2f s) + the %d central tiles holding %.1f%% of the %d tile instances (%.2f s); '
+                      'per-tile part scaled by the instance fraction -> %.1f s per iteration'
+                      % (cores, os.cpu_count() or 1, t_pre, len(subset), 100 * frac, D_total, t_sub, t_full)}
+
+
+if __name__ == '__main__':
+    main()

@@ -59,7 +59,11 @@ SIGNATURES = {
                                                                                   c_void_p, c_void_p] + [c_void_p] * 8
                             + [c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
+    'exa_raster_timing_enable': (ctypes.c_int, [_I32]),
+    'exa_raster_timing_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _I32]),
+    'exa_raster_timing_name': (ctypes.c_char_p, [_I32]),
 }
+TIMING_SLOTS = 8
 
 _lib = None
 
@@ -96,3 +100,15 @@ def workspace_sizes(P, W, H, capacity):
     out = ExaRasterWorkspaceSizes()
     check(load().exa_raster_workspace_sizes(P, W, H, capacity, ctypes.byref(out)))
     return out
+
+
+def timing_enable(on):
+    check(load().exa_raster_timing_enable(int(bool(on))))
+
+
+def timing_read():
+    """{kernel name: milliseconds} of the library's most recent launches (timing must be enabled)."""
+    lib = load()
+    buf = (ctypes.c_float * TIMING_SLOTS)()
+    check(lib.exa_raster_timing_read(buf, TIMING_SLOTS))
+    return {lib.exa_raster_timing_name(i).decode(): float(buf[i]) for i in range(TIMING_SLOTS) if buf[i] >= 0}

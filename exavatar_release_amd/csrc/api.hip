@@ -34,6 +34,29 @@ int debug_sync(const ExaRasterSettings* s, hipStream_t st, const char* where) {
     return 0;
 }
 
+enum { K_MEMSET_TILE, K_PREPROCESS_FWD, K_TILE_SCAN, K_SCATTER, K_RENDER_FWD, K_MEMSET_GRAD, K_RENDER_BWD,
+       K_PREPROCESS_BWD, K_COUNT };
+static_assert(K_COUNT == EXA_RASTER_TIMING_SLOTS, "timing slots");
+const char* const k_names[K_COUNT] = {"memset_tile", "preprocess_fwd", "tile_scan", "scatter", "render_fwd",
+                                      "memset_grad", "render_bwd", "preprocess_bwd"};
+struct Timing {
+    bool enabled = false, created = false;
+    hipEvent_t ev[K_COUNT][2];
+    bool used[K_COUNT] = {};
+};
+Timing g_t;   // process-wide on purpose: autograd runs backward on its own thread
+
+// Enqueue `expr` (a hipError_t expression) bracketed by timing events when timing is on.
+#define EXA_TIMED(slot, expr, where)                                        \
+    do {                                                                    \
+        if (g_t.enabled) EXA_HIP(hipEventRecord(g_t.ev[slot][0], st), where); \
+        EXA_HIP((expr), where);                                             \
+        if (g_t.enabled) {                                                  \
+            EXA_HIP(hipEventRecord(g_t.ev[slot][1], st), where);            \
+            g_t.used[slot] = true;                                          \
+        }                                                                   \
+    } while (0)
+
 int check_settings(const ExaRasterSettings* s) {
     if (!s) return fail(EXA_RASTER_E_NULLPTR, "settings is NULL");
     if (s->image_height < 0 || s->image_width < 0) return fail(EXA_RASTER_E_INVALID, "negative image size");
@@ -95,7 +118,8 @@ int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, 
     const Grid g = make_grid(s->image_width, s->image_height);
     TileWs tw = carve_tile_ws(tile_ws, g.tiles);
     // header + counts are contiguous: one memset node
-    EXA_HIP(hipMemsetAsync(tile_ws, 0, HEADER_BYTES + align256(uint64_t(NSUB) * g.tiles * 4), st), "memset(tile counts)");
+    EXA_TIMED(K_MEMSET_TILE, launch_zero(tile_ws, HEADER_BYTES + align256(uint64_t(NSUB) * g.tiles * 4), st),
+              "memset(tile counts)");
     PreprocessArgs a;
     a.P = P; a.sh_M = sh_M; a.sh_degree = s->sh_degree; a.grid = g;
     a.tanfovx = s->tanfovx; a.tanfovy = s->tanfovy;
@@ -106,9 +130,9 @@ int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, 
     a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
     a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
     a.radii = radii; a.splats = static_cast<Splat*>(geom_ws); a.counts = tw.counts; a.header = tw.header;
-    EXA_HIP(launch_preprocess_fwd(a, st), "preprocess_fwd");
+    EXA_TIMED(K_PREPROCESS_FWD, launch_preprocess_fwd(a, st), "preprocess_fwd");
     if ((rc = debug_sync(s, st, "preprocess_fwd"))) return rc;
-    EXA_HIP(launch_tile_scan(tw, g.tiles, st), "tile_scan");
+    EXA_TIMED(K_TILE_SCAN, launch_tile_scan(tw, g.tiles, st), "tile_scan");
     if ((rc = debug_sync(s, st, "tile_scan"))) return rc;
     return 0;
 }
@@ -126,13 +150,14 @@ int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void*
     const Grid g = make_grid(s->image_width, s->image_height);
     TileWs tw = carve_tile_ws(tile_ws, g.tiles);
     BinWs bw = carve_bin_ws(bin_ws, capacity);
-    EXA_HIP(launch_scatter(P, static_cast<const Splat*>(geom_ws), tw, g.tiles, g.gx, bw, capacity, st), "scatter");
+    EXA_TIMED(K_SCATTER, launch_scatter(P, static_cast<const Splat*>(geom_ws), tw, g.tiles, g.gx, bw, capacity, st),
+              "scatter");
     if ((rc = debug_sync(s, st, "scatter"))) return rc;
     RenderFwdArgs r;
     r.grid = g; r.splats = static_cast<const Splat*>(geom_ws); r.tw = tw; r.bw = bw; r.capacity = capacity;
     r.iw = carve_img_ws(img_ws, g.W, g.H);
     r.bg = s->bg; r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha; r.store_ctx = store_ctx;
-    EXA_HIP(launch_render_fwd(r, st), "render_fwd");
+    EXA_TIMED(K_RENDER_FWD, launch_render_fwd(r, st), "render_fwd");
     if ((rc = debug_sync(s, st, "render_fwd"))) return rc;
     return 0;
 }
@@ -166,7 +191,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     if (!dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Grid g = make_grid(s->image_width, s->image_height);
-    EXA_HIP(hipMemsetAsync(grad_ws, 0, uint64_t(P) * sizeof(GradAcc), st), "memset(grad accumulators)");
+    EXA_TIMED(K_MEMSET_GRAD, launch_zero(grad_ws, uint64_t(P) * sizeof(GradAcc), st), "memset(grad accumulators)");
     RenderBwdArgs r;
     r.grid = g; r.splats = static_cast<const Splat*>(geom_ws);
     r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.tiles);
@@ -174,7 +199,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     r.iw = carve_img_ws(const_cast<void*>(img_ws), g.W, g.H);
     r.bg = s->bg; r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
     r.acc = static_cast<GradAcc*>(grad_ws);
-    EXA_HIP(launch_render_bwd(r, st), "render_bwd");
+    EXA_TIMED(K_RENDER_BWD, launch_render_bwd(r, st), "render_bwd");
     if ((rc = debug_sync(s, st, "render_bwd"))) return rc;
     PreprocessBwdArgs b;
     b.P = P; b.sh_M = sh_M; b.sh_degree = s->sh_degree; b.grid = g;
@@ -188,7 +213,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     b.acc = static_cast<const GradAcc*>(grad_ws);
     b.dL_dmeans2D = dL_dmeans2D; b.dL_dmeans3D = dL_dmeans3D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations; b.dL_dsh = dL_dsh; b.dL_dcov3D = dL_dcov3D;
-    EXA_HIP(launch_preprocess_bwd(b, st), "preprocess_bwd");
+    EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(b, st), "preprocess_bwd");
     if ((rc = debug_sync(s, st, "preprocess_bwd"))) return rc;
     return 0;
 }
@@ -203,5 +228,31 @@ int exa_raster_mark_visible(const ExaRasterSettings* s, int32_t P, const float* 
     EXA_HIP(launch_mark_visible(P, means3D, s->viewmatrix, present, st), "mark_visible");
     return debug_sync(s, st, "mark_visible");
 }
+
+int exa_raster_timing_enable(int32_t on) {
+    if (on && !g_t.created) {
+        for (int i = 0; i < K_COUNT; ++i)
+            for (int j = 0; j < 2; ++j) EXA_HIP(hipEventCreate(&g_t.ev[i][j]), "hipEventCreate");
+        g_t.created = true;
+    }
+    g_t.enabled = on != 0;
+    for (int i = 0; i < K_COUNT; ++i) g_t.used[i] = false;
+    return 0;
+}
+
+int exa_raster_timing_read(float* ms_out, int32_t n) {
+    if (!ms_out) return fail(EXA_RASTER_E_NULLPTR, "ms_out is NULL");
+    for (int i = 0; i < n; ++i) {
+        ms_out[i] = -1.0f;
+        if (i < K_COUNT && g_t.created && g_t.used[i]) {
+            EXA_HIP(hipEventSynchronize(g_t.ev[i][1]), "hipEventSynchronize");
+            EXA_HIP(hipEventElapsedTime(&ms_out[i], g_t.ev[i][0], g_t.ev[i][1]), "hipEventElapsedTime");
+            g_t.used[i] = false;
+        }
+    }
+    return 0;
+}
+
+const char* exa_raster_timing_name(int32_t slot) { return (slot >= 0 && slot < K_COUNT) ? k_names[slot] : ""; }
 
 }  // extern "C"

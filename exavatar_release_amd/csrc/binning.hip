@@ -99,6 +99,21 @@ __global__ __launch_bounds__(BLOCK) void scatter_kernel(int P, const Splat* __re
         }
 }
 
+// Zero `n16` 16-byte words.  Used instead of hipMemsetAsync so that a captured hipGraph contains only
+// kernel nodes (memset nodes of the bundled ROCm runtime misbehaved under capture / replay).
+__global__ __launch_bounds__(BLOCK) void zero_kernel(uint4* __restrict__ p, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const size_t n16 = (bytes + 15) / 16;        // workspaces are 256-byte padded, rounding up is safe
+    const int blocks = (int)((n16 + BLOCK - 1) / BLOCK < 2048 ? (n16 + BLOCK - 1) / BLOCK : 2048);
+    zero_kernel<<<blocks, BLOCK, 0, s>>>(static_cast<uint4*>(p), n16);
+    return hipGetLastError();
+}
+
 hipError_t launch_tile_scan(const TileWs& w, int tiles, hipStream_t s) {
     tile_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(w, tiles);
     return hipGetLastError();

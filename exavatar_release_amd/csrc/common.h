@@ -122,6 +122,7 @@ struct PreprocessArgs {
 hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
+hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
 hipError_t launch_tile_scan(const TileWs& w, int tiles, hipStream_t s);
 hipError_t launch_scatter(int P, const Splat* splats, const TileWs& w, int tiles, int gx, const BinWs& b,
                           uint64_t capacity, hipStream_t s);

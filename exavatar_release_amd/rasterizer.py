@@ -46,11 +46,13 @@ class _Config:
     mode = 'exact'            # 'exact' | 'capacity'
     capacity_growth = 1.5     # capacity mode: head-room over the largest D seen so far
     min_capacity = 1 << 16
+    fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up)
 
 
 config = _Config()
 
 # capacity-mode state, per (device index, P, H, W): largest D observed, pending async read-backs
+_debug_last = {}   # tile workspace / capacity of the most recent forward (developer introspection only)
 _seen_D = {}
 _pending = []     # list of (event, pinned header tensor, key, capacity)
 
@@ -121,6 +123,11 @@ def check_overflow():
     _drain_pending(block=True)
 
 
+def last_header():
+    """(num_rendered, overflow, max_tile_list, num_visible) of the most recent forward (synchronises)."""
+    return tuple(int(v) for v in _debug_last['tile'][:16].view(torch.int32).cpu())
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -168,15 +175,20 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                          capacity, _ptr(img), _ptr(color), _ptr(depth), _ptr(alpha),
                                                          int(need_ctx), stream))
             elif config.mode == 'capacity':
-                _drain_pending()
+                capturing = torch.cuda.is_current_stream_capturing()
+                if not capturing:
+                    _drain_pending()          # event queries are illegal during stream capture
                 key = (device.index, P, H, W)
                 seen = _seen_D.get(key, 0)
-                capacity = max(int(seen * config.capacity_growth), config.min_capacity, 4 * P)
+                if config.fixed_capacity is not None:
+                    capacity = int(config.fixed_capacity)
+                else:
+                    capacity = max(int(seen * config.capacity_growth), config.min_capacity, 4 * P)
                 bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
                                                   _ptr(tile), _ptr(bins), capacity, _ptr(img), _ptr(color),
                                                   _ptr(depth), _ptr(alpha), int(need_ctx), stream))
-                if not torch.cuda.is_current_stream_capturing():
+                if not capturing:
                     host = torch.empty(4, dtype=torch.int32, pin_memory=True)
                     host.copy_(tile[:16].view(torch.int32), non_blocking=True)
                     ev = torch.cuda.Event()
@@ -185,6 +197,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             else:
                 raise ValueError('config.mode must be "exact" or "capacity"')
 
+        _debug_last['tile'] = tile
+        _debug_last['capacity'] = capacity
         ctx.raster_settings = rs
         ctx.need_ctx = need_ctx
         if need_ctx:

@@ -149,6 +149,19 @@ int exa_raster_backward(const ExaRasterSettings* settings, int32_t P, int32_t sh
 int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const float* means3D,
                             uint8_t* present, void* stream);
 
+/*
+ * Optional per-kernel timing for benchmarks (the only state the library ever keeps, process-wide,
+ * off by default, not thread-safe).  While enabled, every kernel / memset the library enqueues is bracketed by a
+ * pair of hipEvents recorded on the caller's stream.  exa_raster_timing_read() synchronises on the
+ * events of the most recent calls and returns their durations in milliseconds (-1 for a slot that
+ * did not run), then clears the slots.  Slot names: exa_raster_timing_name(i), i < EXA_RASTER_TIMING_SLOTS.
+ * Must not be enabled during hipGraph capture.
+ */
+#define EXA_RASTER_TIMING_SLOTS 8
+int exa_raster_timing_enable(int32_t on);
+int exa_raster_timing_read(float* ms_out, int32_t n);
+const char* exa_raster_timing_name(int32_t slot);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,10 +290,13 @@ def build_tile_lists(pre, dtype):
 
 
 def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-              cov3D_precomp=None, settings: OracleSettings = None, dtype=torch.float32, return_aux=False):
+              cov3D_precomp=None, settings: OracleSettings = None, dtype=torch.float32, return_aux=False,
+              tile_subset=None):
     """Full forward. Returns (color[3,H,W], radii[P] int32, depth[1,H,W], alpha[1,H,W]) (+ aux dict).
 
     Argument names / order and output order follow the call at reference module.py:632-640.
+    ``tile_subset`` (iterable of tile ids) restricts the per-tile loop to those tiles (all other
+    pixels stay at the background); used only to time a bounded sample for bench.py's cpu_baseline.
     """
     s = settings
     if (shs is None) == (colors_precomp is None):
@@ -322,7 +325,7 @@ def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales
 
     px, py, conic, z = pre['px'], pre['py'], pre['conic'], pre['depth']
     ranges_l = ranges.tolist()
-    for t in range(gx * gy):
+    for t in (range(gx * gy) if tile_subset is None else tile_subset):
         s0, e0 = ranges_l[t]
         if e0 == s0:
             continue
@@ -426,7 +429,8 @@ def settings_from_camera(cam_param, img_shape, bg, sh_degree=0):
                           sh_degree=sh_degree, campos=cam_pos, prefiltered=False, debug=False)
 
 
-def render(gaussian_assets, img_shape, cam_param, bg=None, dtype=torch.float32, return_aux=False):
+def render(gaussian_assets, img_shape, cam_param, bg=None, dtype=torch.float32, return_aux=False,
+           tile_subset=None):
     """Oracle twin of ``GaussianRenderer.forward`` (reference module.py:592-647), CPU only."""
     if bg is None:
         bg = torch.ones(3)
@@ -436,7 +440,7 @@ def render(gaussian_assets, img_shape, cam_param, bg=None, dtype=torch.float32, 
     res = rasterize(means3D=gaussian_assets['mean_3d'], means2D=mean_2d, shs=None,
                     colors_precomp=gaussian_assets['rgb'], opacities=gaussian_assets['opacity'],
                     scales=gaussian_assets['scale'], rotations=gaussian_assets['rotation'],
-                    cov3D_precomp=None, settings=s, dtype=dtype, return_aux=return_aux)
+                    cov3D_precomp=None, settings=s, dtype=dtype, return_aux=return_aux, tile_subset=tile_subset)
     out = {'img': res[0], 'depthmap': res[2], 'mask': res[3], 'mean_2d': mean_2d,
            'is_vis': res[1] > 0, 'radius': res[1]}
     if return_aux:
