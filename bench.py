@@ -256,13 +256,13 @@ def main():
         _lib.timing_enable(False)
         avg_us = {k: v / reps * 1e3 for k, v in acc.items()}
         V, D, WH = V_mean, D_mean, W * H
-        alg = {   # algorithmic bytes per launch (DESIGN.md section "Kernels")
+        alg = {   # algorithmic bytes per launch (DESIGN.md section "Kernels"; SURVEY.md 8(d) per-unit figures)
             'preprocess_fwd': 60 * P + 64 * V,
-            'tile_scan': 0,
-            'scatter': 32 * V + 8 * D,
+            'cell_scatter': 16 * V + 4 * V + 4 * V,
+            'subtile_bin': 4 * V + 32 * V + 8 * D,
             'render_fwd': 12 * D + 40 * V + 28 * WH,
             'render_bwd': 4 * D + 80 * V + 28 * WH,
-            'preprocess_bwd': 64 * V + 60 * V + 68 * P,
+            'preprocess_bwd': 40 * V + 44 * V + 68 * P,
         }
         dom = max((k for k in avg_us if k in alg and alg[k] > 0), key=lambda k: avg_us[k])
         achieved = alg[dom] / (avg_us[dom] * 1e-6) / 1e9

@@ -34,11 +34,11 @@ int debug_sync(const ExaRasterSettings* s, hipStream_t st, const char* where) {
     return 0;
 }
 
-enum { K_MEMSET_TILE, K_PREPROCESS_FWD, K_TILE_SCAN, K_SCATTER, K_RENDER_FWD, K_MEMSET_GRAD, K_RENDER_BWD,
+enum { K_ZERO, K_PREPROCESS_FWD, K_CELL_SCAN, K_CELL_SCATTER, K_SUBTILE_BIN, K_RENDER_FWD, K_RENDER_BWD,
        K_PREPROCESS_BWD, K_COUNT };
 static_assert(K_COUNT == EXA_RASTER_TIMING_SLOTS, "timing slots");
-const char* const k_names[K_COUNT] = {"memset_tile", "preprocess_fwd", "tile_scan", "scatter", "render_fwd",
-                                      "memset_grad", "render_bwd", "preprocess_bwd"};
+const char* const k_names[K_COUNT] = {"zero", "preprocess_fwd", "cell_scan", "cell_scatter", "subtile_bin",
+                                      "render_fwd", "render_bwd", "preprocess_bwd"};
 struct Timing {
     bool enabled = false, created = false;
     hipEvent_t ev[K_COUNT][2];
@@ -60,8 +60,8 @@ Timing g_t;   // process-wide on purpose: autograd runs backward on its own thre
 int check_settings(const ExaRasterSettings* s) {
     if (!s) return fail(EXA_RASTER_E_NULLPTR, "settings is NULL");
     if (s->image_height < 0 || s->image_width < 0) return fail(EXA_RASTER_E_INVALID, "negative image size");
-    if ((s->image_width + TILE - 1) / TILE > 65535 || (s->image_height + TILE - 1) / TILE > 65535)
-        return fail(EXA_RASTER_E_INVALID, "image too large (tile coordinates are 16-bit)");
+    if (make_grid(s->image_width, s->image_height).cells > MAX_CELLS || s->image_width > 32768 || s->image_height > 32768)
+        return fail(EXA_RASTER_E_INVALID, "image too large (more than 4096 cells of 64x64 pixels)");
     if (!s->bg || !s->viewmatrix || !s->projmatrix || !s->campos)
         return fail(EXA_RASTER_E_NULLPTR, "settings bg/viewmatrix/projmatrix/campos must be device pointers");
     if (!(s->tanfovx > 0.f) || !(s->tanfovy > 0.f)) return fail(EXA_RASTER_E_INVALID, "tanfov must be > 0");
@@ -98,10 +98,10 @@ int exa_raster_workspace_sizes(int32_t P, int32_t W, int32_t H, uint64_t capacit
     if (P < 0 || W < 0 || H < 0) return fail(EXA_RASTER_E_INVALID, "negative size");
     const Grid g = make_grid(W, H);
     out->geom_bytes = align256(uint64_t(P) * sizeof(Splat));
-    out->tile_bytes = tile_ws_bytes(g.tiles);
+    out->tile_bytes = tile_ws_bytes(g.cells, num_chunks(P));
     out->bin_bytes = bin_ws_bytes(capacity);
     out->img_bytes = img_ws_bytes(W, H);
-    out->grad_bytes = align256(uint64_t(P) * sizeof(GradAcc));
+    out->grad_bytes = grad_ws_bytes(capacity);
     return 0;
 }
 
@@ -116,10 +116,9 @@ int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, 
     if (!tile_ws || (P > 0 && (!geom_ws || !radii))) return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Grid g = make_grid(s->image_width, s->image_height);
-    TileWs tw = carve_tile_ws(tile_ws, g.tiles);
-    // header + counts are contiguous: one memset node
-    EXA_TIMED(K_MEMSET_TILE, launch_zero(tile_ws, HEADER_BYTES + align256(uint64_t(NSUB) * g.tiles * 4), st),
-              "memset(tile counts)");
+    TileWs tw = carve_tile_ws(tile_ws, g.cells, num_chunks(P));
+    // header + cell counters + cell cursors are contiguous: one zero-fill
+    EXA_TIMED(K_ZERO, launch_zero(tile_ws, tile_ws_zero_bytes(g.cells), st), "zero(tile counters)");
     PreprocessArgs a;
     a.P = P; a.sh_M = sh_M; a.sh_degree = s->sh_degree; a.grid = g;
     a.tanfovx = s->tanfovx; a.tanfovy = s->tanfovy;
@@ -129,11 +128,11 @@ int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, 
     a.viewmatrix = s->viewmatrix; a.projmatrix = s->projmatrix; a.campos = s->campos;
     a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
     a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
-    a.radii = radii; a.splats = static_cast<Splat*>(geom_ws); a.counts = tw.counts; a.header = tw.header;
+    a.radii = radii; a.splats = static_cast<Splat*>(geom_ws); a.tw = tw;
     EXA_TIMED(K_PREPROCESS_FWD, launch_preprocess_fwd(a, st), "preprocess_fwd");
     if ((rc = debug_sync(s, st, "preprocess_fwd"))) return rc;
-    EXA_TIMED(K_TILE_SCAN, launch_tile_scan(tw, g.tiles, st), "tile_scan");
-    if ((rc = debug_sync(s, st, "tile_scan"))) return rc;
+    EXA_TIMED(K_CELL_SCAN, launch_cell_scan(tw, g, num_chunks(P), st), "cell_scan");
+    if ((rc = debug_sync(s, st, "cell_scan"))) return rc;
     return 0;
 }
 
@@ -148,11 +147,13 @@ int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void*
     if (!out_color || !out_depth || !out_alpha) return fail(EXA_RASTER_E_NULLPTR, "output image is NULL");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Grid g = make_grid(s->image_width, s->image_height);
-    TileWs tw = carve_tile_ws(tile_ws, g.tiles);
+    TileWs tw = carve_tile_ws(tile_ws, g.cells, num_chunks(P));
     BinWs bw = carve_bin_ws(bin_ws, capacity);
-    EXA_TIMED(K_SCATTER, launch_scatter(P, static_cast<const Splat*>(geom_ws), tw, g.tiles, g.gx, bw, capacity, st),
-              "scatter");
-    if ((rc = debug_sync(s, st, "scatter"))) return rc;
+    Splat* splats = static_cast<Splat*>(const_cast<void*>(geom_ws));   // cell_scatter fills Splat::inst_off
+    EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(P, splats, tw, g, bw, capacity, st), "cell_scatter");
+    if ((rc = debug_sync(s, st, "cell_scatter"))) return rc;
+    EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(splats, tw, g, bw, capacity, st), "subtile_bin");
+    if ((rc = debug_sync(s, st, "subtile_bin"))) return rc;
     RenderFwdArgs r;
     r.grid = g; r.splats = static_cast<const Splat*>(geom_ws); r.tw = tw; r.bw = bw; r.capacity = capacity;
     r.iw = carve_img_ws(img_ws, g.W, g.H);
@@ -191,14 +192,13 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     if (!dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Grid g = make_grid(s->image_width, s->image_height);
-    EXA_TIMED(K_MEMSET_GRAD, launch_zero(grad_ws, uint64_t(P) * sizeof(GradAcc), st), "memset(grad accumulators)");
     RenderBwdArgs r;
     r.grid = g; r.splats = static_cast<const Splat*>(geom_ws);
-    r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.tiles);
+    r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.cells, num_chunks(P));
     r.bw = carve_bin_ws(const_cast<void*>(bin_ws), capacity);
     r.iw = carve_img_ws(const_cast<void*>(img_ws), g.W, g.H);
     r.bg = s->bg; r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
-    r.acc = static_cast<GradAcc*>(grad_ws);
+    r.partials = static_cast<Partial*>(grad_ws);
     EXA_TIMED(K_RENDER_BWD, launch_render_bwd(r, st), "render_bwd");
     if ((rc = debug_sync(s, st, "render_bwd"))) return rc;
     PreprocessBwdArgs b;
@@ -210,7 +210,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     b.viewmatrix = s->viewmatrix; b.projmatrix = s->projmatrix; b.campos = s->campos;
     b.means3D = means3D; b.shs = shs; b.opacities = opacities; b.scales = scales; b.rotations = rotations;
     b.cov3D_precomp = cov3D_precomp; b.radii = radii; b.splats = static_cast<const Splat*>(geom_ws);
-    b.acc = static_cast<const GradAcc*>(grad_ws);
+    b.partials = static_cast<const Partial*>(grad_ws);
     b.dL_dmeans2D = dL_dmeans2D; b.dL_dmeans3D = dL_dmeans3D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
     b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations; b.dL_dsh = dL_dsh; b.dL_dcov3D = dL_dcov3D;
     EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(b, st), "preprocess_bwd");

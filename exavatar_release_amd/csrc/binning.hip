@@ -1,15 +1,18 @@
-// Tile binning for gfx950: the "duplicate then radix sort" of the upstream rasterizer restructured
-// as an MSD radix sort whose first digit is the tile id:
-//   count  (in preprocess_fwd.hip)  per-(sub-counter, tile) instance counts           -- histogram
-//   scan   (tile_scan_kernel)       exclusive prefix over (tile, sub) -> bucket cursors and ranges
-//   scatter(scatter_kernel)         every Gaussian writes (depth bits << 32 | id) into its tiles' buckets
-// The remaining 32 depth bits are sorted per bucket inside LDS by the render kernel
-// (render_fwd.hip), which reproduces the order of upstream's stable global sort on
-// (tile << 32 | depth bits): ascending depth, ties by ascending Gaussian id.
+// Binning for gfx950: the "duplicate then radix sort" of the upstream rasterizer restructured as an
+// MSD radix sort with LDS-resident histograms:
+//   digit 1 = 64x64-px cell     histogram in preprocess_fwd.hip (one u64 atomic per (chunk, cell)),
+//                               prefix in cell_scan_kernel, scatter of Gaussian ids in cell_scatter_kernel
+//   digit 2 = 8x8-px sub-tile   subtile_bin_kernel: one workgroup per cell, counts / prefix / ranks in LDS,
+//                               emits (depth bits << 32 | id) keys grouped by sub-tile
+//   digit 3 = depth (+ id)      sorted per sub-tile inside LDS by the render kernel (render_fwd.hip)
+// which reproduces the order of upstream's stable global sort on (tile << 32 | depth bits): ascending
+// depth, ties by ascending Gaussian id.  Device-scope atomics (slow on MI355X) are used once per
+// (512-Gaussian chunk, cell) pair, never per instance.
 //
-// Replaces upstream InclusiveSum + duplicateWithKeys + SortPairs(tile digit) + identifyTileRanges
-// (SURVEY.md section 2.1).  HBM traffic: scan 2 * 4 * NSUB * tiles B; scatter reads 32 B of each
-// visible splat record and writes 8 B per instance.
+// Replaces upstream InclusiveSum + duplicateWithKeys + SortPairs(tile digit) + identifyTileRanges of the
+// rasterizer behind reference avatar/common/nets/module.py:632-640.
+// HBM traffic: reads 16 B of every visible splat record twice, writes 4 B per cell entry and 8 B per
+// instance, 4 B inst_off per Gaussian; scans are O(cells + chunks).
 #include "common.h"
 
 namespace exa {
@@ -26,84 +29,175 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// One workgroup: tiles*NSUB counters -> cursors (exclusive prefix in (tile, sub) order), tile ranges,
-// header {num_rendered, max_tile_list}.
-__global__ __launch_bounds__(SCAN_THREADS) void tile_scan_kernel(TileWs w, int tiles) {
-    __shared__ uint32_t s_wave[SCAN_THREADS / 64];
-    __shared__ uint32_t s_max[SCAN_THREADS / 64];
-    const int tid = threadIdx.x;
-    const int per = (tiles + SCAN_THREADS - 1) / SCAN_THREADS;
-    const int t0 = min(tid * per, tiles), t1 = min(t0 + per, tiles);
-    uint32_t sum = 0, mx = 0;
-    for (int t = t0; t < t1; ++t) {
-        uint32_t ts = 0;
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) ts += w.counts[(size_t)s * tiles + t];
-        sum += ts;
-        mx = max(mx, ts);
-    }
-    const uint32_t incl = wave_incl_scan(sum);
-    uint32_t wmx = mx;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) wmx = max(wmx, __shfl_xor(wmx, d, 64));
-    const int wave = tid >> 6, lane = tid & 63;
-    if (lane == 63) { s_wave[wave] = incl; s_max[wave] = wmx; }
+// Exclusive scan of one value per thread across the workgroup; `total` receives the workgroup sum.
+// s_tmp needs (blockDim / 64) entries.  Ends with a barrier, s_tmp may be reused immediately.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_tmp, uint32_t& total) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) s_tmp[wave] = incl;
     __syncthreads();
-    uint32_t base = 0, total = 0, gmx = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_THREADS / 64; ++i) {
-        const uint32_t ws = s_wave[i];
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < nw; ++i) {
+        const uint32_t ws = s_tmp[i];
         if (i < wave) base += ws;
-        total += ws;
-        gmx = max(gmx, s_max[i]);
+        tot += ws;
     }
-    uint32_t run = base + incl - sum;
-    for (int t = t0; t < t1; ++t) {
-        const uint32_t begin = run;
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) {
-            const size_t o = (size_t)s * tiles + t;
-            w.cursor[o] = run;
-            run += w.counts[o];
-        }
-        w.ranges[t] = make_uint2(begin, run);
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+// Zero `n16` 16-byte words.  Used instead of hipMemsetAsync so that a captured hipGraph contains only
+// kernel nodes (memset nodes of the bundled ROCm runtime did not re-zero the buffer on replay).
+__global__ __launch_bounds__(BLOCK) void zero_kernel(uint4* __restrict__ p, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+// One workgroup: exclusive prefix of the per-cell (entries, instances) totals and of the per-chunk
+// instance counts; header.num_rendered = total instances.
+__global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int cells, int chunks) {
+    __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
+    const int tid = threadIdx.x;
+    uint32_t carry_e = 0, carry_i = 0;
+    for (int base = 0; base < cells; base += SCAN_THREADS) {
+        const int c = base + tid;
+        const unsigned long long v = c < cells ? w.cell_cnt[c] : 0ull;
+        const uint32_t e = (uint32_t)v, n = (uint32_t)(v >> 32);
+        uint32_t te, ti;
+        const uint32_t xe = block_excl_scan(e, s_tmp, te);
+        const uint32_t xi = block_excl_scan(n, s_tmp, ti);
+        if (c < cells) w.cell_off[c] = make_uint2(carry_e + xe, carry_i + xi);
+        carry_e += te;
+        carry_i += ti;
     }
     if (tid == 0) {
-        w.header->num_rendered = total;
-        w.header->max_tile_list = gmx;
+        w.cell_off[cells] = make_uint2(carry_e, carry_i);
+        w.header->num_rendered = carry_i;
+        w.header->max_tile_list = carry_e;     // reused slot: number of (Gaussian, cell) entries
+    }
+    uint32_t carry = 0;
+    for (int base = 0; base < chunks; base += SCAN_THREADS) {
+        const int c = base + tid;
+        const uint32_t v = c < chunks ? w.chunk_inst[c] : 0u;
+        uint32_t t;
+        const uint32_t x = block_excl_scan(v, s_tmp, t);
+        if (c < chunks) w.chunk_off[c] = carry + x;
+        carry += t;
     }
 }
 
-// One thread per Gaussian: emit (depth bits << 32 | id) into every touched tile's bucket.
-__global__ __launch_bounds__(BLOCK) void scatter_kernel(int P, const Splat* __restrict__ splats, TileWs w, int tiles,
-                                                        int gx, BinWs b, uint64_t capacity) {
+// CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
+// into the splat record, (b) Gaussian ids scattered into their cells' buckets; bucket ranges are reserved
+// with one returning atomic per (chunk, non-empty cell), ranks inside the reservation come from LDS atomics.
+__global__ __launch_bounds__(BLOCK) void cell_scatter_kernel(int P, Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
+                                                             uint64_t capacity) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // cnt[cells] | base[cells] | cnt2[cells]
+    __shared__ uint32_t s_tmp[BLOCK / 64];
     const uint32_t D = w.header->num_rendered;
     if ((uint64_t)D > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) w.header->overflow = 1u;
         return;
     }
-    const int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= P) return;
-    const uint4* rec = reinterpret_cast<const uint4*>(splats + idx);
-    const uint4 r3 = rec[3];
-    if (r3.z == 0) return;
-    const uint4 r0 = rec[0];
-    const unsigned long long key = ((unsigned long long)r0.z << 32) | (uint32_t)idx;
-    const int x0 = r3.x & 0xffff, x1 = r3.x >> 16, y0 = r3.y & 0xffff, y1 = r3.y >> 16;
-    uint32_t* cur = w.cursor + (size_t)sub_of(idx) * tiles;
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            const uint32_t pos = __hip_atomic_fetch_add(cur + ty * gx + tx, 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-            b.keys[pos] = key;
+    uint32_t* s_cnt = s_dyn;
+    uint32_t* s_base = s_dyn + g.cells;
+    uint32_t* s_cnt2 = s_dyn + 2 * g.cells;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < 3 * g.cells; c += BLOCK) s_dyn[c] = 0u;
+    __syncthreads();
+
+    constexpr int PER = CHUNK / BLOCK;
+    uint4 r3[PER];
+    int ids[PER];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        ids[it] = blockIdx.x * CHUNK + it * BLOCK + tid;
+        r3[it] = make_uint4(0, 0, 0, 0);
+        if (ids[it] < P) r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
+        mine += r3[it].z;
+    }
+    uint32_t total;
+    uint32_t off = w.chunk_off[blockIdx.x] + block_excl_scan(mine, s_tmp, total);
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        if (r3[it].z) {
+            splats[ids[it]].inst_off = off;
+            off += r3[it].z;
+            const int sx0 = r3[it].x & 0xffff, sx1 = r3[it].x >> 16, sy0 = r3[it].y & 0xffff, sy1 = r3[it].y >> 16;
+            for (int cy = sy0 >> 3; cy <= (sy1 - 1) >> 3; ++cy)
+                for (int cx = sx0 >> 3; cx <= (sx1 - 1) >> 3; ++cx)
+                    __hip_atomic_fetch_add(&s_cnt[cy * g.cx + cx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    }
+    __syncthreads();
+    for (int c = tid; c < g.cells; c += BLOCK) {
+        const uint32_t n = s_cnt[c];
+        if (n)
+            s_base[c] = w.cell_off[c].x +
+                        __hip_atomic_fetch_add(&w.cell_cursor[c], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PER; ++it) {
+        if (r3[it].z) {
+            const int sx0 = r3[it].x & 0xffff, sx1 = r3[it].x >> 16, sy0 = r3[it].y & 0xffff, sy1 = r3[it].y >> 16;
+            for (int cy = sy0 >> 3; cy <= (sy1 - 1) >> 3; ++cy)
+                for (int cx = sx0 >> 3; cx <= (sx1 - 1) >> 3; ++cx) {
+                    const int c = cy * g.cx + cx;
+                    const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[c], 1u, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_WORKGROUP);
+                    b.bucket[s_base[c] + r] = (uint32_t)ids[it];
+                }
+        }
+    }
 }
 
-// Zero `n16` 16-byte words.  Used instead of hipMemsetAsync so that a captured hipGraph contains only
-// kernel nodes (memset nodes of the bundled ROCm runtime misbehaved under capture / replay).
-__global__ __launch_bounds__(BLOCK) void zero_kernel(uint4* __restrict__ p, size_t n16) {
-    const size_t stride = (size_t)gridDim.x * BLOCK;
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
+// One workgroup per cell: second radix digit.  Counts the cell's entries per 8x8 sub-tile in LDS, turns
+// the counts into [begin, end) ranges (cell-major sub-tile order) and scatters the sort keys.
+__global__ __launch_bounds__(BLOCK) void subtile_bin_kernel(const Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
+                                                            uint64_t capacity) {
+    __shared__ uint32_t s_cnt[SUBS_PER_CELL];
+    __shared__ uint32_t s_off[SUBS_PER_CELL];
+    __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
+    const int cell = blockIdx.x, tid = threadIdx.x;
+    const bool overflow = (uint64_t)w.header->num_rendered > capacity;
+    const uint2 o0 = w.cell_off[cell], o1 = w.cell_off[cell + 1];
+    const uint32_t e0 = o0.x, e1 = overflow ? o0.x : o1.x;
+    if (tid < SUBS_PER_CELL) { s_cnt[tid] = 0u; s_cnt2[tid] = 0u; }
+    __syncthreads();
+    const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
+    for (uint32_t e = e0 + tid; e < e1; e += BLOCK) {
+        const uint4 r3 = reinterpret_cast<const uint4*>(splats + b.bucket[e])[3];
+        const int x0 = max((int)(r3.x & 0xffff) - csx0, 0), x1 = min((int)(r3.x >> 16) - csx0, CELL_SUBS);
+        const int y0 = max((int)(r3.y & 0xffff) - csy0, 0), y1 = min((int)(r3.y >> 16) - csy0, CELL_SUBS);
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x)
+                __hip_atomic_fetch_add(&s_cnt[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t n = s_cnt[tid];
+        const uint32_t incl = wave_incl_scan(n);
+        const uint32_t begin = overflow ? 0u : o0.y + incl - n;
+        s_off[tid] = begin;
+        w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
+    }
+    __syncthreads();
+    for (uint32_t e = e0 + tid; e < e1; e += BLOCK) {
+        const uint32_t id = b.bucket[e];
+        const uint4* rec = reinterpret_cast<const uint4*>(splats + id);
+        const uint4 r3 = rec[3];
+        const unsigned long long key = ((unsigned long long)rec[0].z << 32) | id;
+        const int x0 = max((int)(r3.x & 0xffff) - csx0, 0), x1 = min((int)(r3.x >> 16) - csx0, CELL_SUBS);
+        const int y0 = max((int)(r3.y & 0xffff) - csy0, 0), y1 = min((int)(r3.y >> 16) - csy0, CELL_SUBS);
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const int s = y * CELL_SUBS + x;
+                const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                b.keys[s_off[s] + r] = key;
+            }
+    }
 }
 
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
@@ -114,15 +208,22 @@ hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_tile_scan(const TileWs& w, int tiles, hipStream_t s) {
-    tile_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(w, tiles);
+hipError_t launch_cell_scan(const TileWs& w, const Grid& g, int chunks, hipStream_t s) {
+    cell_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(w, g.cells, chunks);
     return hipGetLastError();
 }
 
-hipError_t launch_scatter(int P, const Splat* splats, const TileWs& w, int tiles, int gx, const BinWs& b,
-                          uint64_t capacity, hipStream_t s) {
+hipError_t launch_cell_scatter(int P, Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
+                               hipStream_t s) {
     if (P == 0) return hipSuccess;
-    scatter_kernel<<<(P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(P, splats, w, tiles, gx, b, capacity);
+    cell_scatter_kernel<<<num_chunks(P), BLOCK, (size_t)g.cells * 12, s>>>(P, splats, w, g, b, capacity);
+    return hipGetLastError();
+}
+
+hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
+                              hipStream_t s) {
+    if (g.cells == 0) return hipSuccess;
+    subtile_bin_kernel<<<g.cells, BLOCK, 0, s>>>(splats, w, g, b, capacity);
     return hipGetLastError();
 }
 

@@ -1,6 +1,13 @@
 // Shared device/host definitions of the gfx950 rasterizer (internal; the public ABI is
-// include/exa_raster.h).  Wave = 64 lanes, workgroup = 256 threads = one 16x16 pixel tile,
-// wave w of a tile owns the 16x4 pixel strip of rows 4w..4w+3 (64-byte image row segments).
+// include/exa_raster.h).
+//
+// Geometry of the pipeline (wave = 64 lanes):
+//   sub-tile  = 8x8 pixels  = ONE wave (lane l -> pixel (l & 7, l >> 3)); all per-pixel kernels are
+//               barrier-free, every wave owns its list, its LDS slice and its pixels.
+//   cell      = 8x8 sub-tiles = 64x64 pixels; the unit of the first radix digit of the binning.
+//   upstream's 16x16 tile only survives as the *semantic* clip rectangle of a Gaussian
+//   (oracle step 7): a Gaussian is binned to the sub-tiles that lie inside its 16x16-tile rect AND
+//   intersect the exact bounding box of {alpha >= 1/255}, which yields the same per-pixel result.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -8,10 +15,15 @@
 
 namespace exa {
 
-constexpr int TILE = EXA_RASTER_TILE;
-constexpr int BLOCK = 256;          // threads per workgroup
-constexpr int NSUB = 8;             // sub-counters per tile (spreads same-address atomic contention)
-constexpr int SORT_CAP = 4096;      // per-tile list length sorted inside LDS (32 KiB of keys)
+constexpr int TILE = EXA_RASTER_TILE;      // upstream tile (clip rect granularity)
+constexpr int SUB = 8;                     // sub-tile edge in pixels
+constexpr int CELL_SUBS = 8;               // sub-tiles per cell edge
+constexpr int CELL = SUB * CELL_SUBS;      // 64 px
+constexpr int SUBS_PER_CELL = CELL_SUBS * CELL_SUBS;   // 64
+constexpr int BLOCK = 256;                 // threads per workgroup (4 waves)
+constexpr int CHUNK = 512;                 // Gaussians per workgroup in the per-Gaussian binning kernels
+constexpr int MAX_CELLS = 8192;            // LDS histogram budget (64 KiB of u64) -> images up to ~5700^2
+constexpr int SORT_CAP = 1024;             // per-sub-tile list length sorted inside LDS (8 KiB of keys per wave)
 constexpr int HEADER_BYTES = 256;
 
 constexpr float NEAR_CULL = 0.2f;
@@ -19,70 +31,96 @@ constexpr float LOWPASS = 0.3f;
 constexpr float ALPHA_MAX = 0.99f;
 constexpr float ALPHA_MIN = 1.0f / 255.0f;
 constexpr float T_EPS = 1e-4f;
+constexpr float LOG2E = 1.4426950408889634f;
 
-// 64-byte per-Gaussian splat record: one cache line per gather in the per-tile kernels.
+// 64-byte per-Gaussian splat record: one cache line per gather in the per-pixel kernels.
 struct alignas(64) Splat {
     float px, py, depth; int32_t radius;          // row 0
-    float ca, cb, cc, opacity;                    // row 1: conic (A, B, C) + opacity
+    float ca, cb, cc, opacity;                    // row 1: conic (A, B, C) * log2(e), opacity
     float r, g, b; uint32_t flags;                // row 2: colour + SH clamp bits (bit c: channel c clamped)
-    uint32_t rect_x, rect_y, tiles, pad;          // row 3: x0 | x1 << 16, y0 | y1 << 16, tiles touched
+    uint32_t sub_x, sub_y, n_inst, inst_off;      // row 3: sx0 | sx1 << 16, sy0 | sy1 << 16 (sub-tile rect,
+                                                  //        exclusive upper), instances, Gaussian-major offset
 };
 static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 
-// Per-Gaussian screen-space gradient accumulator written by render-backward (atomics), 64 B.
-struct alignas(64) GradAcc {
-    float dpx, dpy;          // dL/d(pixel centre), pixel units
-    float dA, dB, dC;        // dL/d(conic)
-    float dop;               // dL/d(opacity)
-    float dr, dg, db;        // dL/d(colour)
-    float dz;                // dL/d(view-space depth)
-    float pad[6];
+// Per-instance partial gradient written (plain stores, no atomics) by render-backward: the ten sums over
+// the 64 pixels of one sub-tile.  Indexed Gaussian-major: inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).
+struct alignas(16) Partial {
+    float mx, my;            // sum s*dx, sum s*dy          (s = dL/dG * G)
+    float mxx, mxy, myy;     // sum s*dx^2, s*dx*dy, s*dy^2
+    float dop;               // sum G * dL/dalpha
+    float dr, dg, db;        // sum alpha*T * dL/dC
+    float dz;                // sum alpha*T * dL/dDepth
+    float pad0, pad1;
 };
-static_assert(sizeof(GradAcc) == 64, "GradAcc must be one 64-byte line");
+static_assert(sizeof(Partial) == 48, "Partial is three 16-byte rows");
 
 struct Grid {
-    int W, H, gx, gy, tiles;
+    int W, H;
+    int gx, gy;        // upstream 16x16 tile grid
+    int sx, sy;        // sub-tile grid (8x8 px)
+    int cx, cy, cells; // cell grid (64x64 px)
+    int subtiles;      // cells * 64 (cell-major sub-tile index space, includes padding sub-tiles)
 };
 __host__ __device__ inline Grid make_grid(int W, int H) {
     Grid g;
     g.W = W; g.H = H;
     g.gx = (W + TILE - 1) / TILE;
     g.gy = (H + TILE - 1) / TILE;
-    g.tiles = g.gx * g.gy;
+    g.sx = (W + SUB - 1) / SUB;
+    g.sy = (H + SUB - 1) / SUB;
+    g.cx = (W + CELL - 1) / CELL;
+    g.cy = (H + CELL - 1) / CELL;
+    g.cells = g.cx * g.cy;
+    g.subtiles = g.cells * SUBS_PER_CELL;
     return g;
 }
 
-// Layout of the tile workspace (all sections 256-byte aligned).
-struct TileWs {
-    ExaRasterHeader* header;     // [1] (+ padding to HEADER_BYTES)
-    uint32_t* counts;            // [NSUB][tiles]   instances per (sub-counter, tile)
-    uint32_t* cursor;            // [NSUB][tiles]   exclusive prefix, advanced by the scatter pass
-    uint2* ranges;               // [tiles]         [begin, end) into the instance arrays
-    uint32_t* max_contrib;       // [tiles]         last list position any pixel of the tile blended
-};
 __host__ __device__ inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
-__host__ __device__ inline uint64_t tile_ws_bytes(int tiles) {
-    return HEADER_BYTES + 2 * align256(uint64_t(NSUB) * tiles * 4) + align256(uint64_t(tiles) * 8) +
-           align256(uint64_t(tiles) * 4);
+__host__ __device__ inline int num_chunks(int P) { return (P + CHUNK - 1) / CHUNK; }
+
+// Layout of the tile workspace (all sections 256-byte aligned).  [zeroed] sections are cleared by the
+// first kernel of every forward.
+struct TileWs {
+    ExaRasterHeader* header;          // [1]                      [zeroed]
+    unsigned long long* cell_cnt;     // [cells]  inst << 32 | entries            [zeroed]
+    uint32_t* cell_cursor;            // [cells]  entries already placed per cell [zeroed]
+    uint2* cell_off;                  // [cells + 1]  exclusive prefix (entries, instances)
+    uint32_t* chunk_inst;             // [chunks]     instances emitted by each 512-Gaussian chunk
+    uint32_t* chunk_off;              // [chunks]     exclusive prefix of chunk_inst
+    uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays
+    uint32_t* max_contrib;            // [subtiles]   last list position any pixel of the sub-tile blended
+};
+__host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
+    return HEADER_BYTES + align256(uint64_t(cells) * 8) + align256(uint64_t(cells) * 4);
 }
-__host__ __device__ inline TileWs carve_tile_ws(void* base, int tiles) {
+__host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
+    return tile_ws_zero_bytes(cells) + align256(uint64_t(cells + 1) * 8) + 2 * align256(uint64_t(chunks + 1) * 4) +
+           align256(uint64_t(cells) * SUBS_PER_CELL * 8) + align256(uint64_t(cells) * SUBS_PER_CELL * 4);
+}
+__host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
     TileWs w;
     w.header = reinterpret_cast<ExaRasterHeader*>(p); p += HEADER_BYTES;
-    w.counts = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(NSUB) * tiles * 4);
-    w.cursor = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(NSUB) * tiles * 4);
-    w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(tiles) * 8);
+    w.cell_cnt = reinterpret_cast<unsigned long long*>(p); p += align256(uint64_t(cells) * 8);
+    w.cell_cursor = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
+    w.cell_off = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells + 1) * 8);
+    w.chunk_inst = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
+    w.chunk_off = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
+    w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.max_contrib = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 
-// bin workspace: keys[capacity] (u64: depth bits << 32 | gaussian id), then sorted ids[capacity].
-__host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) { return align256(cap * 8) + align256(cap * 4); }
-struct BinWs { unsigned long long* keys; uint32_t* sorted; };
+// bin workspace: keys[cap] (u64: depth bits << 32 | gaussian id), sorted ids[cap], cell buckets[cap].
+__host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) { return align256(cap * 8) + 2 * align256(cap * 4); }
+struct BinWs { unsigned long long* keys; uint32_t* sorted; uint32_t* bucket; };
 __host__ __device__ inline BinWs carve_bin_ws(void* base, uint64_t cap) {
     BinWs b;
-    b.keys = static_cast<unsigned long long*>(base);
-    b.sorted = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + align256(cap * 8));
+    char* p = static_cast<char*>(base);
+    b.keys = reinterpret_cast<unsigned long long*>(p); p += align256(cap * 8);
+    b.sorted = reinterpret_cast<uint32_t*>(p); p += align256(cap * 4);
+    b.bucket = reinterpret_cast<uint32_t*>(p);
     return b;
 }
 
@@ -96,18 +134,41 @@ __host__ __device__ inline ImgWs carve_img_ws(void* base, int W, int H) {
     return i;
 }
 
-// Which sub-counter a Gaussian uses: constant per 256-Gaussian block, identical in count and scatter.
-__host__ __device__ inline int sub_of(int gaussian) { return (gaussian >> 8) & (NSUB - 1); }
+// backward scratch: one Partial per instance.
+__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * sizeof(Partial)); }
 
-// The two per-(pixel, Gaussian) expressions shared by render-forward and render-backward.  They are
-// pinned (no compiler-chosen contraction) so both kernels take bit-identical skip decisions and the
-// backward pass divides out exactly the alphas the forward pass multiplied in.
-__device__ __forceinline__ float gauss_power(float A, float B, float C, float dx, float dy) {
+// cell-major sub-tile index -> coordinates
+struct SubTile { int cell, local, ox, oy, gsx, gsy; };
+__device__ __forceinline__ SubTile decode_subtile(int st, const Grid& g) {
+    SubTile s;
+    s.cell = st >> 6;
+    s.local = st & 63;
+    const int cxi = s.cell % g.cx, cyi = s.cell / g.cx;
+    s.gsx = cxi * CELL_SUBS + (s.local & 7);        // global sub-tile coordinates
+    s.gsy = cyi * CELL_SUBS + (s.local >> 3);
+    s.ox = s.gsx * SUB;
+    s.oy = s.gsy * SUB;
+    return s;
+}
+
+// The per-(pixel, Gaussian) falloff shared by render-forward and render-backward, pinned (no
+// compiler-chosen contraction) so both kernels take bit-identical skip decisions and the backward
+// pass divides out exactly the alphas the forward pass multiplied in.  The conic is pre-scaled by
+// log2(e): returns log2 of the Gaussian falloff;  G = exp2(power2).
+__device__ __forceinline__ float gauss_power2(float A, float B, float C, float dx, float dy) {
 #pragma clang fp contract(off)
     const float q = __builtin_fmaf(C * dy, dy, (A * dx) * dx);
     return __builtin_fmaf(-(B * dx), dy, -0.5f * q);
 }
-__device__ __forceinline__ float gauss_falloff(float power) { return __expf(power); }
+__device__ __forceinline__ float gauss_falloff2(float power2) { return __builtin_amdgcn_exp2f(power2); }
+
+// Wave-private LDS hand-off (one wave writes, the same wave reads other lanes' data): LDS operations of
+// one wave execute in order, this only stops the compiler from reordering and drains the LDS counter.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 // Host-side launch helpers implemented one per .hip file.
 struct PreprocessArgs {
@@ -117,15 +178,17 @@ struct PreprocessArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* means3D; const float* shs; const float* colors_precomp; const float* opacities;
     const float* scales; const float* rotations; const float* cov3D_precomp;
-    int32_t* radii; Splat* splats; uint32_t* counts; ExaRasterHeader* header;
+    int32_t* radii; Splat* splats; TileWs tw;
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
-hipError_t launch_tile_scan(const TileWs& w, int tiles, hipStream_t s);
-hipError_t launch_scatter(int P, const Splat* splats, const TileWs& w, int tiles, int gx, const BinWs& b,
-                          uint64_t capacity, hipStream_t s);
+hipError_t launch_cell_scan(const TileWs& w, const Grid& g, int chunks, hipStream_t s);
+hipError_t launch_cell_scatter(int P, Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
+                               hipStream_t s);
+hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
+                              hipStream_t s);
 
 struct RenderFwdArgs {
     Grid grid;
@@ -138,7 +201,7 @@ struct RenderBwdArgs {
     Grid grid;
     const Splat* splats; TileWs tw; BinWs bw; ImgWs iw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
-    GradAcc* acc;
+    Partial* partials;
 };
 hipError_t launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
 
@@ -149,7 +212,7 @@ struct PreprocessBwdArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* means3D; const float* shs; const float* opacities;
     const float* scales; const float* rotations; const float* cov3D_precomp;
-    const int32_t* radii; const Splat* splats; const GradAcc* acc;
+    const int32_t* radii; const Splat* splats; const Partial* partials;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
 };

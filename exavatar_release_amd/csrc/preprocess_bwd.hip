@@ -1,5 +1,6 @@
-// Per-Gaussian backward for gfx950: screen-space accumulators -> dL/d{means3D, means2D, scales,
-// rotations, opacities, colours | SH, cov3D}.
+// Per-Gaussian backward for gfx950: gathers the per-instance `Partial` sums render_bwd.hip wrote
+// (Gaussian-major, contiguous per Gaussian -> no atomics) and applies the chain rule down to
+// dL/d{means3D, means2D, scales, rotations, opacities, colours | SH, cov3D}.
 //
 // Replaces upstream computeCov2DCUDA (backward) + preprocessCUDA (backward) of the rasterizer behind
 // reference avatar/common/nets/module.py:632-640.  The chain rule is derived from the forward in
@@ -9,7 +10,7 @@
 // (pixel gradient * (W/2, H/2), z = 0), which is what the reference's densification reads
 // (avatar/main/train.py:51).
 //
-// HBM traffic per Gaussian: reads 64 B accumulator + 16 B of the splat record + 44 B inputs,
+// HBM traffic per Gaussian: reads 48 B per instance + 32 B of the splat record + 44 B inputs,
 // writes 68 B of gradients (SH: + 12 * M B).
 #include "common.h"
 
@@ -29,12 +30,18 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
     const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
 
     if (vis) {
-        const float4* accp = reinterpret_cast<const float4*>(a.acc + idx);
-        const float4 a0 = accp[0], a1 = accp[1], a2 = accp[2];
-        const float dpx = a0.x, dpy = a0.y, dA = a0.z, dB = a0.w, dC = a1.x;
-        dop = a1.y;
-        dcol[0] = a1.z; dcol[1] = a1.w; dcol[2] = a2.x;
-        const float dz_view = a2.y;
+        // ---- gather this Gaussian's instances (contiguous, written exactly once each) -----------------
+        const uint4 r3 = reinterpret_cast<const uint4*>(a.splats + idx)[3];
+        float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
+        {
+            const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)r3.w * 3;
+            for (uint32_t i = 0; i < r3.z; ++i) {
+                const float4 p0 = pp[i * 3 + 0], p1 = pp[i * 3 + 1], p2 = pp[i * 3 + 2];
+                mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w;
+                myy += p1.x; dop += p1.y; dcol[0] += p1.z; dcol[1] += p1.w;
+                dcol[2] += p2.x; dz_view += p2.y;
+            }
+        }
 
         // ---- recompute the forward quantities ---------------------------------------------------
         const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
@@ -94,6 +101,10 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
         const float cc2 = (T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2]) + LOWPASS;
         const float det = ca2 * cc2 - cb2 * cb2;
         const float idet = 1.0f / det, idet2 = idet * idet;
+        // moments of s = dL/dG * G  ->  d/d(pixel centre) and d/d(conic) with the raw conic (A, B, C)
+        const float cA = cc2 * idet, cB = -cb2 * idet, cC = ca2 * idet;
+        const float dpx = -cA * mx - cB * my, dpy = -cC * my - cB * mx;
+        const float dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
 
         // ---- conic (A, B, C) = (c, -b, a) / det  ->  cov2D (a, b, c) -----------------------------
         const float da = idet2 * (-cc2 * cc2 * dA + cb2 * cc2 * dB - cb2 * cb2 * dC);

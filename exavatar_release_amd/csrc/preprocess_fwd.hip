@@ -1,5 +1,5 @@
 // Forward per-Gaussian stage for gfx950: cull, EWA projection, conic, radius, tile rect, optional SH
-// colour, splat record, per-tile instance counting.
+// colour, splat record, exact-footprint sub-tile rect, per-cell histogram (first radix digit).
 //
 // Replaces upstream `preprocessCUDA` of the third-party rasterizer the reference calls at
 // avatar/common/nets/module.py:632-640.  The arithmetic follows
@@ -7,7 +7,7 @@
 // -ffp-contract=off, so px/py/conic/radius/rect are bit-identical to the float32 oracle.
 //
 // HBM traffic per Gaussian: reads mean 12 + scale 12 + quat 16 + opacity 4 + colour 12 = 56 B,
-// writes radius 4 + one 64-byte splat record (one line, later gathered whole by the tile kernels).
+// writes radius 4 + one 64-byte splat record (one line, later gathered whole by the per-pixel kernels).
 #include "common.h"
 
 namespace exa {
@@ -41,9 +41,11 @@ __device__ __forceinline__ float sh_channel(int deg, const float* __restrict__ s
     return res;
 }
 
-__global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
-    const int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
+__device__ __forceinline__ int floor_div8(int v) { return v >= 0 ? (v >> 3) : -((-v + 7) >> 3); }
+
+// One Gaussian: oracle steps 1-7 + splat record.  Returns the number of sub-tile instances and the
+// sub-tile rect through sxy (sx0, sx1, sy0, sy1; upper bounds exclusive).
+__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int idx, int sxy[4], bool& visible) {
     const float* __restrict__ v = a.viewmatrix;
     const float* __restrict__ p = a.projmatrix;
     const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
@@ -54,8 +56,8 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
     const float pvz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
 
     uint4* rec = reinterpret_cast<uint4*>(a.splats + idx);
-    bool visible = pvz > NEAR_CULL;
-    float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    visible = pvz > NEAR_CULL;
+    float px = 0.f, py = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, ca2 = 0.f, cc2 = 0.f;
     int radius = 0;
     int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
     if (visible) {
@@ -107,9 +109,9 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
         const float U10 = (T10 * S00 + T11 * S01) + T12 * S02;
         const float U11 = (T10 * S01 + T11 * S11) + T12 * S12;
         const float U12 = (T10 * S02 + T11 * S12) + T12 * S22;
-        const float ca2 = ((U00 * T00 + U01 * T01) + U02 * T02) + LOWPASS;
+        ca2 = ((U00 * T00 + U01 * T01) + U02 * T02) + LOWPASS;
         const float cb2 = (U00 * T10 + U01 * T11) + U02 * T12;
-        const float cc2 = ((U10 * T10 + U11 * T11) + U12 * T12) + LOWPASS;
+        cc2 = ((U10 * T10 + U11 * T11) + U12 * T12) + LOWPASS;
         const float det = ca2 * cc2 - cb2 * cb2;
         if (det == 0.0f) {
             visible = false;
@@ -137,49 +139,114 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
             if ((x1 - x0) * (y1 - y0) == 0) visible = false;
         }
     }
+    sxy[0] = sxy[1] = sxy[2] = sxy[3] = 0;
     if (!visible) {
         a.radii[idx] = 0;
         const uint4 zero = make_uint4(0, 0, 0, 0);
         rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
-    } else {
-        a.radii[idx] = radius;
-        // colour: precomputed, or SH evaluated here (reference module.py:258-266 semantics)
-        float cr, cg, cbl;
-        uint32_t flags = 0;
-        if (a.shs) {
-            const float* cp = a.campos;
-            float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
-            const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-            dx *= inv; dy *= inv; dz *= inv;
-            const float* sh = a.shs + (size_t)idx * a.sh_M * 3;
-            cr = sh_channel(a.sh_degree, sh, 0, dx, dy, dz) + 0.5f;
-            cg = sh_channel(a.sh_degree, sh, 1, dx, dy, dz) + 0.5f;
-            cbl = sh_channel(a.sh_degree, sh, 2, dx, dy, dz) + 0.5f;
-            if (cr < 0.f) { cr = 0.f; flags |= 1u; }
-            if (cg < 0.f) { cg = 0.f; flags |= 2u; }
-            if (cbl < 0.f) { cbl = 0.f; flags |= 4u; }
-        } else {
-            cr = a.colors_precomp[idx * 3 + 0];
-            cg = a.colors_precomp[idx * 3 + 1];
-            cbl = a.colors_precomp[idx * 3 + 2];
-        }
-        const uint32_t tiles = (uint32_t)((x1 - x0) * (y1 - y0));
-        rec[0] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pvz), (uint32_t)radius);
-        rec[1] = make_uint4(__float_as_uint(ca), __float_as_uint(cb), __float_as_uint(cc),
-                            __float_as_uint(a.opacities[idx]));
-        rec[2] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cbl), flags);
-        rec[3] = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), tiles, 0u);
-        // per-tile instance counting (first half of the counting sort on the tile digit)
-        uint32_t* cnt = a.counts + (size_t)sub_of(idx) * a.grid.tiles;
-        for (int ty_ = y0; ty_ < y1; ++ty_)
-            for (int tx_ = x0; tx_ < x1; ++tx_)
-                __hip_atomic_fetch_add(cnt + ty_ * a.grid.gx + tx_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
     }
-    // V = number of visible Gaussians: one atomic per wave
-    const unsigned long long m = __ballot(visible);
-    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m))
-        __hip_atomic_fetch_add(&a.header->num_visible, (uint32_t)__popcll(m), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+    a.radii[idx] = radius;
+    // colour: precomputed, or SH evaluated here (reference module.py:258-266 semantics)
+    float cr, cg, cbl;
+    uint32_t flags = 0;
+    if (a.shs) {
+        const float* cp = a.campos;
+        float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+        const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+        dx *= inv; dy *= inv; dz *= inv;
+        const float* sh = a.shs + (size_t)idx * a.sh_M * 3;
+        cr = sh_channel(a.sh_degree, sh, 0, dx, dy, dz) + 0.5f;
+        cg = sh_channel(a.sh_degree, sh, 1, dx, dy, dz) + 0.5f;
+        cbl = sh_channel(a.sh_degree, sh, 2, dx, dy, dz) + 0.5f;
+        if (cr < 0.f) { cr = 0.f; flags |= 1u; }
+        if (cg < 0.f) { cg = 0.f; flags |= 2u; }
+        if (cbl < 0.f) { cbl = 0.f; flags |= 4u; }
+    } else {
+        cr = a.colors_precomp[idx * 3 + 0];
+        cg = a.colors_precomp[idx * 3 + 1];
+        cbl = a.colors_precomp[idx * 3 + 2];
+    }
+    // Sub-tile rect: inside the upstream 16x16-tile rect AND intersecting the exact bounding box of
+    // {alpha >= 1/255}: 0.5 d^T Q d <= tau = ln(255 o), whose half extents are sqrt(2 tau cov_xx / yy).
+    // (Conservative: +0.1 % and +0.01 px; a sub-tile outside it holds no pixel that passes the
+    // per-pixel alpha test, so dropping it cannot change the image.)
+    const float op = a.opacities[idx];
+    uint32_t n_inst = 0;
+    const float o255 = 255.0f * op;
+    if (o255 >= 1.0f) {
+        const float tau2 = 2.0f * __logf(o255) + 1e-3f;
+        const float ex = sqrtf(tau2 * ca2) * 1.001f + 0.01f;
+        const float ey = sqrtf(tau2 * cc2) * 1.001f + 0.01f;
+        const float lim = 1.0e6f;
+        const int bx0 = (int)floorf(fminf(fmaxf(px - ex, -lim), lim)), bx1 = (int)ceilf(fminf(fmaxf(px + ex, -lim), lim));
+        const int by0 = (int)floorf(fminf(fmaxf(py - ey, -lim), lim)), by1 = (int)ceilf(fminf(fmaxf(py + ey, -lim), lim));
+        sxy[0] = max(2 * x0, floor_div8(bx0));
+        sxy[1] = min(min(2 * x1, a.grid.sx), floor_div8(bx1) + 1);
+        sxy[2] = max(2 * y0, floor_div8(by0));
+        sxy[3] = min(min(2 * y1, a.grid.sy), floor_div8(by1) + 1);
+        if (sxy[1] > sxy[0] && sxy[3] > sxy[2]) n_inst = (uint32_t)(sxy[1] - sxy[0]) * (uint32_t)(sxy[3] - sxy[2]);
+        else sxy[0] = sxy[1] = sxy[2] = sxy[3] = 0;
+    }
+    rec[0] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pvz), (uint32_t)radius);
+    rec[1] = make_uint4(__float_as_uint(ca * LOG2E), __float_as_uint(cb * LOG2E), __float_as_uint(cc * LOG2E),
+                        __float_as_uint(op));
+    rec[2] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cbl), flags);
+    rec[3] = make_uint4((uint32_t)sxy[0] | ((uint32_t)sxy[1] << 16), (uint32_t)sxy[2] | ((uint32_t)sxy[3] << 16),
+                        n_inst, 0u);
+    return n_inst;
+}
+
+// CHUNK Gaussians per workgroup.  Besides the per-Gaussian work, builds this chunk's histogram over the
+// 64x64-pixel cells in LDS (entries and instances packed in one u64) and flushes it with ONE 64-bit
+// atomic per (chunk, non-empty cell): device-scope atomics run at only ~12 G/s chip-wide on MI355X,
+// so they are spent per cell, never per instance.
+__global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cell[];   // [cells]
+    __shared__ uint32_t s_red[BLOCK / 64];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < a.grid.cells; c += BLOCK) s_cell[c] = 0ull;
+    __syncthreads();
+    uint32_t inst_sum = 0;
+    uint32_t nvis = 0;
+#pragma unroll 1
+    for (int it = 0; it < CHUNK / BLOCK; ++it) {
+        const int idx = blockIdx.x * CHUNK + it * BLOCK + tid;
+        if (idx < a.P) {
+            int sxy[4];
+            bool vis;
+            const uint32_t n = preprocess_one(a, idx, sxy, vis);
+            nvis += vis ? 1u : 0u;
+            if (n) {
+                inst_sum += n;
+                const int cx0 = sxy[0] >> 3, cx1 = (sxy[1] - 1) >> 3, cy0 = sxy[2] >> 3, cy1 = (sxy[3] - 1) >> 3;
+                for (int cy = cy0; cy <= cy1; ++cy) {
+                    const int hy = min(sxy[3], (cy + 1) * CELL_SUBS) - max(sxy[2], cy * CELL_SUBS);
+                    for (int cx = cx0; cx <= cx1; ++cx) {
+                        const int hx = min(sxy[1], (cx + 1) * CELL_SUBS) - max(sxy[0], cx * CELL_SUBS);
+                        const unsigned long long add = ((unsigned long long)(uint32_t)(hx * hy) << 32) | 1ull;
+                        __hip_atomic_fetch_add(&s_cell[cy * a.grid.cx + cx], add, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+    }
+    // chunk totals
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        inst_sum += __shfl_xor(inst_sum, d, 64);
+        nvis += __shfl_xor(nvis, d, 64);
+    }
+    if ((tid & 63) == 0) s_red[tid >> 6] = inst_sum;
+    __syncthreads();
+    if (tid == 0) a.tw.chunk_inst[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    if ((tid & 63) == 0 && nvis)
+        __hip_atomic_fetch_add(&a.tw.header->num_visible, nvis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int c = tid; c < a.grid.cells; c += BLOCK) {
+        const unsigned long long v = s_cell[c];
+        if (v) __hip_atomic_fetch_add(&a.tw.cell_cnt[c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -193,7 +260,7 @@ __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float*
 
 hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
     if (a.P == 0) return hipSuccess;
-    preprocess_fwd_kernel<<<(a.P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(a);
+    preprocess_fwd_kernel<<<num_chunks(a.P), BLOCK, (size_t)a.grid.cells * 8, s>>>(a);
     return hipGetLastError();
 }
 

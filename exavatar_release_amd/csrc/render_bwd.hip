@@ -1,53 +1,60 @@
-// Per-tile back-to-front backward of the alpha compositing for gfx950.
+// Per-sub-tile back-to-front backward of the alpha compositing for gfx950 -- atomic-free.
 //
-// Same geometry as render_fwd.hip (256 threads = 16x16 tile, wave = 16x4 pixel strip).  The sorted
-// id list written by the forward pass is replayed from the last position any pixel of the tile
-// blended (`max_contrib`, so the never-reached tail of long lists costs nothing) down to the front,
-// in batches of 256 splats staged through LDS.  For every (wave, splat) pair with at least one
-// contributing lane the ten partial derivatives are reduced across the wave's four 16-lane DPP rows
-// (4 row steps, no LDS), the four row totals are added into an LDS accumulator, and after the batch
-// ONE thread per splat flushes its ten sums to the per-Gaussian 64-byte accumulator line with
-// hardware fp32 atomics: one atomic burst per Gaussian per tile instead of one per pixel.
+// Same geometry as render_fwd.hip: ONE WAVE per 8x8-pixel sub-tile, four independent waves per
+// workgroup, no __syncthreads.  The sorted id list written by the forward pass is replayed from the last
+// position any pixel of the sub-tile blended (`max_contrib`) down to the front in batches of 64 splats
+// staged through the wave's LDS slice.  For every splat with at least one contributing lane the ten
+// partial sums are reduced across the wave with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31 -- no
+// LDS, no shuffles through memory) and lane 63 parks them in LDS; at the end of the batch the 64 lanes
+// store their splat's 48-byte `Partial` to its Gaussian-major slot with plain stores.  Every instance
+// of the list gets its slot written exactly once (zeros when nothing contributed), so there is no
+// memset and NO atomic in the whole backward pass: device-scope fp32 atomics run at ~12 G/s on
+// MI355X, which made the atomic version of this kernel 15x slower.
 //
 // Replaces upstream BACKWARD::renderCUDA of the rasterizer behind reference
 // avatar/common/nets/module.py:632-640 (backward reached from avatar/main/train.py:46).
-// Derivatives follow oracle/raster_oracle.py (autograd of oracle step 9/10) with
-// straight-through min(0.99, .).
+// Derivatives follow oracle/raster_oracle.py (autograd of oracle step 9/10) with straight-through
+// min(0.99, .).  The screen-space gradients are emitted as five moments of s = dL/dG * G
+// (sum s dx, s dy, s dx^2, s dx dy, s dy^2); preprocess_bwd.hip turns them into d/d(mean2D, conic).
 //
-// Algorithmic HBM bytes: reads 4 B/instance (sorted ids up to max_contrib), 48 B per gathered splat,
-// 12 (+8) B/pixel of incoming gradient, 8 B/pixel (final_T, n_contrib); writes 40 B per
-// (Gaussian, tile) pair as atomics into L2-resident accumulator lines.
+// Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered splat,
+// 12 (+8) B/pixel of incoming gradient, 8 B/pixel (final_T, n_contrib); writes 48 B per instance.
 #include "common.h"
 
 namespace exa {
 
-constexpr int NACC = 10;   // dpx dpy dA dB dC dop dr dg db dz
+constexpr int WAVES = BLOCK / 64;
+constexpr int NACC = 10;   // mx my mxx mxy myy dop dr dg db dz
 
-// Sum over each 16-lane DPP row; afterwards lane 15 of every row holds its row's total.
-__device__ __forceinline__ float row_reduce_16(float v) {
-    // row_shr:1,2,4(=3+1),8 with bound_ctrl:0 (out-of-row lanes read 0)
+// Full wave64 sum with DPP; the total ends up in lane 63.
+__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    // lane 15 of each row holds its row total; row_bcast15 -> rows 1,3 ; row_bcast31 -> rows 2,3
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
     return v;
 }
 
 __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
-    __shared__ float4 s_g0[BLOCK];
-    __shared__ float4 s_g1[BLOCK];
-    __shared__ float4 s_g2[BLOCK];
-    __shared__ uint32_t s_id[BLOCK];
-    __shared__ float s_acc[NACC][BLOCK];
-    __shared__ int s_touched[BLOCK];
+    __shared__ float4 s_g0[WAVES][64];
+    __shared__ float4 s_g1[WAVES][64];
+    __shared__ float4 s_g2[WAVES][64];
+    __shared__ float4 s_out[WAVES][64][3];      // the Partial of each staged splat
+    __shared__ uint32_t s_slot[WAVES][64];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int tile = blockIdx.x;
-    const int n_eff = (int)a.tw.max_contrib[tile];
-    if (n_eff == 0) return;
-    const uint2 range = a.tw.ranges[tile];
-    const int tile_x = tile % a.grid.gx, tile_y = tile / a.grid.gx;
-    const int pxi = tile_x * TILE + (tid & 15), pyi = tile_y * TILE + (tid >> 4);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int st = blockIdx.x * WAVES + wave;
+    const SubTile sub = decode_subtile(st, a.grid);
+    if (sub.ox >= a.grid.W || sub.oy >= a.grid.H) return;
+    const uint2 range = a.tw.ranges[st];
+    const int n = (int)(range.y - range.x);
+    if (n == 0) return;
+    const int n_eff = (int)a.tw.max_contrib[st];
+    const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
     const bool inside = pxi < a.grid.W && pyi < a.grid.H;
     const float fx = (float)pxi, fy = (float)pyi;
     const size_t HW = (size_t)a.grid.W * a.grid.H;
@@ -70,86 +77,92 @@ __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
     float T = T_final;
     float rec_r = 0.f, rec_g = 0.f, rec_b = 0.f, rec_d = 0.f;      // normalised suffix colour / depth
     float last_alpha = 0.f, lw_r = 0.f, lw_g = 0.f, lw_b = 0.f, lw_d = 0.f;
-    const float ddx = 1.0f, ddy = 1.0f;   // pixel units here; the NDC scale (W/2, H/2) is applied per Gaussian later
-    (void)ddx; (void)ddy;
 
-    for (int bend = n_eff; bend > 0; bend -= BLOCK) {
-        const int bstart = max(0, bend - BLOCK);
+    float4* g0s = s_g0[wave];
+    float4* g1s = s_g1[wave];
+    float4* g2s = s_g2[wave];
+    float4 (*outs)[3] = s_out[wave];
+    uint32_t* slots = s_slot[wave];
+    const Splat* __restrict__ splats = a.splats;
+    float4* partials = reinterpret_cast<float4*>(a.partials);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // Batches cover the WHOLE list back to front; positions >= n_eff only get their zero Partial.
+    for (int bend = n; bend > 0; bend -= 64) {
+        const int bstart = max(0, bend - 64);
         const int cnt = bend - bstart;
-        if (tid < cnt) {
-            const uint32_t id = a.bw.sorted[range.x + bstart + tid];
-            const float4* rec = reinterpret_cast<const float4*>(a.splats + id);
-            s_id[tid] = id;
-            s_g0[tid] = rec[0];
-            s_g1[tid] = rec[1];
-            s_g2[tid] = rec[2];
-        }
-#pragma unroll
-        for (int i = 0; i < NACC; ++i) s_acc[i][tid] = 0.f;
-        s_touched[tid] = 0;
-        __syncthreads();
-
-        for (int k = cnt - 1; k >= 0; --k) {
-            const int pos = bstart + k + 1;                   // 1-based list position
-            const float4 g0 = s_g0[k];
-            const float4 g1 = s_g1[k];
-            const float dx = g0.x - fx, dy = g0.y - fy;
-            const float power = gauss_power(g1.x, g1.y, g1.z, dx, dy);
-            const float G = gauss_falloff(power);
-            const float alpha = fminf(ALPHA_MAX, g1.w * G);
-            const bool contrib = inside && pos <= last && power <= 0.0f && alpha >= ALPHA_MIN;
-            if (!__any(contrib)) continue;
-            float v[NACC];
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) v[i] = 0.f;
-            if (contrib) {
-                const float4 g2 = s_g2[k];
-                const float one_m = 1.0f - alpha;
-                T = T / one_m;
-                const float wgt = alpha * T;
-                rec_r = last_alpha * lw_r + (1.0f - last_alpha) * rec_r;
-                rec_g = last_alpha * lw_g + (1.0f - last_alpha) * rec_g;
-                rec_b = last_alpha * lw_b + (1.0f - last_alpha) * rec_b;
-                rec_d = last_alpha * lw_d + (1.0f - last_alpha) * rec_d;
-                lw_r = g2.x; lw_g = g2.y; lw_b = g2.z; lw_d = g0.z;
-                last_alpha = alpha;
-                float dL_dalpha = (g2.x - rec_r) * gr + (g2.y - rec_g) * gg + (g2.z - rec_b) * gb + (g0.z - rec_d) * gd;
-                dL_dalpha = dL_dalpha * T + tail / one_m;
-                const float dL_dG = g1.w * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                v[0] = dL_dG * (-gdx * g1.x - gdy * g1.y);     // dL/dpx
-                v[1] = dL_dG * (-gdy * g1.z - gdx * g1.y);     // dL/dpy
-                v[2] = -0.5f * gdx * dx * dL_dG;               // dL/dA
-                v[3] = -gdx * dy * dL_dG;                      // dL/dB
-                v[4] = -0.5f * gdy * dy * dL_dG;               // dL/dC
-                v[5] = G * dL_dalpha;                          // dL/dopacity
-                v[6] = wgt * gr;
-                v[7] = wgt * gg;
-                v[8] = wgt * gb;
-                v[9] = wgt * gd;
-            }
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) v[i] = row_reduce_16(v[i]);
-            if ((lane & 15) == 15) {
-#pragma unroll
-                for (int i = 0; i < NACC; ++i)
-                    __hip_atomic_fetch_add(&s_acc[i][k], v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                s_touched[k] = 1;
+        const bool live = bstart < n_eff;                     // wave-uniform: any work in this batch?
+        if (lane < cnt) {
+            const uint32_t id = a.bw.sorted[range.x + bstart + lane];
+            const float4* rec = reinterpret_cast<const float4*>(splats + id);
+            const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
+            const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
+            slots[lane] = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
+            if (live) {
+                g0s[lane] = rec[0];
+                g1s[lane] = rec[1];
+                g2s[lane] = rec[2];
             }
         }
-        __syncthreads();
-        if (tid < cnt && s_touched[tid]) {
-            float* dst = reinterpret_cast<float*>(a.acc + s_id[tid]);
+        outs[lane][0] = zero4; outs[lane][1] = zero4; outs[lane][2] = zero4;
+        wave_lds_fence();
+        if (live) {
+            for (int k = min(cnt, n_eff - bstart) - 1; k >= 0; --k) {
+                const int pos = bstart + k + 1;                   // 1-based list position
+                const float4 g0 = g0s[k];
+                const float4 g1 = g1s[k];
+                const float dx = g0.x - fx, dy = g0.y - fy;
+                const float p2 = gauss_power2(g1.x, g1.y, g1.z, dx, dy);
+                const float G = gauss_falloff2(p2);
+                const float alpha = fminf(ALPHA_MAX, g1.w * G);
+                const bool contrib = inside && pos <= last && p2 <= 0.0f && alpha >= ALPHA_MIN;
+                if (!__any(contrib)) continue;
+                float v[NACC];
 #pragma unroll
-            for (int i = 0; i < NACC; ++i) unsafeAtomicAdd(dst + i, s_acc[i][tid]);
+                for (int i = 0; i < NACC; ++i) v[i] = 0.f;
+                if (contrib) {
+                    const float4 g2 = g2s[k];
+                    const float one_m = 1.0f - alpha;
+                    T = T / one_m;
+                    const float wgt = alpha * T;
+                    rec_r = last_alpha * lw_r + (1.0f - last_alpha) * rec_r;
+                    rec_g = last_alpha * lw_g + (1.0f - last_alpha) * rec_g;
+                    rec_b = last_alpha * lw_b + (1.0f - last_alpha) * rec_b;
+                    rec_d = last_alpha * lw_d + (1.0f - last_alpha) * rec_d;
+                    lw_r = g2.x; lw_g = g2.y; lw_b = g2.z; lw_d = g0.z;
+                    last_alpha = alpha;
+                    float dL_dalpha = (g2.x - rec_r) * gr + (g2.y - rec_g) * gg + (g2.z - rec_b) * gb + (g0.z - rec_d) * gd;
+                    dL_dalpha = dL_dalpha * T + tail / one_m;
+                    const float sG = g1.w * dL_dalpha * G;        // s = dL/dG * G
+                    const float sdx = sG * dx, sdy = sG * dy;
+                    v[0] = sdx; v[1] = sdy;
+                    v[2] = sdx * dx; v[3] = sdx * dy; v[4] = sdy * dy;
+                    v[5] = G * dL_dalpha;
+                    v[6] = wgt * gr; v[7] = wgt * gg; v[8] = wgt * gb; v[9] = wgt * gd;
+                }
+#pragma unroll
+                for (int i = 0; i < NACC; ++i) v[i] = wave_reduce_to_lane63(v[i]);
+                if (lane == 63) {
+                    outs[k][0] = make_float4(v[0], v[1], v[2], v[3]);
+                    outs[k][1] = make_float4(v[4], v[5], v[6], v[7]);
+                    outs[k][2] = make_float4(v[8], v[9], 0.f, 0.f);
+                }
+            }
+            wave_lds_fence();
         }
-        __syncthreads();
+        if (lane < cnt) {
+            float4* dst = partials + (size_t)slots[lane] * 3;
+            dst[0] = outs[lane][0];
+            dst[1] = outs[lane][1];
+            dst[2] = outs[lane][2];
+        }
+        wave_lds_fence();
     }
 }
 
 hipError_t launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
-    if (a.grid.tiles == 0) return hipSuccess;
-    render_bwd_kernel<<<a.grid.tiles, BLOCK, 0, s>>>(a);
+    if (a.grid.subtiles == 0) return hipSuccess;
+    render_bwd_kernel<<<a.grid.subtiles / WAVES, BLOCK, 0, s>>>(a);
     return hipGetLastError();
 }
 

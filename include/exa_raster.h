@@ -60,17 +60,17 @@ typedef struct ExaRasterSettings {
 /* Byte sizes of the caller-allocated workspaces. */
 typedef struct ExaRasterWorkspaceSizes {
     uint64_t geom_bytes;   /* per-Gaussian splat records, 64 B * P                         */
-    uint64_t tile_bytes;   /* per-tile counters, cursors, ranges + the device header        */
-    uint64_t bin_bytes;    /* per-instance keys + sorted ids, 12 B * capacity               */
+    uint64_t tile_bytes;   /* per-cell counters / prefixes, per-sub-tile ranges + the header */
+    uint64_t bin_bytes;    /* per-instance keys + sorted ids + cell buckets, 16 B * capacity */
     uint64_t img_bytes;    /* per-pixel final_T + n_contrib, 8 B * W * H                    */
-    uint64_t grad_bytes;   /* backward scratch: per-Gaussian screen-space accumulators      */
+    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
 /* Device-side header at the start of the tile workspace (readable with a 16-byte D2H copy). */
 typedef struct ExaRasterHeader {
-    uint32_t num_rendered;   /* D = sum of tiles touched ("num_rendered" upstream)           */
+    uint32_t num_rendered;   /* D = (Gaussian, 8x8 sub-tile) instances (role of upstream's num_rendered) */
     uint32_t overflow;       /* != 0: D exceeded bin capacity, outputs of this call invalid  */
-    uint32_t max_tile_list;  /* longest per-tile list                                        */
+    uint32_t max_tile_list;  /* number of (Gaussian, 64x64 cell) entries                     */
     uint32_t num_visible;    /* V = Gaussians with radius > 0                                */
 } ExaRasterHeader;
 
@@ -85,7 +85,7 @@ int exa_raster_workspace_sizes(int32_t P, int32_t W, int32_t H, uint64_t capacit
 
 /*
  * Forward, stage 1 (replaces upstream preprocessCUDA + InclusiveSum): per-Gaussian cull, EWA
- * projection, radius, tile rect, optional SH colour; per-tile instance counts and their prefix.
+ * projection, radius, tile rect, optional SH colour; per-cell instance counts and their prefix.
  * After it completes, the header in `tile_ws` holds num_rendered so the caller can size `bin_ws`
  * (upstream reads the same number back to the host at this point).
  * Exactly one of shs / colors_precomp and one of (scales+rotations) / cov3D_precomp is non-NULL.
@@ -99,7 +99,8 @@ int exa_raster_forward_bin(const ExaRasterSettings* settings, int32_t P, int32_t
 
 /*
  * Forward, stage 2 (replaces duplicateWithKeys + SortPairs + identifyTileRanges + renderCUDA):
- * scatter instances into per-tile buckets, depth-sort every bucket in LDS, blend front to back.
+ * scatter Gaussians into cell buckets and then sub-tile buckets, depth-sort every bucket in LDS,
+ * blend front to back.  (geom_ws is logically const; the call fills one reserved field per record.)
  * If the header's num_rendered > capacity nothing is rendered and header.overflow is set.
  * `store_ctx` != 0 additionally writes what the backward pass needs (sorted ids, final_T,
  * n_contrib); pass 0 for inference.
