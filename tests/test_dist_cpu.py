@@ -1,0 +1,85 @@
+"""world_size-2 gloo tests of the N > 1 path: view sharding, flat gradient all-reduce, densify stats."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+import multiprocessing as mp
+
+from exavatar_release_amd.dist import FlatGradAllReducer, reduce_densify_stats, shard_views
+
+
+def test_shard_views_partition_and_reshuffle():
+    for world in (1, 2, 3, 8):
+        for epoch in (0, 1):
+            shards = [shard_views(200, r, world, epoch=epoch) for r in range(world)]
+            allv = sorted(v for s in shards for v in s)
+            assert allv == list(range(200))
+            assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    assert shard_views(200, 0, 8, epoch=0) != shard_views(200, 0, 8, epoch=1)
+    assert shard_views(10, 1, 2, shuffle=False) == [1, 3, 5, 7, 9]
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        P = 1000
+        g = torch.Generator().manual_seed(100 + rank)
+        shapes = [(P, 3), (P, 3), (P, 4), (P, 1), (P, 3)]
+        grads = [torch.randn(*s, generator=g) for s in shapes]
+        red = FlatGradAllReducer(grads, average=True)
+        assert red.nbytes == P * 14 * 4
+        red.start(grads)
+        out = [v.clone() for v in red.finish()]
+        # second step: rank 1 did not touch the opacity parameter (None grad = zeros)
+        grads2 = [torch.full(s, float(rank + 1)) for s in shapes]
+        if rank == 1:
+            grads2[3] = None
+        red.start(grads2)
+        out2 = [v.clone() for v in red.finish()]
+        acc = torch.full((P,), float(rank + 1))
+        cnt = torch.full((P,), 1.0 + rank)
+        rmax = torch.arange(P, dtype=torch.float32) * (1 if rank == 0 else -1)
+        reduce_densify_stats(acc, cnt, rmax)
+        q.put((rank, [o.numpy() for o in out], [o.numpy() for o in out2], acc.numpy(), cnt.numpy(), rmax.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2_gloo():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, out, out2, acc, cnt, rmax = q.get(timeout=120)
+        res[rank] = ([torch.from_numpy(o) for o in out], [torch.from_numpy(o) for o in out2],
+                     torch.from_numpy(acc), torch.from_numpy(cnt), torch.from_numpy(rmax))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # expected mean of the two ranks' seeded gradients
+    shapes = [(1000, 3), (1000, 3), (1000, 4), (1000, 1), (1000, 3)]
+    exp = []
+    for i, s in enumerate(shapes):
+        gs = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 + r)
+            gg = [torch.randn(*ss, generator=g) for ss in shapes]
+            gs.append(gg[i])
+        exp.append((gs[0] + gs[1]) / 2)
+    for r in range(world):
+        out, out2, acc, cnt, rmax = res[r]
+        for o, e in zip(out, exp):
+            assert torch.allclose(o, e, atol=1e-6)
+        assert torch.allclose(out2[0], torch.full((1000, 3), 1.5))
+        assert torch.allclose(out2[3], torch.full((1000, 1), 0.5))       # (1 + 0) / 2
+        assert torch.all(acc == 3.0) and torch.all(cnt == 3.0)
+        assert torch.equal(rmax, torch.arange(1000, dtype=torch.float32))
+    assert torch.equal(res[0][0][0], res[1][0][0])

@@ -1,0 +1,146 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, argument
+validation works without a GPU, the Python surface mirrors the reference's plugin interface, and the
+product path refuses to run without a ROCm device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import exavatar_release_amd as exa
+from exavatar_release_amd import _lib, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, 'include', 'exa_raster.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(exa_raster_\w+)\s*\(', src)))
+
+
+def test_library_exports_every_symbol_the_header_declares():
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 11
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
+    assert lib.exa_raster_version() == 100
+    assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
+
+
+def test_settings_struct_layout_matches_c():
+    # 4 ints/floats, ptr, float(+pad), 2 ptrs, int(+pad), ptr, 2 ints  on LP64
+    assert ctypes.sizeof(_lib.ExaRasterSettings) == 72
+    assert _lib.ExaRasterSettings.bg.offset == 16 and _lib.ExaRasterSettings.campos.offset == 56
+
+
+def test_workspace_sizes():
+    s = _lib.workspace_sizes(150_000, 1024, 1024, 1_000_000)
+    assert s.geom_bytes == 150_000 * 64
+    assert s.bin_bytes >= 16 * 1_000_000 and s.grad_bytes >= 48 * 1_000_000
+    assert s.img_bytes >= 8 * 1024 * 1024
+    s2 = _lib.workspace_sizes(0, 0, 0, 0)
+    assert s2.geom_bytes == 0
+    with pytest.raises(RuntimeError):
+        _lib.workspace_sizes(-1, 16, 16, 0)
+
+
+def test_argument_validation_returns_negative_status_without_touching_the_gpu():
+    lib = _lib.load()
+    st = _lib.ExaRasterSettings()
+    st.image_height, st.image_width, st.tanfovx, st.tanfovy = 64, 64, 0.5, 0.5
+    null = ctypes.c_void_p(0)
+    # NULL device pointers in the settings
+    rc = lib.exa_raster_forward_bin(ctypes.byref(st), 10, 0, null, null, null, null, null, null, null, null, null,
+                                    null, null)
+    assert rc == -2 and b'settings' in lib.exa_raster_last_error()
+    fake = ctypes.c_void_p(4096)
+    st.bg = st.viewmatrix = st.projmatrix = st.campos = 4096
+    # both colours and SHs missing
+    rc = lib.exa_raster_forward_bin(ctypes.byref(st), 10, 0, fake, null, null, fake, fake, fake, null, fake, fake,
+                                    fake, null)
+    assert rc == -1 and b'exactly one' in lib.exa_raster_last_error()
+    # scales without rotations
+    rc = lib.exa_raster_forward_bin(ctypes.byref(st), 10, 0, fake, null, fake, fake, fake, null, null, fake, fake,
+                                    fake, null)
+    assert rc == -1
+    # sh_M too small for the degree
+    st.sh_degree = 3
+    rc = lib.exa_raster_forward_bin(ctypes.byref(st), 10, 4, fake, fake, null, fake, fake, fake, null, fake, fake,
+                                    fake, null)
+    assert rc == -1 and b'sh_M' in lib.exa_raster_last_error()
+    st.sh_degree = 0
+    # image larger than the cell budget
+    st.image_height = st.image_width = 40000
+    rc = lib.exa_raster_forward_bin(ctypes.byref(st), 10, 0, fake, null, fake, fake, fake, fake, null, fake, fake,
+                                    fake, null)
+    assert rc == -1 and b'too large' in lib.exa_raster_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc)
+
+
+def test_python_surface_matches_the_reference_plugin():
+    fields = exa.GaussianRasterizationSettings._fields
+    assert fields == ('image_height', 'image_width', 'tanfovx', 'tanfovy', 'bg', 'scale_modifier', 'viewmatrix',
+                      'projmatrix', 'sh_degree', 'campos', 'prefiltered', 'debug')      # module.py:609-622
+    import inspect
+    sig = inspect.signature(exa.GaussianRasterizer.forward)
+    assert list(sig.parameters)[1:] == ['means3D', 'means2D', 'opacities', 'shs', 'colors_precomp', 'scales',
+                                        'rotations', 'cov3D_precomp']
+    sig = inspect.signature(exa.GaussianRenderer.forward)
+    assert list(sig.parameters)[1:] == ['gaussian_assets', 'img_shape', 'cam_param', 'bg']   # module.py:592
+
+
+def _settings():
+    H = W = 32
+    from exavatar_release_amd.camera import make_raster_matrices
+    tanx, tany, view, proj, campos = make_raster_matrices(scenes.neutral_camera(H, W), (H, W))
+    return exa.GaussianRasterizationSettings(H, W, tanx, tany, torch.ones(3), 1.0, view, proj, 0, campos, False, False)
+
+
+def test_rasterizer_rejects_bad_argument_combinations_like_upstream():
+    r = exa.GaussianRasterizer(_settings())
+    m = torch.zeros(4, 3)
+    with pytest.raises(Exception, match='SHs or precomputed colors'):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), shs=None, colors_precomp=None,
+          scales=torch.ones(4, 3), rotations=torch.ones(4, 4))
+    with pytest.raises(Exception, match='scale/rotation pair or precomputed 3D covariance'):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), colors_precomp=m, scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4), cov3D_precomp=torch.ones(4, 6))
+
+
+def test_product_path_has_no_cpu_fallback():
+    r = exa.GaussianRasterizer(_settings())
+    m = torch.zeros(4, 3)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        r(means3D=m, means2D=m, opacities=torch.ones(4, 1), colors_precomp=m, scales=torch.ones(4, 3),
+          rotations=torch.ones(4, 4))
+    # and nothing in the package imports the oracle
+    pkg = os.path.join(ROOT, 'exavatar_release_amd')
+    pat = re.compile(r'^\s*(from\s+oracle\b|import\s+oracle\b)|import_module\([\'"]oracle', re.M)
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            assert not pat.search(open(os.path.join(pkg, fn)).read()), fn
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        _lib.load()
+
+
+def test_scenes_are_seeded_and_shaped():
+    a1, shp, cam = scenes.make_config('c1')
+    a2, _, _ = scenes.make_config('c1')
+    assert shp == (256, 256) and a1['mean_3d'].shape == (10_000, 3)
+    for k in a1:
+        assert torch.equal(a1[k], a2[k]) and a1[k].dtype == torch.float32 and a1[k].is_contiguous()
+    b = scenes.dist_b_avatar(5000, seed=1)
+    assert torch.all(b['opacity'] == 1) and torch.all(b['rotation'][:, 0] == 1)
+    assert torch.all(b['scale'][:, 0] == b['scale'][:, 1])
+    sh = scenes.sh_from_rgb(a1['rgb'][:7], 3)
+    assert sh.shape == (7, 16, 3)

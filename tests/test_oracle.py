@@ -1,0 +1,290 @@
+"""CPU tests that pin the oracle: reference-derived golden vectors (camera helpers, SH, covariance),
+analytic known answers and float64 finite differences."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from exavatar_release_amd import camera, scenes
+from oracle import raster_oracle as ro
+
+torch.set_num_threads(2)
+
+
+def _one_gaussian(mean, scale=0.01, opacity=1.0, rgb=(0.2, 0.5, 0.9), rot=(1, 0, 0, 0)):
+    return {'mean_3d': torch.tensor([mean], dtype=torch.float32),
+            'scale': torch.full((1, 3), scale), 'rotation': torch.tensor([rot], dtype=torch.float32),
+            'opacity': torch.tensor([[opacity]]), 'rgb': torch.tensor([rgb], dtype=torch.float32)}
+
+
+def _cat(*assets):
+    return {k: torch.cat([a[k] for a in assets]) for k in assets[0]}
+
+
+# ---------------------------------------------------------------- reference-derived golden vectors
+def test_camera_helpers_match_reference_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'ref_transforms.npz'))
+    for i in range(int(z['n_cams'])):
+        H, W, fx, fy = z['cam%d_in' % i]
+        shape = (int(H), int(W))
+        focal = torch.tensor([fx, fy], dtype=torch.float32)
+        princpt = torch.tensor(z['cam%d_princpt' % i])
+        R = torch.tensor(z['cam%d_R' % i])
+        t = torch.tensor(z['cam%d_t' % i])
+        assert np.array_equal(camera.get_fov(focal, princpt, shape).numpy(), z['cam%d_fov' % i])
+        assert np.array_equal(camera.get_view_matrix(R, t).numpy(), z['cam%d_view' % i])
+        assert np.array_equal(camera.get_proj_matrix(focal, princpt, shape, 0.01, 100, 1.0).numpy(), z['cam%d_proj' % i])
+
+
+def test_sh_colour_matches_reference_eval_sh(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'ref_transforms.npz'))
+    sh_ref_layout = torch.tensor(z['sh_coeff'])            # [N, 3, 16] (reference layout)
+    dirs = torch.tensor(z['sh_dirs'])
+    shs = sh_ref_layout.permute(0, 2, 1).contiguous()      # rasterizer layout [N, M, 3]
+    campos = torch.zeros(3)
+    means = dirs * 2.5                                       # direction = normalize(mean - campos)
+    for deg in range(4):
+        got = ro.eval_sh_color(deg, shs, means, campos)
+        want = torch.clamp_min(torch.tensor(z['sh_eval_deg%d' % deg]) + 0.5, 0.0)   # module.py:266
+        assert torch.allclose(got, want, atol=2e-6), deg
+    assert np.allclose((z['rgb'] - 0.5) / ro.C0, z['rgb2sh'], atol=1e-6)
+
+
+def test_cov3d_matches_reference_get_covariance_matrix(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'ref_transforms.npz'))
+    R = torch.tensor(z['cov_R'])
+    S = torch.tensor(z['cov_S'])
+    M = R * S[:, None, :]
+    assert np.allclose((M @ M.transpose(1, 2)).numpy(), z['cov'], atol=1e-7)
+    # and the quaternion path builds the same matrix as an explicit rotation matrix
+    q = torch.tensor([[0.9, 0.1, -0.3, 0.2]])
+    q = q / q.norm()
+    Rq = ro.quat_to_rotmat(q)
+    assert torch.allclose(Rq @ Rq.transpose(1, 2), torch.eye(3)[None], atol=1e-6)
+    assert torch.allclose(torch.linalg.det(Rq), torch.ones(1), atol=1e-6)
+
+
+def test_oracle_regression_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, 'oracle_small.npz'))
+    H, W = int(z['H']), int(z['W'])
+    assets = {k: torch.tensor(z[k]).requires_grad_(True) for k in ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')}
+    cam = scenes.neutral_camera(H, W, focal=float(z['focal']))
+    out = ro.render(assets, (H, W), cam, torch.tensor(z['bg']))
+    loss = (out['img'] * torch.tensor(z['G'])).sum() + (out['depthmap'] * torch.tensor(z['Gd'])).sum() + \
+        (out['mask'] * torch.tensor(z['Ga'])).sum()
+    loss.backward()
+    assert np.allclose(out['img'].detach().numpy(), z['img'], atol=1e-6)
+    assert np.array_equal(out['radius'].numpy(), z['radii'])
+    for k in assets:
+        ref = z['grad_' + k]
+        assert np.allclose(assets[k].grad.numpy(), ref, atol=1e-4 * np.abs(ref).max()), k
+
+
+# ---------------------------------------------------------------- analytic known answers
+def test_single_gaussian_centre_and_falloff():
+    H = W = 33
+    f = 50.0
+    cam = scenes.neutral_camera(H, W, focal=f)
+    # pixel (16,16) is the image centre: pix = f x/z + W/2 - 0.5 = 16 for x = 0
+    z0, s = 2.0, 0.06
+    a = _one_gaussian((0.0, 0.0, z0), scale=s, opacity=1.0, rgb=(0.2, 0.5, 0.9))
+    bg = torch.tensor([1.0, 0.0, 0.5])
+    out = ro.render(a, (H, W), cam, bg)
+    img = out['img']
+    c = torch.tensor([0.2, 0.5, 0.9])
+    assert torch.allclose(img[:, 16, 16], 0.99 * c + 0.01 * bg, atol=1e-6)
+    sigma2 = (s * f / z0) ** 2 + 0.3
+    for d in (1, 2, 3):
+        al = min(0.99, math.exp(-0.5 * d * d / sigma2))
+        want = al * c + (1 - al) * bg
+        assert torch.allclose(img[:, 16, 16 + d], want, atol=2e-5), d
+        assert torch.allclose(img[:, 16 + d, 16], want, atol=2e-5), d
+    assert abs(float(out['mask'][0, 16, 16].detach()) - 0.99) < 1e-6
+    assert abs(float(out['depthmap'][0, 16, 16].detach()) - 0.99 * z0) < 1e-5
+    # isotropic: mid^2 - det = 0, upstream floors that at 0.1 before the sqrt (oracle step 5)
+    assert int(out['radius'][0]) == math.ceil(3 * math.sqrt(sigma2 + math.sqrt(0.1)))
+
+
+def test_two_layer_order_follows_depth_not_index():
+    H = W = 17
+    cam = scenes.neutral_camera(H, W, focal=40.0)
+    near = _one_gaussian((0, 0, 2.0), scale=0.1, opacity=0.8, rgb=(1, 0, 0))
+    far = _one_gaussian((0, 0, 3.0), scale=0.15, opacity=0.8, rgb=(0, 1, 0))
+    bg = torch.zeros(3)
+    i1 = ro.render(_cat(near, far), (H, W), cam, bg)['img']
+    i2 = ro.render(_cat(far, near), (H, W), cam, bg)['img']
+    assert torch.allclose(i1, i2, atol=1e-7)
+    assert torch.allclose(i1[:, 8, 8], torch.tensor([0.8, 0.2 * 0.8, 0.0]), atol=1e-5)
+
+
+def test_alpha_is_one_minus_T_and_bg_linearity():
+    a, shp, cam = scenes.make_config('c1')
+    a = {k: v[:1500] for k, v in a.items()}
+    bg1, bg2 = torch.tensor([0.1, 0.7, 0.3]), torch.tensor([0.9, 0.2, 0.6])
+    o1 = ro.render(a, shp, cam, bg1, return_aux=True)
+    o2 = ro.render(a, shp, cam, bg2)
+    T = o1['aux']['final_T']
+    assert torch.allclose(o1['mask'][0] + T, torch.ones_like(T), atol=1e-6)
+    assert torch.allclose(o1['img'] - o2['img'], T[None] * (bg1 - bg2).view(3, 1, 1), atol=1e-6)
+    assert torch.equal(o1['depthmap'], o2['depthmap'])
+
+
+def test_near_plane_cull_at_0p2():
+    H = W = 17
+    cam = scenes.neutral_camera(H, W, focal=20.0)
+    a = _cat(_one_gaussian((0, 0, 0.2)), _one_gaussian((0, 0, 0.2001)), _one_gaussian((0, 0, -1.0)))
+    out = ro.render(a, (H, W), cam, torch.ones(3))
+    assert out['radius'].tolist()[0] == 0 and out['radius'].tolist()[2] == 0
+    assert out['radius'].tolist()[1] > 0
+    assert ro.mark_visible(a['mean_3d'], ro.settings_from_camera(cam, (H, W), torch.ones(3))).tolist() == [False, True, False]
+
+
+def test_empty_inputs_render_background():
+    H, W = 20, 36
+    cam = scenes.neutral_camera(H, W)
+    empty = {'mean_3d': torch.zeros(0, 3), 'scale': torch.zeros(0, 3), 'rotation': torch.zeros(0, 4),
+             'opacity': torch.zeros(0, 1), 'rgb': torch.zeros(0, 3)}
+    bg = torch.tensor([0.3, 0.6, 0.9])
+    out = ro.render(empty, (H, W), cam, bg)
+    assert torch.equal(out['img'], bg.view(3, 1, 1).expand(3, H, W))
+    assert float(out['mask'].abs().max()) == 0.0 and out['radius'].numel() == 0
+
+
+def test_no_seam_at_non_multiple_of_16_width():
+    # 540 px wide: 33.75 tiles; a Gaussian straddling x = 528..539 must be continuous across tile edges
+    H, W = 32, 540
+    f, z0, sc = 400.0, 2.0, 0.02
+    cam = scenes.neutral_camera(H, W, focal=f)
+    x = (531.0 - W / 2 + 0.5) / f * z0          # pixel centre (531, 16)
+    y = (16.0 - H / 2 + 0.5) / f * z0
+    a = _one_gaussian((x, y, z0), scale=sc, opacity=0.9, rgb=(1, 1, 1))
+    out = ro.render(a, (H, W), cam, torch.zeros(3))
+    row = out['img'][0, 16, 515:540].detach()
+    # EWA: off-axis Jacobian widens the x variance by (1 + (x/z)^2)
+    sigma2 = (sc * f / z0) ** 2 * (1 + (x / z0) ** 2) + 0.3
+    want = torch.tensor([min(0.99, 0.9 * math.exp(-0.5 * (xx - 531.0) ** 2 / sigma2)) for xx in range(515, 540)])
+    want = torch.where(want >= 1 / 255., want, torch.zeros_like(want))
+    assert torch.allclose(row, want, atol=1e-4)
+    assert float(row[13]) > 0.5 and float(row[12]) > 0.5      # x = 528 / 527: both sides of the tile edge
+
+
+def test_tile_rect_clips_contributions_outside_3_sigma_tiles():
+    # opaque Gaussian: alpha >= 1/255 extends to 3.33 sigma, beyond the ceil(3 sigma) tile rect (oracle step 7)
+    H = W = 64
+    f = 64.0
+    cam = scenes.neutral_camera(H, W, focal=f)
+    sigma_px = 4.8
+    s = math.sqrt(sigma_px ** 2 - 0.3) / f * 2.0
+    # centre at pixel (24.0, 31.5): radius = ceil(14.4) = 15 -> x tiles [0, 3): columns >= 48 never see it
+    x = (24.0 - W / 2 + 0.5) / f * 2.0
+    a = _one_gaussian((x, 0.0, 2.0), scale=s, opacity=1.0, rgb=(1, 1, 1))
+    out = ro.render(a, (H, W), cam, torch.zeros(3))
+    r = int(out['radius'][0])
+    assert r == 15
+    d = 15.5    # pixel x = 39.5 does not exist; use x = 39 (inside rect) and check value, then a column outside
+    assert float(out['img'][0, 31, 39]) > 1 / 255.
+    assert float(out['img'][0, 31, 48:].abs().max()) == 0.0
+
+
+def test_invalid_argument_combinations_raise():
+    a, shp, cam = scenes.make_config('c1')
+    a = {k: v[:10] for k, v in a.items()}
+    s = ro.settings_from_camera(cam, shp, torch.ones(3))
+    m2 = torch.zeros(10, 3)
+    with pytest.raises(Exception):
+        ro.rasterize(a['mean_3d'], m2, a['opacity'], shs=None, colors_precomp=None, scales=a['scale'],
+                     rotations=a['rotation'], settings=s)
+    with pytest.raises(Exception):
+        ro.rasterize(a['mean_3d'], m2, a['opacity'], colors_precomp=a['rgb'], scales=a['scale'], rotations=None,
+                     settings=s)
+    with pytest.raises(Exception):
+        ro.rasterize(a['mean_3d'], m2, a['opacity'], colors_precomp=a['rgb'], scales=a['scale'],
+                     rotations=a['rotation'], cov3D_precomp=torch.zeros(10, 6), settings=s)
+
+
+def test_cov3d_precomp_path_equals_scale_rotation_path():
+    a, shp, cam = scenes.make_config('c1')
+    a = {k: v[:800] for k, v in a.items()}
+    s = ro.settings_from_camera(cam, shp, torch.ones(3))
+    m2 = torch.zeros(800, 3)
+    o1 = ro.rasterize(a['mean_3d'], m2, a['opacity'], colors_precomp=a['rgb'], scales=a['scale'],
+                      rotations=a['rotation'], settings=s)
+    S = ro.cov3d_from_scale_rot(a['scale'], a['rotation'], 1.0)
+    c6 = torch.stack((S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]), 1)
+    o2 = ro.rasterize(a['mean_3d'], m2, a['opacity'], colors_precomp=a['rgb'], cov3D_precomp=c6, settings=s)
+    assert torch.allclose(o1[0], o2[0], atol=2e-5)
+
+
+# ---------------------------------------------------------------- gradients: float64 finite differences
+def test_float64_autograd_matches_finite_differences():
+    torch.manual_seed(0)
+    H, W = 24, 24
+    P = 24
+    a = scenes.dist_a_random(P, H, W, seed=2, focal=30.0, z_range=(1.5, 3.0))
+    cam = scenes.neutral_camera(H, W, focal=30.0)
+    g = torch.Generator().manual_seed(1)
+    G = torch.randn(3, H, W, generator=g, dtype=torch.float64)
+    Gd = torch.randn(1, H, W, generator=g, dtype=torch.float64)
+    Ga = torch.randn(1, H, W, generator=g, dtype=torch.float64)
+    bg = torch.rand(3, generator=g)
+
+    def loss_of(assets):
+        o = ro.render(assets, (H, W), cam, bg, dtype=torch.float64)
+        return (o['img'] * G).sum() + (o['depthmap'] * Gd).sum() + (o['mask'] * Ga).sum(), o
+
+    base = {k: v.double().clone().requires_grad_(True) for k, v in a.items()}
+    L, o = loss_of(base)
+    L.backward()
+    m2_grad = o['mean_2d'].grad
+    assert float(m2_grad[:, 2].abs().max()) == 0.0
+    rng = np.random.RandomState(0)
+    for k, eps in (('mean_3d', 1e-6), ('scale', 1e-7), ('rotation', 1e-6), ('opacity', 1e-6), ('rgb', 1e-6)):
+        for _ in range(6):
+            i = rng.randint(P)
+            j = rng.randint(a[k].shape[1])
+            hi = {kk: v.double().clone() for kk, v in a.items()}
+            lo = {kk: v.double().clone() for kk, v in a.items()}
+            hi[k][i, j] += eps
+            lo[k][i, j] -= eps
+            fd = (float(loss_of(hi)[0]) - float(loss_of(lo)[0])) / (2 * eps)
+            an = float(base[k].grad[i, j])
+            assert abs(fd - an) <= 2e-4 * max(1.0, abs(an)), (k, i, j, fd, an)
+
+
+def test_means2d_gradient_is_pixel_gradient_times_half_size():
+    # d L / d means2D == d L / d pix * (W/2, H/2): shift the Gaussian by one pixel via means2D units
+    H, W = 32, 48
+    cam = scenes.neutral_camera(H, W, focal=40.0)
+    a = scenes.dist_a_random(40, H, W, seed=4, focal=40.0)
+    a64 = {k: v.double().requires_grad_(True) for k, v in a.items()}
+    s = ro.settings_from_camera(cam, (H, W), torch.ones(3))
+    m2 = torch.zeros(40, 3, dtype=torch.float64, requires_grad=True)
+    G = torch.randn(3, H, W, dtype=torch.float64)
+    out = ro.rasterize(a64['mean_3d'], m2, a64['opacity'], colors_precomp=a64['rgb'], scales=a64['scale'],
+                       rotations=a64['rotation'], settings=s, dtype=torch.float64)
+    (out[0] * G).sum().backward()
+    eps = 1e-7
+    i = 7
+    for ax in (0, 1):
+        mp = torch.zeros(40, 3, dtype=torch.float64)
+        mm = torch.zeros(40, 3, dtype=torch.float64)
+        mp[i, ax] = eps
+        mm[i, ax] = -eps
+        f = lambda m: float((ro.rasterize(a64['mean_3d'].detach(), m, a64['opacity'].detach(),
+                                          colors_precomp=a64['rgb'].detach(), scales=a64['scale'].detach(),
+                                          rotations=a64['rotation'].detach(), settings=s, dtype=torch.float64)[0] * G).sum())
+        fd = (f(mp) - f(mm)) / (2 * eps)
+        assert abs(fd - float(m2.grad[i, ax])) <= 1e-4 * max(1.0, abs(fd))
+
+
+def test_float32_and_float64_oracles_agree_away_from_thresholds():
+    a, shp, cam = scenes.make_config('c1')
+    a = {k: v[:3000] for k, v in a.items()}
+    o32 = ro.render(a, shp, cam, torch.ones(3), return_aux=True)
+    o64 = ro.render(a, shp, cam, torch.ones(3), dtype=torch.float64)
+    amb = ro.ambiguous_pixel_mask(o32['aux'], *shp, rel=1e-4, include_gaussians=True)
+    d = (o32['img'].double() - o64['img']).abs()
+    d[:, amb] = 0
+    assert float(d.max()) < 5e-5
