@@ -129,8 +129,11 @@ def main():
         color, radii, depth, alpha = rasterize_gaussians(m3, mean_2d, None, rgb, op, sc, rot, None, settings)
         grads = torch.autograd.grad([color], params + [mean_2d], grad_outputs=[dL_dimg])
         if world > 1:
-            torch._foreach_copy_(grad_views, list(grads[:5]))
-        return grads
+            # pack for the all-reduce with elementwise kernels (copy_ would become hipMemcpyAsync graph nodes,
+            # which break stream capture in the ROCm runtime bundled with torch 2.10)
+            for v_, g_ in zip(grad_views, grads[:5]):
+                torch.add(g_, 0.0, out=v_)
+        return None
 
     # ---- calibrate the instance-buffer capacity over this rank's views (exact mode, untimed) -------
     probe = range(len(my_views))        # every view of the shard: the capacity below provably covers them

@@ -13,8 +13,9 @@ after the binning stage.  Two policies (``config.mode``):
 
 * ``'exact'`` (default, what upstream does): stage 1, read D back (16-byte D2H copy, one stream
   sync), allocate exactly, stage 2.
-* ``'capacity'``: one fused call with a buffer sized from the D of earlier calls
-  (x ``config.capacity_growth``); no host sync and hipGraph-capturable.  An overflow is latched on
+* ``'capacity'``: one fused call with a buffer sized from the D of earlier calls of the same shape
+  (x ``config.capacity_growth``; the first call of a shape runs in exact mode to measure D), or from
+  ``config.fixed_capacity``; no host sync and hipGraph-capturable.  An overflow is latched on
   the device, surfaced by :func:`check_overflow` (also called at the start of every later call
   once the asynchronous read-back has landed) and raises ``RuntimeError``.
 """
@@ -165,25 +166,33 @@ class _RasterizeGaussians(torch.autograd.Function):
             img = torch.empty(int(sz.img_bytes) if need_ctx else 0, **u8)
             inputs = (_ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales), _ptr(rotations),
                       _ptr(cov3Ds_precomp))
-            if config.mode == 'exact':
+            mode = config.mode
+            if mode not in ('exact', 'capacity'):
+                raise ValueError('config.mode must be "exact" or "capacity"')
+            key = (device.index, P, H, W)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if mode == 'capacity' and config.fixed_capacity is None and key not in _seen_D:
+                if capturing:
+                    raise RuntimeError('exavatar_release_amd: capacity mode needs config.fixed_capacity (or one '
+                                       'earlier un-captured call of the same shape) before stream capture')
+                mode = 'exact'            # first call of this shape: measure D once, like upstream does
+            if mode == 'exact':
                 _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
                                                       _ptr(tile), stream))
                 hdr = tile[:16].view(torch.int32).cpu()          # D2H + sync, as upstream does
                 capacity = max(int(hdr[0]), 1)
+                _seen_D[key] = max(_seen_D.get(key, 0), int(hdr[0]))
                 bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward_render(ctypes.byref(st), P, _ptr(geom), _ptr(tile), _ptr(bins),
                                                          capacity, _ptr(img), _ptr(color), _ptr(depth), _ptr(alpha),
                                                          int(need_ctx), stream))
-            elif config.mode == 'capacity':
-                capturing = torch.cuda.is_current_stream_capturing()
+            else:
                 if not capturing:
                     _drain_pending()          # event queries are illegal during stream capture
-                key = (device.index, P, H, W)
-                seen = _seen_D.get(key, 0)
                 if config.fixed_capacity is not None:
                     capacity = int(config.fixed_capacity)
                 else:
-                    capacity = max(int(seen * config.capacity_growth), config.min_capacity, 4 * P)
+                    capacity = max(int(_seen_D[key] * config.capacity_growth), config.min_capacity)
                 bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
                                                   _ptr(tile), _ptr(bins), capacity, _ptr(img), _ptr(color),
@@ -194,8 +203,6 @@ class _RasterizeGaussians(torch.autograd.Function):
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(device))
                     _pending.append((ev, host, key, capacity))
-            else:
-                raise ValueError('config.mode must be "exact" or "capacity"')
 
         _debug_last['tile'] = tile
         _debug_last['capacity'] = capacity

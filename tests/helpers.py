@@ -3,7 +3,7 @@ import torch
 
 IMG_TOL = 1e-4        # per-pixel L-infinity on colour / depth / alpha (north_star)
 GRAD_REL_TOL = 1e-3   # relative gradient error (north_star)
-AMBIGUOUS_MAX_FRACTION = 1e-3   # pixels whose discrete decisions sit within 1e-5 of a threshold
+AMBIGUOUS_MAX_FRACTION = 5e-3   # pixels whose discrete decisions sit within 1e-4 (relative) of a threshold
 AMBIGUOUS_TOL = 2e-2            # such a pixel may flip one alpha >= 1/255 / T < 1e-4 decision
 
 

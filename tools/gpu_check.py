@@ -33,7 +33,7 @@ def run(name, do_oracle=True):
     t = time.time()
     (ref['img'] * G).sum().backward()
     print(name, 'oracle bwd %.2f s' % (time.time() - t))
-    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W, rel=1e-5, include_gaussians=False)
+    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W, include_gaussians=False)
     print('ambiguous pixels', int(amb.sum()))
     for k, rk in (('img', 'img'), ('depthmap', 'depthmap'), ('mask', 'mask')):
         d = (out[k].detach().cpu() - ref[rk].detach()).abs()
