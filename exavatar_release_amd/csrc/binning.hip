@@ -76,6 +76,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
         w.header->num_rendered = carry_i;
         w.header->max_tile_list = carry_e;     // reused slot: number of (Gaussian, cell) entries
     }
+    // Launch order of the per-pixel kernels: cells bucketed by floor(log2(instances)) (33 buckets),
+    // heaviest bucket first, so the longest lists start early and the tail of the launch is light.
+    __shared__ uint32_t s_bucket[34];
+    if (tid < 34) s_bucket[tid] = 0u;
+    __syncthreads();
+    for (int c = tid; c < cells; c += SCAN_THREADS) {
+        const uint32_t n = (uint32_t)(w.cell_cnt[c] >> 32);
+        atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u);       // bucket 0 = empty, 32 = largest
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 32; b >= 0; --b) { const uint32_t n = s_bucket[b]; s_bucket[b] = run; run += n; }
+    }
+    __syncthreads();
+    for (int c = tid; c < cells; c += SCAN_THREADS) {
+        const uint32_t n = (uint32_t)(w.cell_cnt[c] >> 32);
+        w.cell_order[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = (uint32_t)c;
+    }
     uint32_t carry = 0;
     for (int base = 0; base < chunks; base += SCAN_THREADS) {
         const int c = base + tid;
@@ -109,12 +128,17 @@ __global__ __launch_bounds__(BLOCK) void cell_scatter_kernel(int P, Splat* __res
     constexpr int PER = CHUNK / BLOCK;
     uint4 r3[PER];
     int ids[PER];
+    uint32_t depth_bits[PER];
     uint32_t mine = 0;
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
         ids[it] = blockIdx.x * CHUNK + it * BLOCK + tid;
         r3[it] = make_uint4(0, 0, 0, 0);
-        if (ids[it] < P) r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
+        depth_bits[it] = 0;
+        if (ids[it] < P) {
+            r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
+            depth_bits[it] = reinterpret_cast<const uint4*>(splats + ids[it])[0].z;
+        }
         mine += r3[it].z;
     }
     uint32_t total;
@@ -147,30 +171,31 @@ __global__ __launch_bounds__(BLOCK) void cell_scatter_kernel(int P, Splat* __res
                     const int c = cy * g.cx + cx;
                     const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[c], 1u, __ATOMIC_RELAXED,
                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                    b.bucket[s_base[c] + r] = (uint32_t)ids[it];
+                    b.bucket[s_base[c] + r] = make_uint4((uint32_t)ids[it], depth_bits[it], r3[it].x, r3[it].y);
                 }
         }
     }
 }
 
-// One workgroup per cell: second radix digit.  Counts the cell's entries per 8x8 sub-tile in LDS, turns
-// the counts into [begin, end) ranges (cell-major sub-tile order) and scatters the sort keys.
-__global__ __launch_bounds__(BLOCK) void subtile_bin_kernel(const Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
-                                                            uint64_t capacity) {
+// One 1024-thread workgroup per cell: second radix digit.  Counts the cell's entries per 8x8 sub-tile in
+// LDS, turns the counts into [begin, end) ranges (cell-major sub-tile order) and scatters the sort keys.
+// Entries are 16-byte records read coalesced; no gather from the splat array.
+constexpr int BIN_THREADS = 1024;
+__global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid g, BinWs b, uint64_t capacity) {
     __shared__ uint32_t s_cnt[SUBS_PER_CELL];
     __shared__ uint32_t s_off[SUBS_PER_CELL];
     __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
-    const int cell = blockIdx.x, tid = threadIdx.x;
+    const int cell = (int)w.cell_order[blockIdx.x], tid = threadIdx.x;
     const bool overflow = (uint64_t)w.header->num_rendered > capacity;
     const uint2 o0 = w.cell_off[cell], o1 = w.cell_off[cell + 1];
     const uint32_t e0 = o0.x, e1 = overflow ? o0.x : o1.x;
     if (tid < SUBS_PER_CELL) { s_cnt[tid] = 0u; s_cnt2[tid] = 0u; }
     __syncthreads();
     const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
-    for (uint32_t e = e0 + tid; e < e1; e += BLOCK) {
-        const uint4 r3 = reinterpret_cast<const uint4*>(splats + b.bucket[e])[3];
-        const int x0 = max((int)(r3.x & 0xffff) - csx0, 0), x1 = min((int)(r3.x >> 16) - csx0, CELL_SUBS);
-        const int y0 = max((int)(r3.y & 0xffff) - csy0, 0), y1 = min((int)(r3.y >> 16) - csy0, CELL_SUBS);
+    for (uint32_t e = e0 + tid; e < e1; e += BIN_THREADS) {
+        const uint4 en = b.bucket[e];
+        const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
+        const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x)
                 __hip_atomic_fetch_add(&s_cnt[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -184,13 +209,11 @@ __global__ __launch_bounds__(BLOCK) void subtile_bin_kernel(const Splat* __restr
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
     }
     __syncthreads();
-    for (uint32_t e = e0 + tid; e < e1; e += BLOCK) {
-        const uint32_t id = b.bucket[e];
-        const uint4* rec = reinterpret_cast<const uint4*>(splats + id);
-        const uint4 r3 = rec[3];
-        const unsigned long long key = ((unsigned long long)rec[0].z << 32) | id;
-        const int x0 = max((int)(r3.x & 0xffff) - csx0, 0), x1 = min((int)(r3.x >> 16) - csx0, CELL_SUBS);
-        const int y0 = max((int)(r3.y & 0xffff) - csy0, 0), y1 = min((int)(r3.y >> 16) - csy0, CELL_SUBS);
+    for (uint32_t e = e0 + tid; e < e1; e += BIN_THREADS) {
+        const uint4 en = b.bucket[e];
+        const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
+        const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
+        const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 const int s = y * CELL_SUBS + x;
@@ -223,7 +246,8 @@ hipError_t launch_cell_scatter(int P, Splat* splats, const TileWs& w, const Grid
 hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
                               hipStream_t s) {
     if (g.cells == 0) return hipSuccess;
-    subtile_bin_kernel<<<g.cells, BLOCK, 0, s>>>(splats, w, g, b, capacity);
+    (void)splats;
+    subtile_bin_kernel<<<g.cells, BIN_THREADS, 0, s>>>(w, g, b, capacity);
     return hipGetLastError();
 }
 

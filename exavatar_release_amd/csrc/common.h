@@ -22,7 +22,7 @@ constexpr int CELL = SUB * CELL_SUBS;      // 64 px
 constexpr int SUBS_PER_CELL = CELL_SUBS * CELL_SUBS;   // 64
 constexpr int BLOCK = 256;                 // threads per workgroup (4 waves)
 constexpr int CHUNK = 512;                 // Gaussians per workgroup in the per-Gaussian binning kernels
-constexpr int MAX_CELLS = 8192;            // LDS histogram budget (64 KiB of u64) -> images up to ~5700^2
+constexpr int MAX_CELLS = 4096;            // LDS histogram budget (48 KiB of counters) -> images up to 4096x4096
 constexpr int SORT_CAP = 1024;             // per-sub-tile list length sorted inside LDS (8 KiB of keys per wave)
 constexpr int HEADER_BYTES = 256;
 
@@ -88,6 +88,7 @@ struct TileWs {
     uint2* cell_off;                  // [cells + 1]  exclusive prefix (entries, instances)
     uint32_t* chunk_inst;             // [chunks]     instances emitted by each 512-Gaussian chunk
     uint32_t* chunk_off;              // [chunks]     exclusive prefix of chunk_inst
+    uint32_t* cell_order;             // [cells]      cells by descending instance count (heavy work first)
     uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays
     uint32_t* max_contrib;            // [subtiles]   last list position any pixel of the sub-tile blended
 };
@@ -96,7 +97,8 @@ __host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
 }
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return tile_ws_zero_bytes(cells) + align256(uint64_t(cells + 1) * 8) + 2 * align256(uint64_t(chunks + 1) * 4) +
-           align256(uint64_t(cells) * SUBS_PER_CELL * 8) + align256(uint64_t(cells) * SUBS_PER_CELL * 4);
+           align256(uint64_t(cells) * 4) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
+           align256(uint64_t(cells) * SUBS_PER_CELL * 4);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -107,20 +109,24 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.cell_off = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells + 1) * 8);
     w.chunk_inst = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.chunk_off = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
+    w.cell_order = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.max_contrib = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 
-// bin workspace: keys[cap] (u64: depth bits << 32 | gaussian id), sorted ids[cap], cell buckets[cap].
-__host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) { return align256(cap * 8) + 2 * align256(cap * 4); }
-struct BinWs { unsigned long long* keys; uint32_t* sorted; uint32_t* bucket; };
+// bin workspace: keys[cap] (u64: depth bits << 32 | gaussian id), sorted ids[cap], cell buckets[cap]
+// (16-byte entries {id, depth bits, sub-tile rect x, y} so the second digit reads them coalesced).
+__host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) {
+    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16);
+}
+struct BinWs { unsigned long long* keys; uint32_t* sorted; uint4* bucket; };
 __host__ __device__ inline BinWs carve_bin_ws(void* base, uint64_t cap) {
     BinWs b;
     char* p = static_cast<char*>(base);
     b.keys = reinterpret_cast<unsigned long long*>(p); p += align256(cap * 8);
     b.sorted = reinterpret_cast<uint32_t*>(p); p += align256(cap * 4);
-    b.bucket = reinterpret_cast<uint32_t*>(p);
+    b.bucket = reinterpret_cast<uint4*>(p);
     return b;
 }
 
@@ -137,12 +143,14 @@ __host__ __device__ inline ImgWs carve_img_ws(void* base, int W, int H) {
 // backward scratch: one Partial per instance.
 __host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * sizeof(Partial)); }
 
-// cell-major sub-tile index -> coordinates
-struct SubTile { int cell, local, ox, oy, gsx, gsy; };
-__device__ __forceinline__ SubTile decode_subtile(int st, const Grid& g) {
+// (launch slot, cell order) -> sub-tile.  Slot b*4+w of the render kernels is sub-tile `local` of the
+// cell_order[slot >> 6]-th heaviest cell; `st` = cell * 64 + local indexes ranges / max_contrib.
+struct SubTile { int st, cell, local, ox, oy, gsx, gsy; };
+__device__ __forceinline__ SubTile decode_subtile(int slot, const Grid& g, const uint32_t* __restrict__ cell_order) {
     SubTile s;
-    s.cell = st >> 6;
-    s.local = st & 63;
+    s.cell = (int)cell_order[slot >> 6];
+    s.local = slot & 63;
+    s.st = s.cell * SUBS_PER_CELL + s.local;
     const int cxi = s.cell % g.cx, cyi = s.cell / g.cx;
     s.gsx = cxi * CELL_SUBS + (s.local & 7);        // global sub-tile coordinates
     s.gsy = cyi * CELL_SUBS + (s.local >> 3);

@@ -4,8 +4,9 @@
 // workgroup, no __syncthreads.  The sorted id list written by the forward pass is replayed from the last
 // position any pixel of the sub-tile blended (`max_contrib`) down to the front in batches of 64 splats
 // staged through the wave's LDS slice.  For every splat with at least one contributing lane the ten
-// partial sums are reduced across the wave with DPP (row_shr 1/2/4/8, row_bcast15, row_bcast31 -- no
-// LDS, no shuffles through memory) and lane 63 parks them in LDS; at the end of the batch the 64 lanes
+// partial sums are reduced across the wave with a packed DPP / permlane-swap butterfly (two transposing
+// quad_perm steps shrink 10 registers to 3, then row_shr:4/8 + v_permlane16/32_swap -- no LDS traffic)
+// and four lanes park them in LDS; at the end of the batch the 64 lanes
 // store their splat's 48-byte `Partial` to its Gaussian-major slot with plain stores.  Every instance
 // of the list gets its slot written exactly once (zeros when nothing contributed), so there is no
 // memset and NO atomic in the whole backward pass: device-scope fp32 atomics run at ~12 G/s on
@@ -26,16 +27,57 @@ namespace exa {
 constexpr int WAVES = BLOCK / 64;
 constexpr int NACC = 10;   // mx my mxx mxy myy dop dr dg db dz
 
-// Full wave64 sum with DPP; the total ends up in lane 63.
-__device__ __forceinline__ float wave_reduce_to_lane63(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
-    // lane 15 of each row holds its row total; row_bcast15 -> rows 1,3 ; row_bcast31 -> rows 2,3
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false));
-    return v;
+// ---- packed wave64 reduction of the ten partial sums ------------------------------------------------
+// A plain DPP reduction costs 6 steps x 10 values.  Here the first two butterfly steps (lane ^ 1, lane ^ 2,
+// DPP quad_perm) also TRANSPOSE: a lane keeps half of its registers and ships the other half, so 10
+// registers shrink to 5 and then to 3, each holding four different sums selected by (lane & 3).  The
+// remaining steps (row_shr:4, row_shr:8, v_permlane16_swap, v_permlane32_swap) only run on 3 registers.
+// Result: lanes 12..15 of every row hold   q0 = {v0,v1,v2,v3}[lane&3], q1 = {v4..v7}, q2 = {v8,v9,v8,v9}.
+__device__ __forceinline__ float dpp_quad_xor1(float x) {      // quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {      // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float reduce_rows_and_wave(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));  // row_shr:4
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));  // row_shr:8
+    // v_permlane{16,32}_swap exchange halves BETWEEN two registers (vdst odd rows / upper half <-> src even
+    // rows / lower half).  Inline asm: with hipcc 7.2 the builtins return the new vdst in BOTH result slots
+    // (probed on gfx950, tools/probe/reduce_probe.hip), so the second register would be lost.
+    // `s_nop 1` = the two wait states a VALU write needs before v_permlane*_swap reads it.
+    {   // rows 0<->1, 2<->3:  a = [x0 x0 x2 x2], b = [x1 x1 x3 x3]
+        float a = x, b = x;
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        x = a + b;
+    }
+    {   // halves:  a = [lo lo], b = [hi hi]
+        float a = x, b = x;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+        x = a + b;
+    }
+    return x;
+}
+__device__ __forceinline__ void packed_reduce10(const float (&v)[10], bool odd, bool hi, float& q0, float& q1, float& q2) {
+    float r[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const float keep = odd ? b : a, send = odd ? a : b;
+        r[i] = keep + dpp_quad_xor1(send);                 // even lanes: pair-sum of a, odd lanes: pair-sum of b
+    }
+    {
+        const float keep = hi ? r[1] : r[0], send = hi ? r[0] : r[1];
+        q0 = keep + dpp_quad_xor2(send);                   // lane&3 -> quad sums of v0, v1, v2, v3
+    }
+    {
+        const float keep = hi ? r[3] : r[2], send = hi ? r[2] : r[3];
+        q1 = keep + dpp_quad_xor2(send);                   // v4 .. v7
+    }
+    q2 = r[4] + dpp_quad_xor2(r[4]);                       // v8, v9, v8, v9
+    q0 = reduce_rows_and_wave(q0);
+    q1 = reduce_rows_and_wave(q1);
+    q2 = reduce_rows_and_wave(q2);
 }
 
 __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
@@ -47,8 +89,8 @@ __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int st = blockIdx.x * WAVES + wave;
-    const SubTile sub = decode_subtile(st, a.grid);
+    const SubTile sub = decode_subtile(blockIdx.x * WAVES + wave, a.grid, a.tw.cell_order);
+    const int st = sub.st;
     if (sub.ox >= a.grid.W || sub.oy >= a.grid.H) return;
     const uint2 range = a.tw.ranges[st];
     const int n = (int)(range.y - range.x);
@@ -140,12 +182,14 @@ __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
                     v[5] = G * dL_dalpha;
                     v[6] = wgt * gr; v[7] = wgt * gg; v[8] = wgt * gb; v[9] = wgt * gd;
                 }
-#pragma unroll
-                for (int i = 0; i < NACC; ++i) v[i] = wave_reduce_to_lane63(v[i]);
-                if (lane == 63) {
-                    outs[k][0] = make_float4(v[0], v[1], v[2], v[3]);
-                    outs[k][1] = make_float4(v[4], v[5], v[6], v[7]);
-                    outs[k][2] = make_float4(v[8], v[9], 0.f, 0.f);
+                float q0, q1, q2;
+                packed_reduce10(v, (lane & 1) != 0, (lane & 2) != 0, q0, q1, q2);
+                // lanes 12..15 hold the totals: Partial layout {v0..v3 | v4..v7 | v8, v9, 0, 0}
+                if ((lane & ~3) == 12) {
+                    float* o = reinterpret_cast<float*>(&outs[k][0]) + (lane & 3);
+                    o[0] = q0;
+                    o[4] = q1;
+                    if ((lane & 2) == 0) o[8] = q2;
                 }
             }
             wave_lds_fence();

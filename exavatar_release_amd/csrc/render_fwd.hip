@@ -88,15 +88,15 @@ __global__ __launch_bounds__(BLOCK) void render_fwd_kernel(RenderFwdArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int st = blockIdx.x * WAVES + wave;
-    const SubTile sub = decode_subtile(st, a.grid);
+    const SubTile sub = decode_subtile(blockIdx.x * WAVES + wave, a.grid, a.tw.cell_order);
+    const int st = sub.st;
     if (sub.ox >= a.grid.W || sub.oy >= a.grid.H) return;       // padding sub-tile of a border cell
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
     const bool inside = pxi < a.grid.W && pyi < a.grid.H;
     const float fx = (float)pxi, fy = (float)pyi;
 
     const bool overflow = (uint64_t)a.tw.header->num_rendered > a.capacity;
-    if (overflow && st == 0 && lane == 0) a.tw.header->overflow = 1u;
+    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) a.tw.header->overflow = 1u;
     const uint2 range = a.tw.ranges[st];
     const int n = overflow ? 0 : (int)(range.y - range.x);
 
