@@ -262,8 +262,9 @@ def main():
         alg = {   # algorithmic bytes per launch (DESIGN.md section "Kernels"; SURVEY.md 8(d) per-unit figures)
             'preprocess_fwd': 60 * P + 64 * V,
             'cell_scatter': 16 * V + 4 * V + 4 * V,
-            'subtile_bin': 4 * V + 32 * V + 8 * D,
-            'render_fwd': 12 * D + 40 * V + 28 * WH,
+            'subtile_bin': 16 * V + 8 * D,
+            'sort_subtiles': 12 * D,
+            'render_fwd': 4 * D + 40 * V + 28 * WH,
             'render_bwd': 4 * D + 80 * V + 28 * WH,
             'preprocess_bwd': 40 * V + 44 * V + 68 * P,
         }

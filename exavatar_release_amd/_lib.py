@@ -63,7 +63,7 @@ SIGNATURES = {
     'exa_raster_timing_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _I32]),
     'exa_raster_timing_name': (ctypes.c_char_p, [_I32]),
 }
-TIMING_SLOTS = 8
+TIMING_SLOTS = 9
 
 _lib = None
 

@@ -34,11 +34,11 @@ int debug_sync(const ExaRasterSettings* s, hipStream_t st, const char* where) {
     return 0;
 }
 
-enum { K_ZERO, K_PREPROCESS_FWD, K_CELL_SCAN, K_CELL_SCATTER, K_SUBTILE_BIN, K_RENDER_FWD, K_RENDER_BWD,
+enum { K_ZERO, K_PREPROCESS_FWD, K_CELL_SCAN, K_CELL_SCATTER, K_SUBTILE_BIN, K_SORT, K_RENDER_FWD, K_RENDER_BWD,
        K_PREPROCESS_BWD, K_COUNT };
 static_assert(K_COUNT == EXA_RASTER_TIMING_SLOTS, "timing slots");
 const char* const k_names[K_COUNT] = {"zero", "preprocess_fwd", "cell_scan", "cell_scatter", "subtile_bin",
-                                      "render_fwd", "render_bwd", "preprocess_bwd"};
+                                      "sort_subtiles", "render_fwd", "render_bwd", "preprocess_bwd"};
 struct Timing {
     bool enabled = false, created = false;
     hipEvent_t ev[K_COUNT][2];
@@ -158,6 +158,8 @@ int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void*
     r.grid = g; r.splats = static_cast<const Splat*>(geom_ws); r.tw = tw; r.bw = bw; r.capacity = capacity;
     r.iw = carve_img_ws(img_ws, g.W, g.H);
     r.bg = s->bg; r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha; r.store_ctx = store_ctx;
+    EXA_TIMED(K_SORT, launch_sort_subtiles(r, st), "sort_subtiles");
+    if ((rc = debug_sync(s, st, "sort_subtiles"))) return rc;
     EXA_TIMED(K_RENDER_FWD, launch_render_fwd(r, st), "render_fwd");
     if ((rc = debug_sync(s, st, "render_fwd"))) return rc;
     return 0;

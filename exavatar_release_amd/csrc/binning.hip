@@ -207,6 +207,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid
         const uint32_t begin = overflow ? 0u : o0.y + incl - n;
         s_off[tid] = begin;
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
+        // launch-order record: workgroup (blockIdx.x * 64 + tid) of the per-pixel kernels handles this sub-tile
+        w.slots[blockIdx.x * SUBS_PER_CELL + tid] = make_uint4(begin, begin + n, (uint32_t)(cell * SUBS_PER_CELL + tid), 0u);
     }
     __syncthreads();
     for (uint32_t e = e0 + tid; e < e1; e += BIN_THREADS) {

@@ -23,7 +23,6 @@ constexpr int SUBS_PER_CELL = CELL_SUBS * CELL_SUBS;   // 64
 constexpr int BLOCK = 256;                 // threads per workgroup (4 waves)
 constexpr int CHUNK = 512;                 // Gaussians per workgroup in the per-Gaussian binning kernels
 constexpr int MAX_CELLS = 4096;            // LDS histogram budget (48 KiB of counters) -> images up to 4096x4096
-constexpr int SORT_CAP = 1024;             // per-sub-tile list length sorted inside LDS (8 KiB of keys per wave)
 constexpr int HEADER_BYTES = 256;
 
 constexpr float NEAR_CULL = 0.2f;
@@ -89,7 +88,9 @@ struct TileWs {
     uint32_t* chunk_inst;             // [chunks]     instances emitted by each 512-Gaussian chunk
     uint32_t* chunk_off;              // [chunks]     exclusive prefix of chunk_inst
     uint32_t* cell_order;             // [cells]      cells by descending instance count (heavy work first)
-    uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays
+    uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays, cell-major
+    uint4* slots;                     // [subtiles]   launch-order records {begin, end, st, 0}: ONE load gives a
+                                      //              per-pixel-kernel workgroup everything it needs
     uint32_t* max_contrib;            // [subtiles]   last list position any pixel of the sub-tile blended
 };
 __host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
@@ -98,7 +99,7 @@ __host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return tile_ws_zero_bytes(cells) + align256(uint64_t(cells + 1) * 8) + 2 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 4) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
-           align256(uint64_t(cells) * SUBS_PER_CELL * 4);
+           align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 4);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -111,6 +112,7 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.chunk_off = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.cell_order = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
+    w.slots = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 16);
     w.max_contrib = reinterpret_cast<uint32_t*>(p);
     return w;
 }
@@ -143,14 +145,13 @@ __host__ __device__ inline ImgWs carve_img_ws(void* base, int W, int H) {
 // backward scratch: one Partial per instance.
 __host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * sizeof(Partial)); }
 
-// (launch slot, cell order) -> sub-tile.  Slot b*4+w of the render kernels is sub-tile `local` of the
-// cell_order[slot >> 6]-th heaviest cell; `st` = cell * 64 + local indexes ranges / max_contrib.
+// cell-major sub-tile index st = cell * 64 + local  ->  coordinates
 struct SubTile { int st, cell, local, ox, oy, gsx, gsy; };
-__device__ __forceinline__ SubTile decode_subtile(int slot, const Grid& g, const uint32_t* __restrict__ cell_order) {
+__device__ __forceinline__ SubTile decode_subtile(int st, const Grid& g) {
     SubTile s;
-    s.cell = (int)cell_order[slot >> 6];
-    s.local = slot & 63;
-    s.st = s.cell * SUBS_PER_CELL + s.local;
+    s.st = st;
+    s.cell = st >> 6;
+    s.local = st & 63;
     const int cxi = s.cell % g.cx, cyi = s.cell / g.cx;
     s.gsx = cxi * CELL_SUBS + (s.local & 7);        // global sub-tile coordinates
     s.gsy = cyi * CELL_SUBS + (s.local >> 3);
@@ -171,13 +172,12 @@ __device__ __forceinline__ float gauss_power2(float A, float B, float C, float d
 __device__ __forceinline__ float gauss_falloff2(float power2) { return __builtin_amdgcn_exp2f(power2); }
 
 // Wave-private LDS hand-off (one wave writes, the same wave reads other lanes' data): LDS operations of
-// one wave execute in order, this only stops the compiler from reordering and drains the LDS counter.
+// one wave execute in order; this stops the compiler from reordering across it and drains the LDS
+// counter ONLY (no vmcnt wait, so global prefetches stay in flight across it).
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-
 // Host-side launch helpers implemented one per .hip file.
 struct PreprocessArgs {
     int P, sh_M, sh_degree;
@@ -203,6 +203,7 @@ struct RenderFwdArgs {
     const Splat* splats; TileWs tw; BinWs bw; uint64_t capacity; ImgWs iw;
     const float* bg; float* out_color; float* out_depth; float* out_alpha; int store_ctx;
 };
+hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s);
 hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
 
 struct RenderBwdArgs {

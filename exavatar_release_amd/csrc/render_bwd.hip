@@ -24,7 +24,9 @@
 
 namespace exa {
 
-constexpr int WAVES = BLOCK / 64;
+constexpr int RBLOCK = 64;            // threads per workgroup of the per-pixel kernels: ONE wave, so a finished
+                                      // sub-tile frees its LDS slice and wave slot at once (no hostage effect)
+constexpr int WAVES = RBLOCK / 64;
 constexpr int NACC = 10;   // mx my mxx mxy myy dop dr dg db dz
 
 // ---- packed wave64 reduction of the ten partial sums ------------------------------------------------
@@ -80,7 +82,7 @@ __device__ __forceinline__ void packed_reduce10(const float (&v)[10], bool odd, 
     q2 = reduce_rows_and_wave(q2);
 }
 
-__global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
+__global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
     __shared__ float4 s_g0[WAVES][64];
     __shared__ float4 s_g1[WAVES][64];
     __shared__ float4 s_g2[WAVES][64];
@@ -89,12 +91,13 @@ __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const SubTile sub = decode_subtile(blockIdx.x * WAVES + wave, a.grid, a.tw.cell_order);
-    const int st = sub.st;
-    if (sub.ox >= a.grid.W || sub.oy >= a.grid.H) return;
-    const uint2 range = a.tw.ranges[st];
+    const uint4 slot = a.tw.slots[blockIdx.x * WAVES + wave];  // {begin, end, st, 0}
+    const uint2 range = make_uint2(slot.x, slot.y);
     const int n = (int)(range.y - range.x);
     if (n == 0) return;
+    const SubTile sub = decode_subtile((int)slot.z, a.grid);
+    const int st = sub.st;
+    if (sub.ox >= a.grid.W || sub.oy >= a.grid.H) return;
     const int n_eff = (int)a.tw.max_contrib[st];
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
     const bool inside = pxi < a.grid.W && pyi < a.grid.H;
@@ -130,21 +133,43 @@ __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // Batches cover the WHOLE list back to front; positions >= n_eff only get their zero Partial.
+    // Software pipeline: sorted ids two batches ahead, splat records one batch ahead, so the two dependent
+    // global round trips of a batch hide behind the arithmetic of the previous one.
+    const uint32_t* __restrict__ sorted = a.bw.sorted + range.x;
+    uint32_t id_next = 0;
+    float4 r0 = zero4, r1 = zero4, r2 = zero4;
+    uint4 r3 = make_uint4(0, 0, 0, 0);
+    {
+        const int bs0 = max(0, n - 64), c0 = n - bs0;
+        const uint32_t id0 = lane < c0 ? sorted[bs0 + lane] : 0u;
+        const int bs1 = max(0, bs0 - 64), c1 = bs0 - bs1;
+        if (lane < c1) id_next = sorted[bs1 + lane];
+        if (lane < c0) {
+            const float4* rec = reinterpret_cast<const float4*>(splats + id0);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            r3 = reinterpret_cast<const uint4*>(rec)[3];
+        }
+    }
     for (int bend = n; bend > 0; bend -= 64) {
         const int bstart = max(0, bend - 64);
         const int cnt = bend - bstart;
         const bool live = bstart < n_eff;                     // wave-uniform: any work in this batch?
         if (lane < cnt) {
-            const uint32_t id = a.bw.sorted[range.x + bstart + lane];
-            const float4* rec = reinterpret_cast<const float4*>(splats + id);
-            const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
             const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
             slots[lane] = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
-            if (live) {
-                g0s[lane] = rec[0];
-                g1s[lane] = rec[1];
-                g2s[lane] = rec[2];
+            g0s[lane] = r0;
+            g1s[lane] = r1;
+            g2s[lane] = r2;
+        }
+        {   // prefetch the next (closer to the camera) batch and the ids of the one after it
+            const int nbs = max(0, bstart - 64), ncnt = bstart - nbs;
+            if (lane < ncnt) {
+                const float4* rec = reinterpret_cast<const float4*>(splats + id_next);
+                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+                r3 = reinterpret_cast<const uint4*>(rec)[3];
             }
+            const int nnbs = max(0, nbs - 64), nncnt = nbs - nnbs;
+            if (lane < nncnt) id_next = sorted[nnbs + lane];
         }
         outs[lane][0] = zero4; outs[lane][1] = zero4; outs[lane][2] = zero4;
         wave_lds_fence();
@@ -206,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void render_bwd_kernel(RenderBwdArgs a) {
 
 hipError_t launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
     if (a.grid.subtiles == 0) return hipSuccess;
-    render_bwd_kernel<<<a.grid.subtiles / WAVES, BLOCK, 0, s>>>(a);
+    render_bwd_kernel<<<a.grid.subtiles / WAVES, RBLOCK, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -1,60 +1,176 @@
-// Per-sub-tile depth sort + front-to-back alpha compositing for gfx950.
+// Per-sub-tile depth sort and front-to-back alpha compositing for gfx950 -- two barrier-free kernels.
 //
-// ONE WAVE per 8x8-pixel sub-tile (lane l -> pixel (l & 7, l >> 3)); a 256-thread workgroup is four
-// independent waves working on four consecutive sub-tiles of one cell.  No __syncthreads anywhere:
-// every wave owns its list, a private LDS slice and its 64 pixels, so there is no barrier or
-// cross-wave tail to wait for and a finished wave frees its SIMD slot immediately.
-//   Phase A: the wave loads its bucket of (depth bits << 32 | id) keys into LDS and sorts it with a
-//            wave-synchronous bitonic network (ascending-only comparators: any length, no padding);
-//            for training it writes the sorted ids once for the backward pass.
-//   Phase B: the sorted list is streamed in batches of 64: each lane gathers ONE 64-byte splat record
-//            (48 B used) into the wave's LDS slice, then the 64 pixels blend the batch from LDS
-//            broadcast reads, four Gaussians per iteration so four exp2 evaluations are in flight
-//            while the serial T recurrence of the previous ones retires.
+// ONE WAVE per 8x8-pixel sub-tile (lane l -> pixel (l & 7, l >> 3)), one wave per workgroup, no
+// __syncthreads anywhere: a wave owns its list, its LDS slice and its 64 pixels, and frees its slot the
+// moment it is done.  Split in two launches so each gets the occupancy it needs:
+//   sort_subtiles_kernel  (8 KiB LDS): sorts the sub-tile's bucket of (depth bits << 32 | id) keys -- rank
+//       sorted runs of 64 merged by rank (binary search) inside LDS; lists > 1024 keys fall back to a
+//       register rank sort -- and writes the sorted ids.  Third radix digit of the binning (binning.hip).
+//   render_fwd_kernel     (3 KiB LDS / wave, <= 64 VGPRs -> 8 waves / SIMD): streams the sorted ids in
+//       batches of 64; each lane gathers ONE 64-byte splat record (48 B used) into the wave's LDS slice --
+//       ids are fetched two batches ahead and records one batch ahead, so the two dependent global
+//       round trips hide behind the blend of the current batch -- then the 64 pixels blend the batch from
+//       LDS broadcast reads, four Gaussians per iteration so four exp2 are in flight while the serial
+//       T recurrence of the previous ones retires.
 //
 // Replaces upstream SortPairs(depth digit) + renderCUDA (forward) of the rasterizer the reference
 // calls at avatar/common/nets/module.py:632-640; per-pixel rule = oracle step 9/10
 // (oracle/raster_oracle.py).
 //
-// Algorithmic HBM bytes: reads 8 B/instance (keys) + 48 B per gathered splat per sub-tile it touches
-// (L2-resident after the first touch), writes 4 B/instance (sorted ids, training only) and
-// 20 B/pixel (rgb, depth, alpha) + 8 B/pixel (final_T, n_contrib, training only).
+// Algorithmic HBM bytes: sort reads 8 B/instance, writes 4 B/instance; blend reads 4 B/instance + 48 B per
+// gathered splat per sub-tile it touches (L2-resident after the first touch), writes 20 B/pixel
+// (rgb, depth, alpha) + 8 B/pixel (final_T, n_contrib, training only).
 #include "common.h"
 
 namespace exa {
 
-constexpr int WAVES = BLOCK / 64;
+constexpr int RBLOCK = 64;            // threads per workgroup of the per-pixel kernels: ONE wave
 
-// Wave-synchronous bitonic sort of k[0..n) ascending.  Only the calling wave touches k.
-template <typename KeyPtr>
-__device__ __forceinline__ void wave_bitonic_sort_asc(KeyPtr k, int n, int lane) {
-    int m = 1;
-    while (m < n) m <<= 1;
-    const int pairs = m >> 1;
-    for (int kk = 2; kk <= m; kk <<= 1) {
-        const int half = kk >> 1;
-        // flip stage: compare i with its mirror inside each kk-block (both halves ascending)
-        for (int i = lane; i < pairs; i += 64) {
-            const int off = i & (half - 1);
-            const int blk = (i - off) << 1;
-            const int lo = blk + off, hi = blk + kk - 1 - off;
-            if (hi < n) {
-                const unsigned long long a = k[lo], b = k[hi];
-                if (a > b) { k[lo] = b; k[hi] = a; }
+constexpr int SORT_TILE = 1024;       // keys of the LDS buffer (8 KiB)
+
+// ---- sort of lists up to SORT_TILE keys: rank-sorted runs of 64 + rank-based merges, all in LDS ---------
+// Phase 1: every 64-key run is rank sorted (each lane counts the keys of its run that are smaller than its
+// own; comparands are LDS broadcast reads, two keys per ds_read_b128).  Phase 2: runs are merged pairwise,
+// doubling the run length per level; an element's merged position is its offset in its own run plus its
+// rank in the partner run, found by a binary search (keys are unique: the Gaussian id is the low word).
+// log2(n / 64) levels of <= 11 dependent LDS reads each, with n / 64 independent searches per lane in
+// flight -- versus 36-55 dependent LDS round trips of a bitonic network (measured 2-5x slower) or the
+// O(n^2) compares of a pure rank sort.
+template <int E>      // E = keys per lane: lists of up to 64 * E keys
+__device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restrict__ gkeys, int n,
+                                               uint32_t* __restrict__ sorted, unsigned long long* buf, int lane) {
+    constexpr int NPAD = 64 * E;
+    unsigned long long key[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        key[e] = i < n ? gkeys[i] : ~0ull;                    // pad with +inf keys
+        buf[i] = key[e];
+    }
+    wave_lds_fence();
+    // Every level reads the whole buffer into registers / finishes all its searches before it writes, and
+    // a wave executes in lockstep, so the levels run IN PLACE in one 8 KiB buffer.
+    // phase 1: runs of 64 (all E runs of a lane advance together: E independent chains)
+    {
+        uint32_t rank[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) rank[e] = 0;
+        const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(buf);
+#pragma unroll 4
+        for (int j = 0; j < 32; ++j) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const ulonglong2 kk = s2[e * 32 + j];
+                rank[e] += (kk.x < key[e]) ? 1u : 0u;
+                rank[e] += (kk.y < key[e]) ? 1u : 0u;
             }
         }
         wave_lds_fence();
-        for (int j = half >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < pairs; i += 64) {
-                const int lo = 2 * i - (i & (j - 1)), hi = lo + j;
-                if (hi < n) {
-                    const unsigned long long a = k[lo], b = k[hi];
-                    if (a > b) { k[lo] = b; k[hi] = a; }
-                }
-            }
-            wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            // +inf pads compare equal to each other: give them distinct slots at the end of their run
+            const uint32_t r = (e * 64 + lane >= n) ? (uint32_t)lane : rank[e];
+            buf[e * 64 + r] = key[e];
         }
     }
+    wave_lds_fence();
+    // phase 2: merge levels; the E binary searches of a lane run in lockstep (branch-free, fixed trip count)
+#pragma unroll
+    for (int L = 64, steps = 7; L < NPAD; L <<= 1, ++steps) {
+        uint32_t lohi[E];                                      // lo | hi << 16
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            key[e] = buf[e * 64 + lane];
+            lohi[e] = (uint32_t)L << 16;
+        }
+        for (int it = 0; it < steps; ++it) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = e * 64 + lane;
+                const int base = i & ~(2 * L - 1);
+                const bool first = (i - base) < L;
+                const int p0 = base + (first ? L : 0);          // partner run
+                const int lo = lohi[e] & 0xffff, hi = lohi[e] >> 16;
+                const int mid = (lo + hi) >> 1;
+                const bool act = lo < hi;
+                const unsigned long long pk = buf[p0 + min(mid, L - 1)];
+                // unique keys except the +inf pads: ties broken by run order so slots stay distinct
+                const bool less = first ? (pk < key[e]) : (pk <= key[e]);
+                const int nlo = (act && less) ? mid + 1 : lo;
+                const int nhi = (act && !less) ? mid : hi;
+                lohi[e] = (uint32_t)nlo | ((uint32_t)nhi << 16);
+            }
+        }
+        wave_lds_fence();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = e * 64 + lane;
+            const int base = i & ~(2 * L - 1);
+            const int off = i - base;
+            buf[base + (off < L ? off : off - L) + (int)(lohi[e] & 0xffff)] = key[e];
+        }
+        wave_lds_fence();
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * 64 + lane;
+        if (i < n) sorted[i] = (uint32_t)buf[i];
+    }
+}
+
+// ---- lists longer than SORT_TILE: rank sort, 1024 own keys in registers per pass, comparands staged in
+// LDS 1024 at a time.  O(n^2 / 64) but any length and no global scratch; such lists are rare.
+template <int R>
+__device__ __forceinline__ void rank_sort_list(const unsigned long long* __restrict__ gkeys, int n, int first,
+                                               uint32_t* __restrict__ sorted, unsigned long long* s_keys, int lane) {
+    unsigned long long mine[R];
+    uint32_t rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = first + r * 64 + lane;
+        mine[r] = i < n ? gkeys[i] : ~0ull;
+        rank[r] = 0;
+    }
+    for (int tile = 0; tile < n; tile += SORT_TILE) {
+        const int tn = min(SORT_TILE, n - tile);
+        wave_lds_fence();
+        for (int i = lane; i < ((tn + 1) & ~1); i += 64) s_keys[i] = i < tn ? gkeys[tile + i] : ~0ull;
+        wave_lds_fence();
+        const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(s_keys);
+#pragma unroll 4
+        for (int j = 0; j < (tn + 1) / 2; ++j) {
+            const ulonglong2 kk = s2[j];                      // wave-uniform address: LDS broadcast read
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                rank[r] += (kk.x < mine[r]) ? 1u : 0u;
+                rank[r] += (kk.y < mine[r]) ? 1u : 0u;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (first + r * 64 + lane < n) sorted[rank[r]] = (uint32_t)mine[r];
+}
+
+__global__ __launch_bounds__(RBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_bufA[SORT_TILE];
+    const int lane = threadIdx.x;
+    const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty on overflow
+    const uint2 range = make_uint2(slot.x, slot.y);
+    const int n = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));
+    if (n == 0) {
+        if (blockIdx.x == 0 && lane == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
+        return;
+    }
+    const unsigned long long* gkeys = a.bw.keys + range.x;
+    uint32_t* sorted = a.bw.sorted + range.x;
+    if (n <= 64) lds_merge_sort<1>(gkeys, n, sorted, s_bufA, lane);
+    else if (n <= 128) lds_merge_sort<2>(gkeys, n, sorted, s_bufA, lane);
+    else if (n <= 256) lds_merge_sort<4>(gkeys, n, sorted, s_bufA, lane);
+    else if (n <= 512) lds_merge_sort<8>(gkeys, n, sorted, s_bufA, lane);
+    else if (n <= 1024) lds_merge_sort<16>(gkeys, n, sorted, s_bufA, lane);
+    else
+        for (int first = 0; first < n; first += 1024) rank_sort_list<16>(gkeys, n, first, sorted, s_bufA, lane);
 }
 
 struct PixelState {
@@ -80,62 +196,51 @@ __device__ __forceinline__ void blend_one(PixelState& s, float alpha, bool valid
 }
 
 template <bool STORE>
-__global__ __launch_bounds__(BLOCK) void render_fwd_kernel(RenderFwdArgs a) {
-    __shared__ unsigned long long s_keys[WAVES][SORT_CAP];
-    __shared__ float4 s_g0[WAVES][64];
-    __shared__ float4 s_g1[WAVES][64];
-    __shared__ float4 s_g2[WAVES][64];
+__global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
+    __shared__ float4 s_g0[64];
+    __shared__ float4 s_g1[64];
+    __shared__ float4 s_g2[64];
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const SubTile sub = decode_subtile(blockIdx.x * WAVES + wave, a.grid, a.tw.cell_order);
+    const int lane = threadIdx.x;
+    const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty range on overflow
+    const SubTile sub = decode_subtile((int)slot.z, a.grid);
     const int st = sub.st;
     if (sub.ox >= a.grid.W || sub.oy >= a.grid.H) return;       // padding sub-tile of a border cell
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
     const bool inside = pxi < a.grid.W && pyi < a.grid.H;
     const float fx = (float)pxi, fy = (float)pyi;
+    const uint2 range = make_uint2(slot.x, slot.y);
+    const int n = (int)(range.y - range.x);
 
-    const bool overflow = (uint64_t)a.tw.header->num_rendered > a.capacity;
-    if (overflow && blockIdx.x == 0 && threadIdx.x == 0) a.tw.header->overflow = 1u;
-    const uint2 range = a.tw.ranges[st];
-    const int n = overflow ? 0 : (int)(range.y - range.x);
-
-    // ---- phase A: depth sort of this sub-tile's bucket --------------------------------------------
-    unsigned long long* gkeys = a.bw.keys + range.x;
-    unsigned long long* lkeys = s_keys[wave];
-    const bool in_lds = n <= SORT_CAP;
-    if (n > 0) {
-        if (in_lds) {
-            for (int i = lane; i < n; i += 64) lkeys[i] = gkeys[i];
-            wave_lds_fence();
-            if (n > 1) wave_bitonic_sort_asc(lkeys, n, lane);
-            if (STORE)
-                for (int i = lane; i < n; i += 64) a.bw.sorted[range.x + i] = (uint32_t)lkeys[i];
-        } else {
-            // rare: list longer than the LDS slice -> same network on the bucket in global memory
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-            wave_bitonic_sort_asc(gkeys, n, lane);
-            if (STORE)
-                for (int i = lane; i < n; i += 64) a.bw.sorted[range.x + i] = (uint32_t)gkeys[i];
-        }
-    }
-
-    // ---- phase B: front-to-back blend ----------------------------------------------------------
     PixelState s;
     s.T = 1.0f; s.Cr = 0.f; s.Cg = 0.f; s.Cb = 0.f; s.Dp = 0.f; s.last = 0; s.done = !inside;
     const Splat* __restrict__ splats = a.splats;
-    float4* g0s = s_g0[wave];
-    float4* g1s = s_g1[wave];
-    float4* g2s = s_g2[wave];
+    const uint32_t* __restrict__ sorted = a.bw.sorted + range.x;
+
+    // software pipeline: ids two batches ahead, records one batch ahead
+    uint32_t id_next = 0;
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    if (n > 0) {
+        const uint32_t id0 = lane < n ? sorted[lane] : 0u;
+        if (64 + lane < n) id_next = sorted[64 + lane];
+        if (lane < n) {
+            const float4* rec = reinterpret_cast<const float4*>(splats + id0);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+        }
+    }
     for (int base = 0; base < n; base += 64) {
         if (__all(s.done)) break;
-        const int j = base + lane;
-        if (j < n) {
-            const uint32_t id = in_lds ? (uint32_t)lkeys[j] : (uint32_t)gkeys[j];
-            const float4* rec = reinterpret_cast<const float4*>(splats + id);
-            g0s[lane] = rec[0];
-            g1s[lane] = rec[1];
-            g2s[lane] = rec[2];
+        s_g0[lane] = r0;
+        s_g1[lane] = r1;
+        s_g2[lane] = r2;
+        // issue the next batch's gathers and the ids of the batch after it
+        {
+            const int jn = base + 64 + lane;
+            if (jn < n) {
+                const float4* rec = reinterpret_cast<const float4*>(splats + id_next);
+                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            }
+            if (jn + 64 < n) id_next = sorted[jn + 64];
         }
         wave_lds_fence();
         const int cnt = min(64, n - base);
@@ -146,8 +251,8 @@ __global__ __launch_bounds__(BLOCK) void render_fwd_kernel(RenderFwdArgs a) {
             float4 q0[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                q0[u] = g0s[k + u];
-                const float4 q1 = g1s[k + u];
+                q0[u] = s_g0[k + u];
+                const float4 q1 = s_g1[k + u];
                 const float dx = q0[u].x - fx, dy = q0[u].y - fy;
                 const float p2 = gauss_power2(q1.x, q1.y, q1.z, dx, dy);
                 al[u] = fminf(ALPHA_MAX, q1.w * gauss_falloff2(p2));
@@ -155,18 +260,18 @@ __global__ __launch_bounds__(BLOCK) void render_fwd_kernel(RenderFwdArgs a) {
             }
             if (__any((va[0] || va[1] || va[2] || va[3]) && !s.done)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) blend_one(s, al[u], va[u], q0[u], g2s[k + u], (uint32_t)(base + k + u + 1));
+                for (int u = 0; u < 4; ++u) blend_one(s, al[u], va[u], q0[u], s_g2[k + u], (uint32_t)(base + k + u + 1));
                 if (__all(s.done)) break;
             }
         }
         for (; k < cnt; ++k) {
-            const float4 q0 = g0s[k];
-            const float4 q1 = g1s[k];
+            const float4 q0 = s_g0[k];
+            const float4 q1 = s_g1[k];
             const float dx = q0.x - fx, dy = q0.y - fy;
             const float p2 = gauss_power2(q1.x, q1.y, q1.z, dx, dy);
             const float al = fminf(ALPHA_MAX, q1.w * gauss_falloff2(p2));
             const bool va = (p2 <= 0.0f) && (al >= ALPHA_MIN);
-            if (__any(va && !s.done)) blend_one(s, al, va, q0, g2s[k], (uint32_t)(base + k + 1));
+            if (__any(va && !s.done)) blend_one(s, al, va, q0, s_g2[k], (uint32_t)(base + k + 1));
         }
         wave_lds_fence();
     }
@@ -194,13 +299,18 @@ __global__ __launch_bounds__(BLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     }
 }
 
+hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s) {
+    if (a.grid.subtiles == 0) return hipSuccess;
+    sort_subtiles_kernel<<<a.grid.subtiles, RBLOCK, 0, s>>>(a);
+    return hipGetLastError();
+}
+
 hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s) {
     if (a.grid.subtiles == 0) return hipSuccess;
-    const int blocks = a.grid.subtiles / WAVES;
     if (a.store_ctx)
-        render_fwd_kernel<true><<<blocks, BLOCK, 0, s>>>(a);
+        render_fwd_kernel<true><<<a.grid.subtiles, RBLOCK, 0, s>>>(a);
     else
-        render_fwd_kernel<false><<<blocks, BLOCK, 0, s>>>(a);
+        render_fwd_kernel<false><<<a.grid.subtiles, RBLOCK, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -158,7 +158,7 @@ int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const 
  * did not run), then clears the slots.  Slot names: exa_raster_timing_name(i), i < EXA_RASTER_TIMING_SLOTS.
  * Must not be enabled during hipGraph capture.
  */
-#define EXA_RASTER_TIMING_SLOTS 8
+#define EXA_RASTER_TIMING_SLOTS 9
 int exa_raster_timing_enable(int32_t on);
 int exa_raster_timing_read(float* ms_out, int32_t n);
 const char* exa_raster_timing_name(int32_t slot);
