@@ -3,9 +3,10 @@
 // ONE WAVE per 8x8-pixel sub-tile (lane l -> pixel (l & 7, l >> 3)), one wave per workgroup, no
 // __syncthreads anywhere: a wave owns its list, its LDS slice and its 64 pixels, and frees its slot the
 // moment it is done.  Split in two launches so each gets the occupancy it needs:
-//   sort_subtiles_kernel  (8 KiB LDS): sorts the sub-tile's bucket of (depth bits << 32 | id) keys -- rank
-//       sorted runs of 64 merged by rank (binary search) inside LDS; lists > 1024 keys fall back to a
-//       register rank sort -- and writes the sorted ids.  Third radix digit of the binning (binning.hip).
+//   sort_subtiles_kernel  (256 threads, 8 KiB LDS): four waves co-operate on one sub-tile's bucket of
+//       (depth bits << 32 | id) keys -- rank sorted runs of 64 merged by rank (binary search) in place in
+//       LDS; lists > 1024 keys fall back to a register rank sort -- and write the sorted ids.
+//       Third radix digit of the binning (binning.hip).
 //   render_fwd_kernel     (3 KiB LDS / wave, <= 64 VGPRs -> 8 waves / SIMD): streams the sorted ids in
 //       batches of 64; each lane gathers ONE 64-byte splat record (48 B used) into the wave's LDS slice --
 //       ids are fetched two batches ahead and records one batch ahead, so the two dependent global
@@ -27,31 +28,32 @@ namespace exa {
 constexpr int RBLOCK = 64;            // threads per workgroup of the per-pixel kernels: ONE wave
 
 constexpr int SORT_TILE = 1024;       // keys of the LDS buffer (8 KiB)
+constexpr int SBLOCK = 256;           // threads of a sort workgroup: four waves co-operate on ONE list
 
-// ---- sort of lists up to SORT_TILE keys: rank-sorted runs of 64 + rank-based merges, all in LDS ---------
-// Phase 1: every 64-key run is rank sorted (each lane counts the keys of its run that are smaller than its
-// own; comparands are LDS broadcast reads, two keys per ds_read_b128).  Phase 2: runs are merged pairwise,
-// doubling the run length per level; an element's merged position is its offset in its own run plus its
-// rank in the partner run, found by a binary search (keys are unique: the Gaussian id is the low word).
-// log2(n / 64) levels of <= 11 dependent LDS reads each, with n / 64 independent searches per lane in
-// flight -- versus 36-55 dependent LDS round trips of a bitonic network (measured 2-5x slower) or the
-// O(n^2) compares of a pure rank sort.
-template <int E>      // E = keys per lane: lists of up to 64 * E keys
+// ---- sort of lists up to SORT_TILE keys: rank-sorted runs of 64 + rank-based merges, in place in LDS -----
+// A single wave issues roughly one VALU instruction per 5 cycles on gfx950 (probe: tools/probe/cmp_probe.hip),
+// so the latency of a list is its instruction count; the longest lists (500-1000 keys) set the kernel time.
+// Hence four waves share one list: thread t owns elements e * 256 + t.
+//   Phase 1: every 64-key run is rank sorted by its own wave (each lane counts the keys of the run that are
+//            smaller than its own; comparands are LDS broadcast reads, two keys per ds_read_b128).
+//   Phase 2: runs are merged pairwise, doubling the run length per level; an element's merged position is
+//            its offset in its own run plus its rank in the partner run (binary search; keys are unique:
+//            the Gaussian id is the low word).  All searches of a level finish (barrier) before any write,
+//            so the levels run IN PLACE.
+template <int E>      // E = keys per thread: lists of up to 256 * E keys
 __device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restrict__ gkeys, int n,
-                                               uint32_t* __restrict__ sorted, unsigned long long* buf, int lane) {
-    constexpr int NPAD = 64 * E;
+                                               uint32_t* __restrict__ sorted, unsigned long long* buf, int tid) {
+    constexpr int NPAD = SBLOCK * E;
+    const int lane = tid & 63;
     unsigned long long key[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int i = e * 64 + lane;
+        const int i = e * SBLOCK + tid;
         key[e] = i < n ? gkeys[i] : ~0ull;                    // pad with +inf keys
         buf[i] = key[e];
     }
-    wave_lds_fence();
-    // Every level reads the whole buffer into registers / finishes all its searches before it writes, and
-    // a wave executes in lockstep, so the levels run IN PLACE in one 8 KiB buffer.
-    // phase 1: runs of 64 (all E runs of a lane advance together: E independent chains)
-    {
+    __syncthreads();
+    {   // phase 1: element i = e * 256 + tid lives in run (i >> 6); the E runs of a thread advance together
         uint32_t rank[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) rank[e] = 0;
@@ -60,33 +62,34 @@ __device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restr
         for (int j = 0; j < 32; ++j) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const ulonglong2 kk = s2[e * 32 + j];
+                const ulonglong2 kk = s2[((e * SBLOCK + tid) >> 6) * 32 + j];
                 rank[e] += (kk.x < key[e]) ? 1u : 0u;
                 rank[e] += (kk.y < key[e]) ? 1u : 0u;
             }
         }
-        wave_lds_fence();
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
+            const int i = e * SBLOCK + tid;
             // +inf pads compare equal to each other: give them distinct slots at the end of their run
-            const uint32_t r = (e * 64 + lane >= n) ? (uint32_t)lane : rank[e];
-            buf[e * 64 + r] = key[e];
+            const uint32_t r = (i >= n) ? (uint32_t)lane : rank[e];
+            buf[(i & ~63) + r] = key[e];
         }
     }
-    wave_lds_fence();
-    // phase 2: merge levels; the E binary searches of a lane run in lockstep (branch-free, fixed trip count)
+    __syncthreads();
+    // phase 2: merge levels; the E binary searches of a thread run in lockstep (branch-free, fixed trip count)
 #pragma unroll
     for (int L = 64, steps = 7; L < NPAD; L <<= 1, ++steps) {
         uint32_t lohi[E];                                      // lo | hi << 16
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            key[e] = buf[e * 64 + lane];
+            key[e] = buf[e * SBLOCK + tid];
             lohi[e] = (uint32_t)L << 16;
         }
         for (int it = 0; it < steps; ++it) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int i = e * 64 + lane;
+                const int i = e * SBLOCK + tid;
                 const int base = i & ~(2 * L - 1);
                 const bool first = (i - base) < L;
                 const int p0 = base + (first ? L : 0);          // partner run
@@ -101,45 +104,62 @@ __device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restr
                 lohi[e] = (uint32_t)nlo | ((uint32_t)nhi << 16);
             }
         }
-        wave_lds_fence();
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            const int i = e * 64 + lane;
+            const int i = e * SBLOCK + tid;
             const int base = i & ~(2 * L - 1);
             const int off = i - base;
             buf[base + (off < L ? off : off - L) + (int)(lohi[e] & 0xffff)] = key[e];
         }
-        wave_lds_fence();
+        __syncthreads();
     }
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const int i = e * 64 + lane;
+        const int i = e * SBLOCK + tid;
         if (i < n) sorted[i] = (uint32_t)buf[i];
     }
 }
 
-// ---- lists longer than SORT_TILE: rank sort, 1024 own keys in registers per pass, comparands staged in
-// LDS 1024 at a time.  O(n^2 / 64) but any length and no global scratch; such lists are rare.
+// Single-wave variant for short lists (<= 64 keys): one rank-sort pass, no barriers.
+__device__ __forceinline__ void wave_rank_sort64(const unsigned long long* __restrict__ gkeys, int n,
+                                                 uint32_t* __restrict__ sorted, unsigned long long* buf, int lane) {
+    const unsigned long long mine = lane < n ? gkeys[lane] : ~0ull;
+    buf[lane] = mine;
+    wave_lds_fence();
+    const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(buf);
+    uint32_t rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+        const ulonglong2 kk = s2[j];
+        rank += (kk.x < mine) ? 1u : 0u;
+        rank += (kk.y < mine) ? 1u : 0u;
+    }
+    if (lane < n) sorted[rank] = (uint32_t)mine;
+}
+
+// ---- lists longer than SORT_TILE: rank sort, R own keys per thread in registers per pass, comparands staged
+// in LDS 1024 at a time.  O(n^2 / 256) but any length and no global scratch; such lists are rare.
 template <int R>
 __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restrict__ gkeys, int n, int first,
-                                               uint32_t* __restrict__ sorted, unsigned long long* s_keys, int lane) {
+                                               uint32_t* __restrict__ sorted, unsigned long long* s_keys, int tid) {
     unsigned long long mine[R];
     uint32_t rank[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int i = first + r * 64 + lane;
+        const int i = first + r * SBLOCK + tid;
         mine[r] = i < n ? gkeys[i] : ~0ull;
         rank[r] = 0;
     }
     for (int tile = 0; tile < n; tile += SORT_TILE) {
         const int tn = min(SORT_TILE, n - tile);
-        wave_lds_fence();
-        for (int i = lane; i < ((tn + 1) & ~1); i += 64) s_keys[i] = i < tn ? gkeys[tile + i] : ~0ull;
-        wave_lds_fence();
+        __syncthreads();
+        for (int i = tid; i < ((tn + 1) & ~1); i += SBLOCK) s_keys[i] = i < tn ? gkeys[tile + i] : ~0ull;
+        __syncthreads();
         const ulonglong2* s2 = reinterpret_cast<const ulonglong2*>(s_keys);
 #pragma unroll 4
         for (int j = 0; j < (tn + 1) / 2; ++j) {
-            const ulonglong2 kk = s2[j];                      // wave-uniform address: LDS broadcast read
+            const ulonglong2 kk = s2[j];                      // uniform address: LDS broadcast read
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 rank[r] += (kk.x < mine[r]) ? 1u : 0u;
@@ -149,28 +169,28 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
-        if (first + r * 64 + lane < n) sorted[rank[r]] = (uint32_t)mine[r];
+        if (first + r * SBLOCK + tid < n) sorted[rank[r]] = (uint32_t)mine[r];
 }
 
-__global__ __launch_bounds__(RBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned long long s_bufA[SORT_TILE];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
+    const int tid = threadIdx.x;
     const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty on overflow
     const uint2 range = make_uint2(slot.x, slot.y);
-    const int n = __builtin_amdgcn_readfirstlane((int)(range.y - range.x));
+    const int n = (int)(range.y - range.x);                     // workgroup-uniform
     if (n == 0) {
-        if (blockIdx.x == 0 && lane == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
+        if (blockIdx.x == 0 && tid == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
         return;
     }
     const unsigned long long* gkeys = a.bw.keys + range.x;
     uint32_t* sorted = a.bw.sorted + range.x;
-    if (n <= 64) lds_merge_sort<1>(gkeys, n, sorted, s_bufA, lane);
-    else if (n <= 128) lds_merge_sort<2>(gkeys, n, sorted, s_bufA, lane);
-    else if (n <= 256) lds_merge_sort<4>(gkeys, n, sorted, s_bufA, lane);
-    else if (n <= 512) lds_merge_sort<8>(gkeys, n, sorted, s_bufA, lane);
-    else if (n <= 1024) lds_merge_sort<16>(gkeys, n, sorted, s_bufA, lane);
-    else
-        for (int first = 0; first < n; first += 1024) rank_sort_list<16>(gkeys, n, first, sorted, s_bufA, lane);
+    if (n <= 64) {
+        if (tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);
+    } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);
+    else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);
+    else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
+    else   // longer lists: 2048 own keys at a time against the whole list (any length)
+        for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
 }
 
 struct PixelState {
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
 
 hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s) {
     if (a.grid.subtiles == 0) return hipSuccess;
-    sort_subtiles_kernel<<<a.grid.subtiles, RBLOCK, 0, s>>>(a);
+    sort_subtiles_kernel<<<a.grid.subtiles, SBLOCK, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -1,0 +1,33 @@
+"""Developer probe (needs a library built with -DEXA_PROBE_SORT): per-sub-tile cycles of the sort kernel."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, numpy as np
+import exavatar_release_amd as exa
+from exavatar_release_amd import scenes, _lib
+from exavatar_release_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians, _debug_last
+from exavatar_release_amd.camera import make_raster_matrices
+dev = torch.device('cuda:0'); H = W = 1024; P = 150000
+assets = scenes.dist_b_avatar(P, seed=0)
+params = [assets[k].to(dev) for k in ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')]
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+tanx, tany, view, proj, cpos = make_raster_matrices(scenes.ring_camera(H, W, k, 200), (H, W))
+st = GaussianRasterizationSettings(H, W, tanx, tany, torch.ones(3, device=dev), 1.0, view.to(dev), proj.to(dev), 0, cpos.to(dev), False, False)
+exa.config.mode = 'exact'
+for rep in range(3):
+    with torch.no_grad():
+        m3, sc, rot, op, rgb = params
+        rasterize_gaussians(m3, torch.zeros(P, 3, device=dev), None, rgb, op, sc, rot, None, st)
+    torch.cuda.synchronize()
+tile = _debug_last['tile']
+cells = 256; chunks = (P + 511) // 512
+a256 = lambda v: (v + 255) & ~255
+off = 256 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4) + a256(cells * 4) + a256(cells * 64 * 8)
+slots = tile[off: off + cells * 64 * 16].view(torch.int32).view(-1, 4).cpu().numpy().astype(np.int64)
+n = slots[:, 1] - slots[:, 0]; cyc = slots[:, 3] & 0xffffffff
+act = n > 0
+print('active', act.sum(), 'cycles: mean %.0f  p50 %.0f  p99 %.0f  max %.0f' % (cyc[act].mean(), np.median(cyc[act]), np.percentile(cyc[act], 99), cyc[act].max()))
+for lo, hi in ((1, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 100000)):
+    m = (n >= lo) & (n <= hi)
+    if m.any(): print('n in [%d,%d]: count %d  mean cycles %.0f  max %.0f' % (lo, hi, m.sum(), cyc[m].mean(), cyc[m].max()))
+order = np.argsort(-cyc)[:5]
+print('slowest slots (launch idx, n, cycles):', [(int(i), int(n[i]), int(cyc[i])) for i in order])
