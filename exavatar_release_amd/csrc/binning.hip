@@ -63,7 +63,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
     for (int base = 0; base < cells; base += SCAN_THREADS) {
         const int c = base + tid;
         const unsigned long long v = c < cells ? w.cell_cnt[c] : 0ull;
-        const uint32_t e = (uint32_t)v, n = (uint32_t)(v >> 32);
+        const uint32_t e = (uint32_t)v, n = cell_slots((uint32_t)(v >> 32)) * BATCH;   // instance space in 64-slots
         uint32_t te, ti;
         const uint32_t xe = block_excl_scan(e, s_tmp, te);
         const uint32_t xi = block_excl_scan(n, s_tmp, ti);
@@ -203,10 +203,12 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid
     __syncthreads();
     if (tid < 64) {
         const uint32_t n = s_cnt[tid];
-        const uint32_t incl = wave_incl_scan(n);
-        const uint32_t begin = overflow ? 0u : o0.y + incl - n;
+        const uint32_t nslot = n ? (n + BATCH - 1) / BATCH + 1 : 0u;       // real batches + one end slot
+        const uint32_t incl = wave_incl_scan(nslot);
+        const uint32_t begin = overflow ? 0u : o0.y + (incl - nslot) * BATCH;
         s_off[tid] = begin;
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
+        for (uint32_t bq = 0; bq + 1 < nslot; ++bq) b.owner[begin / BATCH + bq] = (uint32_t)(cell * SUBS_PER_CELL + tid) + 1u;
         // launch-order record: workgroup (blockIdx.x * 64 + tid) of the per-pixel kernels handles this sub-tile
         w.slots[blockIdx.x * SUBS_PER_CELL + tid] = make_uint4(begin, begin + n, (uint32_t)(cell * SUBS_PER_CELL + tid), 0u);
     }

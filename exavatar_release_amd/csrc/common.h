@@ -91,7 +91,7 @@ struct TileWs {
     uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays, cell-major
     uint4* slots;                     // [subtiles]   launch-order records {begin, end, st, 0}: ONE load gives a
                                       //              per-pixel-kernel workgroup everything it needs
-    uint32_t* max_contrib;            // [subtiles]   last list position any pixel of the sub-tile blended
+    uint2* fwd_exit;                  // [subtiles]   {last list position any pixel blended, batches the forward entered}
 };
 __host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
     return HEADER_BYTES + align256(uint64_t(cells) * 8) + align256(uint64_t(cells) * 4);
@@ -99,7 +99,7 @@ __host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return tile_ws_zero_bytes(cells) + align256(uint64_t(cells + 1) * 8) + 2 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 4) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
-           align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 4);
+           align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -113,23 +113,36 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.cell_order = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.slots = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 16);
-    w.max_contrib = reinterpret_cast<uint32_t*>(p);
+    w.fwd_exit = reinterpret_cast<uint2*>(p);
     return w;
 }
 
+// Instance space.  Every non-empty sub-tile owns a 64-aligned range of BATCH slots (64 instances each):
+// ceil(n / 64) batches + one end slot; `capacity` (always a multiple of 64) counts slots * 64, which is what
+// header.num_rendered reports.  A batch slot is the unit of work of the backward pass (one wave each).
+constexpr int BATCH = 64;
 // bin workspace: keys[cap] (u64: depth bits << 32 | gaussian id), sorted ids[cap], cell buckets[cap]
-// (16-byte entries {id, depth bits, sub-tile rect x, y} so the second digit reads them coalesced).
+// (16-byte entries {id, depth bits, sub-tile rect x, y} so the second digit reads them coalesced),
+// batch owner[cap / 64] (sub-tile + 1, 0 = unused; zeroed by stage 2), per-pixel forward checkpoints
+// ckpt[cap / 64][5][64] floats (T, Cr, Cg, Cb, depth at the START of every batch slot / at the forward's exit).
 __host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) {
-    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16);
+    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16) + align256((cap / BATCH + 1) * 4) +
+           align256((cap / BATCH + 1) * 5 * 64 * 4);
 }
-struct BinWs { unsigned long long* keys; uint32_t* sorted; uint4* bucket; };
+struct BinWs { unsigned long long* keys; uint32_t* sorted; uint4* bucket; uint32_t* owner; float* ckpt; };
 __host__ __device__ inline BinWs carve_bin_ws(void* base, uint64_t cap) {
     BinWs b;
     char* p = static_cast<char*>(base);
     b.keys = reinterpret_cast<unsigned long long*>(p); p += align256(cap * 8);
     b.sorted = reinterpret_cast<uint32_t*>(p); p += align256(cap * 4);
-    b.bucket = reinterpret_cast<uint4*>(p);
+    b.bucket = reinterpret_cast<uint4*>(p); p += align256(cap * 16);
+    b.owner = reinterpret_cast<uint32_t*>(p); p += align256((cap / BATCH + 1) * 4);
+    b.ckpt = reinterpret_cast<float*>(p);
     return b;
+}
+// slots a cell needs at most: ceil(inst / 64) real batches + < 1 padding and 1 end slot per sub-tile
+__host__ __device__ inline uint32_t cell_slots(uint32_t inst) {
+    return inst ? (inst + BATCH - 1) / BATCH + 2 * SUBS_PER_CELL : 0u;
 }
 
 // image workspace: final_T[H*W] f32, n_contrib[H*W] u32.
@@ -207,7 +220,7 @@ hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s);
 hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
 
 struct RenderBwdArgs {
-    Grid grid;
+    Grid grid; uint64_t capacity;
     const Splat* splats; TileWs tw; BinWs bw; ImgWs iw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
     Partial* partials;

@@ -19,7 +19,20 @@ namespace exa {
 __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs a) {
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.P) return;
+    // r3 first: the partial gather depends on it; every other input load is independent and issued before it
+    // is needed (one round trip for the inputs, one for the partials)
+    const uint4 r3 = reinterpret_cast<const uint4*>(a.splats + idx)[3];
     const bool vis = a.radii[idx] > 0;
+    float in_s[3] = {0.f, 0.f, 0.f};
+    float4 in_q = make_float4(1.f, 0.f, 0.f, 0.f);
+    float in_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) in_cov[i] = a.cov3D_precomp[idx * 6 + i];
+    } else {
+        in_s[0] = a.scales[idx * 3 + 0]; in_s[1] = a.scales[idx * 3 + 1]; in_s[2] = a.scales[idx * 3 + 2];
+        in_q = reinterpret_cast<const float4*>(a.rotations)[idx];
+    }
 
     float dmean[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -31,15 +44,25 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
 
     if (vis) {
         // ---- gather this Gaussian's instances (contiguous, written exactly once each) -----------------
-        const uint4 r3 = reinterpret_cast<const uint4*>(a.splats + idx)[3];
         float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
         {
             const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)r3.w * 3;
-            for (uint32_t i = 0; i < r3.z; ++i) {
-                const float4 p0 = pp[i * 3 + 0], p1 = pp[i * 3 + 1], p2 = pp[i * 3 + 2];
-                mx += p0.x; my += p0.y; mxx += p0.z; mxy += p0.w;
-                myy += p1.x; dop += p1.y; dcol[0] += p1.z; dcol[1] += p1.w;
-                dcol[2] += p2.x; dz_view += p2.y;
+            // four instances per trip: 12 independent 16-byte loads in flight (a typical avatar splat has ~6)
+            for (uint32_t i = 0; i < r3.z; i += 4) {
+                float4 q[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = i + u < r3.z;
+                    const float4* src = pp + (size_t)(ok ? i + u : i) * 3;
+                    q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2];
+                    if (!ok) { q[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); q[u][1] = q[u][0]; q[u][2] = q[u][0]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mx += q[u][0].x; my += q[u][0].y; mxx += q[u][0].z; mxy += q[u][0].w;
+                    myy += q[u][1].x; dop += q[u][1].y; dcol[0] += q[u][1].z; dcol[1] += q[u][1].w;
+                    dcol[2] += q[u][2].x; dz_view += q[u][2].y;
+                }
             }
         }
 
@@ -56,13 +79,12 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
         float R[9], sc[3];
         float qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
         if (a.cov3D_precomp) {
-            const float* c6 = a.cov3D_precomp + idx * 6;
-            S00 = c6[0]; S01 = c6[1]; S02 = c6[2]; S11 = c6[3]; S12 = c6[4]; S22 = c6[5];
+            S00 = in_cov[0]; S01 = in_cov[1]; S02 = in_cov[2]; S11 = in_cov[3]; S12 = in_cov[4]; S22 = in_cov[5];
         } else {
-            sc[0] = a.scale_modifier * a.scales[idx * 3 + 0];
-            sc[1] = a.scale_modifier * a.scales[idx * 3 + 1];
-            sc[2] = a.scale_modifier * a.scales[idx * 3 + 2];
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            sc[0] = a.scale_modifier * in_s[0];
+            sc[1] = a.scale_modifier * in_s[1];
+            sc[2] = a.scale_modifier * in_s[2];
+            const float4 q = in_q;
             qr = q.x; qx = q.y; qy = q.z; qz = q.w;
             R[0] = 1.0f - 2.0f * (qy * qy + qz * qz); R[1] = 2.0f * (qx * qy - qr * qz); R[2] = 2.0f * (qx * qz + qr * qy);
             R[3] = 2.0f * (qx * qy + qr * qz); R[4] = 1.0f - 2.0f * (qx * qx + qz * qz); R[5] = 2.0f * (qy * qz - qr * qx);

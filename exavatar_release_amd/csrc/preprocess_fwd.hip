@@ -49,6 +49,21 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
     const float* __restrict__ v = a.viewmatrix;
     const float* __restrict__ p = a.projmatrix;
     const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
+    // issue every input load up front (one memory round trip instead of a dependent chain)
+    const float op = a.opacities[idx];
+    float in_s0 = 0.f, in_s1 = 0.f, in_s2 = 0.f, in_c0 = 0.f, in_c1 = 0.f, in_c2 = 0.f;
+    float4 in_q = make_float4(1.f, 0.f, 0.f, 0.f);
+    float in_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.cov3D_precomp) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) in_cov[i] = a.cov3D_precomp[idx * 6 + i];
+    } else {
+        in_s0 = a.scales[idx * 3 + 0]; in_s1 = a.scales[idx * 3 + 1]; in_s2 = a.scales[idx * 3 + 2];
+        in_q = reinterpret_cast<const float4*>(a.rotations)[idx];
+    }
+    if (!a.shs) {
+        in_c0 = a.colors_precomp[idx * 3 + 0]; in_c1 = a.colors_precomp[idx * 3 + 1]; in_c2 = a.colors_precomp[idx * 3 + 2];
+    }
 
     // 1. view space
     const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
@@ -70,13 +85,12 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
         // 3. 3D covariance
         float S00, S01, S02, S11, S12, S22;
         if (a.cov3D_precomp) {
-            const float* c6 = a.cov3D_precomp + idx * 6;
-            S00 = c6[0]; S01 = c6[1]; S02 = c6[2]; S11 = c6[3]; S12 = c6[4]; S22 = c6[5];
+            S00 = in_cov[0]; S01 = in_cov[1]; S02 = in_cov[2]; S11 = in_cov[3]; S12 = in_cov[4]; S22 = in_cov[5];
         } else {
-            const float s0 = a.scale_modifier * a.scales[idx * 3 + 0];
-            const float s1 = a.scale_modifier * a.scales[idx * 3 + 1];
-            const float s2 = a.scale_modifier * a.scales[idx * 3 + 2];
-            const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+            const float s0 = a.scale_modifier * in_s0;
+            const float s1 = a.scale_modifier * in_s1;
+            const float s2 = a.scale_modifier * in_s2;
+            const float4 q = in_q;
             const float qr = q.x, qx = q.y, qy = q.z, qz = q.w;
             const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz), R01 = 2.0f * (qx * qy - qr * qz),
                         R02 = 2.0f * (qx * qz + qr * qy);
@@ -163,15 +177,14 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
         if (cg < 0.f) { cg = 0.f; flags |= 2u; }
         if (cbl < 0.f) { cbl = 0.f; flags |= 4u; }
     } else {
-        cr = a.colors_precomp[idx * 3 + 0];
-        cg = a.colors_precomp[idx * 3 + 1];
-        cbl = a.colors_precomp[idx * 3 + 2];
+        cr = in_c0;
+        cg = in_c1;
+        cbl = in_c2;
     }
     // Sub-tile rect: inside the upstream 16x16-tile rect AND intersecting the exact bounding box of
     // {alpha >= 1/255}: 0.5 d^T Q d <= tau = ln(255 o), whose half extents are sqrt(2 tau cov_xx / yy).
     // (Conservative: +0.1 % and +0.01 px; a sub-tile outside it holds no pixel that passes the
     // per-pixel alpha test, so dropping it cannot change the image.)
-    const float op = a.opacities[idx];
     uint32_t n_inst = 0;
     const float o255 = 255.0f * op;
     if (o255 >= 1.0f) {

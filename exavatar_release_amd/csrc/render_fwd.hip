@@ -248,8 +248,17 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
         }
     }
+    // training: per-pixel state at the START of every batch slot (and at the exit), so that the backward
+    // pass can give every batch its own wave (render_bwd.hip)
+    float* ckpt = a.bw.ckpt + (size_t)(range.x / BATCH) * (5 * 64) + lane;
+    int entered = 0;
     for (int base = 0; base < n; base += 64) {
         if (__all(s.done)) break;
+        if (STORE && base > 0) {
+            float* c = ckpt + (size_t)entered * (5 * 64);
+            c[0] = s.T; c[64] = s.Cr; c[128] = s.Cg; c[192] = s.Cb; c[256] = s.Dp;
+        }
+        ++entered;
         s_g0[lane] = r0;
         s_g1[lane] = r1;
         s_g2[lane] = r2;
@@ -315,7 +324,11 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         uint32_t wl = s.last;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
-        if (lane == 0) a.tw.max_contrib[st] = wl;
+        if (lane == 0) a.tw.fwd_exit[st] = make_uint2(wl, (uint32_t)entered);
+        if (n > 0) {   // exit state = end state of the last batch entered
+            float* c = ckpt + (size_t)entered * (5 * 64);
+            c[0] = s.T; c[64] = s.Cr; c[128] = s.Cg; c[192] = s.Cb; c[256] = s.Dp;
+        }
     }
 }
 

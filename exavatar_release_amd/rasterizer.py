@@ -180,7 +180,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
                                                       _ptr(tile), stream))
                 hdr = tile[:16].view(torch.int32).cpu()          # D2H + sync, as upstream does
-                capacity = max(int(hdr[0]), 1)
+                capacity = max(int(hdr[0]), 64)          # header reports whole 64-instance batch slots
                 _seen_D[key] = max(_seen_D.get(key, 0), int(hdr[0]))
                 bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward_render(ctypes.byref(st), P, _ptr(geom), _ptr(tile), _ptr(bins),
@@ -193,6 +193,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     capacity = int(config.fixed_capacity)
                 else:
                     capacity = max(int(_seen_D[key] * config.capacity_growth), config.min_capacity)
+                capacity = (capacity + 63) // 64 * 64
                 bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
                                                   _ptr(tile), _ptr(bins), capacity, _ptr(img), _ptr(color),

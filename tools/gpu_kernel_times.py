@@ -30,16 +30,5 @@ for k in views:
             for n, v in _lib.timing_read().items():
                 acc[n] = acc.get(n, 0.0) + v / 3 * 1e3
     hdr = last_header()
-    # list-length stats from the sub-tile ranges
-    from exavatar_release_amd import _lib as L
-    tile = _debug_last['tile']
-    cells = ((W + 63) // 64) * ((H + 63) // 64); chunks = (P + 511) // 512
-    a256 = lambda v: (v + 255) & ~255
-    off = 256 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4)
-    rng = tile[off: off + cells * 64 * 8].view(torch.int32).view(-1, 2).cpu()
-    n = (rng[:, 1] - rng[:, 0])
-    mc = tile[off + a256(cells * 64 * 8): off + a256(cells * 64 * 8) + cells * 64 * 4].view(torch.int32).cpu()
-    print('view %3d D=%d entries=%d nonempty=%d maxlist=%d p50=%d p99=%d  sum(max_contrib)=%d max(max_contrib)=%d' % (
-        k, hdr[0], hdr[2], int((n > 0).sum()), int(n.max()), int(n[n > 0].float().median()),
-        int(n[n > 0].float().quantile(0.99)), int(mc[n > 0].sum()), int(mc[n > 0].max())))
+    print('view %3d slots*64=%d entries=%d' % (k, hdr[0], hdr[2]))
     print('   ' + '  '.join('%s=%.1f' % (kk, vv) for kk, vv in acc.items()) + '  total=%.1f us' % sum(acc.values()))
