@@ -138,7 +138,7 @@ def main():
     # ---- calibrate the instance-buffer capacity over this rank's views (exact mode, untimed) -------
     probe = range(len(my_views))        # every view of the shard: the capacity below provably covers them
     # read D and V for every probed view through the C ABI header of a fresh forward_bin
-    D_list, V_list = [], []
+    D_list, V_list, I_list = [], [], []
     import ctypes
     lib = _lib.load()
     from exavatar_release_amd.rasterizer import _make_settings, _ptr, _stream_ptr
@@ -153,10 +153,11 @@ def main():
         m3, sc, rot, op, rgb = [t.detach() for t in params]
         _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, 0, _ptr(m3), None, _ptr(rgb), _ptr(op), _ptr(sc),
                                               _ptr(rot), None, _ptr(radii), _ptr(geom), _ptr(tile), _stream_ptr(device)))
-        hdr = tile[:16].view(torch.int32).cpu()
-        D_list.append(int(hdr[0]))
+        hdr = tile[:20].view(torch.int32).cpu()
+        D_list.append(int(hdr[0]))        # capacity this view needs (64 * batch slots)
         V_list.append(int(hdr[3]))
-    D_max, D_mean, V_mean = max(D_list), sum(D_list) / len(D_list), sum(V_list) / len(V_list)
+        I_list.append(int(hdr[4]))        # sub-tile instances actually emitted
+    D_max, D_mean, V_mean = max(D_list), sum(I_list) / len(I_list), sum(V_list) / len(V_list)
     exa.config.mode = 'capacity'
     exa.config.fixed_capacity = int(D_max * 1.3) + 1024
 

@@ -59,10 +59,11 @@ __global__ __launch_bounds__(BLOCK) void zero_kernel(uint4* __restrict__ p, size
 __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int cells, int chunks) {
     __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
     const int tid = threadIdx.x;
-    uint32_t carry_e = 0, carry_i = 0;
+    uint32_t carry_e = 0, carry_i = 0, true_inst = 0;
     for (int base = 0; base < cells; base += SCAN_THREADS) {
         const int c = base + tid;
         const unsigned long long v = c < cells ? w.cell_cnt[c] : 0ull;
+        true_inst += (uint32_t)(v >> 32);
         const uint32_t e = (uint32_t)v, n = cell_slots((uint32_t)(v >> 32)) * BATCH;   // instance space in 64-slots
         uint32_t te, ti;
         const uint32_t xe = block_excl_scan(e, s_tmp, te);
@@ -70,6 +71,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
         if (c < cells) w.cell_off[c] = make_uint2(carry_e + xe, carry_i + xi);
         carry_e += te;
         carry_i += ti;
+    }
+    {
+        uint32_t tot;
+        block_excl_scan(true_inst, s_tmp, tot);
+        if (tid == 0) w.header->num_instances = tot;
     }
     if (tid == 0) {
         w.cell_off[cells] = make_uint2(carry_e, carry_i);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
         const float* ce = a.bw.ckpt + (size_t)(blockIdx.x + 1) * (5 * 64) + lane;
         const float* cf = a.bw.ckpt + (size_t)(b0 + (int)fe.y) * (5 * 64) + lane;
         float T = ce[0];
-        const float inv_Te = 1.0f / T;
+        const float inv_Te = __builtin_amdgcn_rcpf(T);
         // normalised suffix colour / depth behind this batch (zero once the pixel has finished)
         float rec_r = (cf[64] - ce[64]) * inv_Te, rec_g = (cf[128] - ce[128]) * inv_Te;
         float rec_b = (cf[192] - ce[192]) * inv_Te, rec_d = (cf[256] - ce[256]) * inv_Te;
@@ -160,14 +160,16 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
             const float alpha = fminf(ALPHA_MAX, g1.w * G);
             const bool contrib = inside && pos <= last && p2 <= 0.0f && alpha >= ALPHA_MIN;
             if (!__any(contrib)) continue;
-            float v[NACC];
-#pragma unroll
-            for (int i = 0; i < NACC; ++i) v[i] = 0.f;
+            // Per-lane scalars; lanes that do not contribute get zeros through three selects (sG, aG, wgt) instead
+            // of ten.  1 / (1 - alpha) is a hardware reciprocal (1 ulp) shared by the two divisions.
+            float sG = 0.f, aG = 0.f, wgt = 0.f;
+            float g2x = 0.f, g2y = 0.f, g2z = 0.f;
             if (contrib) {
                 const float4 g2 = s_g2[k];
-                const float one_m = 1.0f - alpha;
-                T = T / one_m;
-                const float wgt = alpha * T;
+                g2x = g2.x; g2y = g2.y; g2z = g2.z;
+                const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);
+                T = T * inv_one_m;
+                wgt = alpha * T;
                 rec_r = last_alpha * lw_r + (1.0f - last_alpha) * rec_r;
                 rec_g = last_alpha * lw_g + (1.0f - last_alpha) * rec_g;
                 rec_b = last_alpha * lw_b + (1.0f - last_alpha) * rec_b;
@@ -175,14 +177,17 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
                 lw_r = g2.x; lw_g = g2.y; lw_b = g2.z; lw_d = g0.z;
                 last_alpha = alpha;
                 float dL_dalpha = (g2.x - rec_r) * gr + (g2.y - rec_g) * gg + (g2.z - rec_b) * gb + (g0.z - rec_d) * gd;
-                dL_dalpha = dL_dalpha * T + tail / one_m;
-                const float sG = g1.w * dL_dalpha * G;        // s = dL/dG * G
-                const float sdx = sG * dx, sdy = sG * dy;
-                v[0] = sdx; v[1] = sdy;
-                v[2] = sdx * dx; v[3] = sdx * dy; v[4] = sdy * dy;
-                v[5] = G * dL_dalpha;
-                v[6] = wgt * gr; v[7] = wgt * gg; v[8] = wgt * gb; v[9] = wgt * gd;
+                dL_dalpha = dL_dalpha * T + tail * inv_one_m;
+                aG = G * dL_dalpha;                           // d/d(opacity)
+                sG = g1.w * aG;                               // s = dL/dG * G
             }
+            (void)g2x; (void)g2y; (void)g2z;
+            float v[NACC];
+            const float sdx = sG * dx, sdy = sG * dy;
+            v[0] = sdx; v[1] = sdy;
+            v[2] = sdx * dx; v[3] = sdx * dy; v[4] = sdy * dy;
+            v[5] = aG;
+            v[6] = wgt * gr; v[7] = wgt * gg; v[8] = wgt * gb; v[9] = wgt * gd;
             float q0, q1, q2;
             packed_reduce10(v, (lane & 1) != 0, (lane & 2) != 0, q0, q1, q2);
             // lanes 12..15 hold the totals: Partial layout {v0..v3 | v4..v7 | v8, v9, 0, 0}

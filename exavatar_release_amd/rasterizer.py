@@ -125,8 +125,8 @@ def check_overflow():
 
 
 def last_header():
-    """(num_rendered, overflow, max_tile_list, num_visible) of the most recent forward (synchronises)."""
-    return tuple(int(v) for v in _debug_last['tile'][:16].view(torch.int32).cpu())
+    """(num_rendered, overflow, entries, num_visible, num_instances) of the most recent forward (synchronises)."""
+    return tuple(int(v) for v in _debug_last['tile'][:20].view(torch.int32).cpu())
 
 
 class _RasterizeGaussians(torch.autograd.Function):

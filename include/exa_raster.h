@@ -66,12 +66,14 @@ typedef struct ExaRasterWorkspaceSizes {
     uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
-/* Device-side header at the start of the tile workspace (readable with a 16-byte D2H copy). */
+/* Device-side header at the start of the tile workspace (readable with a 20-byte D2H copy). */
 typedef struct ExaRasterHeader {
-    uint32_t num_rendered;   /* D = (Gaussian, 8x8 sub-tile) instances (role of upstream's num_rendered) */
-    uint32_t overflow;       /* != 0: D exceeded bin capacity, outputs of this call invalid  */
+    uint32_t num_rendered;   /* instance capacity this call needs: 64 * batch slots (role of upstream's
+                                num_rendered: what the caller sizes the bin workspace with)   */
+    uint32_t overflow;       /* != 0: num_rendered exceeded the capacity, outputs of this call invalid */
     uint32_t max_tile_list;  /* number of (Gaussian, 64x64 cell) entries                     */
     uint32_t num_visible;    /* V = Gaussians with radius > 0                                */
+    uint32_t num_instances;  /* D = (Gaussian, 8x8 sub-tile) instances actually emitted      */
 } ExaRasterHeader;
 
 int exa_raster_version(void);
