@@ -311,7 +311,7 @@ def main():
         total_bytes = 128 * P + 252 * V + 44 * D + 56 * WH
         result['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom),
             'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
             'kernel_avg_us': avg_us,
             'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),
@@ -328,6 +328,17 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate rocprofv3 --pmc runs of the same C3 workload); None if not available."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic.json')
+    try:
+        with open(path) as f:
+            return float(json.load(f)['kernels'][kernel]['hbm_bytes'])
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def concurrent_throughput(S, args, params, P, H, W, bg, vs, view_tab, proj_tab, cpos_tab, dL_dimg, rasterize_gaussians,
