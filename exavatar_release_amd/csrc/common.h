@@ -21,7 +21,7 @@ constexpr int CELL_SUBS = 8;               // sub-tiles per cell edge
 constexpr int CELL = SUB * CELL_SUBS;      // 64 px
 constexpr int SUBS_PER_CELL = CELL_SUBS * CELL_SUBS;   // 64
 constexpr int BLOCK = 256;                 // threads per workgroup (4 waves)
-constexpr int CHUNK = 512;                 // Gaussians per workgroup in the per-Gaussian binning kernels
+constexpr int CHUNK = 1024;                // Gaussians per workgroup in the per-Gaussian binning kernels
 constexpr int MAX_CELLS = 4096;            // LDS histogram budget (48 KiB of counters) -> images up to 4096x4096
 constexpr int HEADER_BYTES = 256;
 
