@@ -17,7 +17,8 @@ BUILD = os.path.join(HERE, '_build')
 
 ARCH = 'gfx950'
 COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
-          '-Wall', '-Wno-unused-function'] + (['-DEXA_PROBE_SORT'] if os.environ.get('EXA_PROBE_SORT') else [])
+          '-Wall', '-Wno-unused-function'] + (['-DEXA_PROBE_SORT'] if os.environ.get('EXA_PROBE_SORT') else []) + \
+    (['-DEXA_PROBE_FWD'] if os.environ.get('EXA_PROBE_FWD') else [])
 # per-file extra flags: the forward per-Gaussian stage is the bit-exact-with-oracle part
 SOURCES = {
     'preprocess_fwd.hip': ['-ffp-contract=off'],

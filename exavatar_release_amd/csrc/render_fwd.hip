@@ -193,26 +193,38 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) 
         for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
 }
 
+// Per-pixel running state.  `live` is 1.0f while the pixel still accepts splats and 0.0f once it has
+// stopped (T * (1 - alpha) < 1e-4) or lies outside the image: a float, not a bool, so that the blend below is
+// pure VALU arithmetic with selects -- boolean state costs SGPR-mask traffic (v_cmp -> s_and/s_or ->
+// v_cndmask) that more than doubled the instruction count of this loop (measured ~60 issue slots per splat).
 struct PixelState {
-    float T, Cr, Cg, Cb, Dp;
+    float T, Cr, Cg, Cb, Dp, live;
     uint32_t last;
-    bool done;
 };
 
-// Blend one Gaussian (uniform operands g0 = px,py,depth,. ; alpha precomputed per lane) into the pixel.
-__device__ __forceinline__ void blend_one(PixelState& s, float alpha, bool valid, const float4& g0, const float4& g2,
-                                          uint32_t pos) {
-    const float test_T = s.T * (1.0f - alpha);
-    const bool stop = valid && !s.done && test_T < T_EPS;
-    const bool take = valid && !s.done && !stop;
-    const float wgt = take ? alpha * s.T : 0.0f;
-    s.Cr = fmaf(g2.x, wgt, s.Cr);
-    s.Cg = fmaf(g2.y, wgt, s.Cg);
-    s.Cb = fmaf(g2.z, wgt, s.Cb);
-    s.Dp = fmaf(g0.z, wgt, s.Dp);
-    s.T = take ? test_T : s.T;
-    s.last = take ? pos : s.last;
-    s.done = s.done || stop;
+// alpha of one splat at this pixel, 0 when the splat is skipped (power > 0 or alpha < 1/255)
+__device__ __forceinline__ float splat_alpha(const float4& q0, const float4& q1, float fx, float fy) {
+    const float dx = q0.x - fx, dy = q0.y - fy;
+    const float p2 = gauss_power2(q1.x, q1.y, q1.z, dx, dy);
+    float al = fminf(ALPHA_MAX, q1.w * gauss_falloff2(p2));
+    al = (al >= ALPHA_MIN) ? al : 0.0f;
+    return (p2 <= 0.0f) ? al : 0.0f;
+}
+
+// Blend one splat (alpha = 0: no-op).  Exactly the sequential rule: skip dead pixels, stop (without blending)
+// when T (1 - alpha) < 1e-4, else accumulate with weight alpha * T.
+__device__ __forceinline__ void blend_one(PixelState& s, float alpha, const float4& c /* r g b depth */, uint32_t pos) {
+    const float a = alpha * s.live;                    // exact: live is 1 or 0
+    const float tT = fmaf(-a, s.T, s.T);               // T (1 - a); equals T when a == 0, and T >= 1e-4 always
+    const bool stop = tT < T_EPS;
+    const float w = stop ? 0.0f : a * s.T;
+    s.live = stop ? 0.0f : s.live;
+    s.T = stop ? s.T : tT;
+    s.Cr = fmaf(c.x, w, s.Cr);
+    s.Cg = fmaf(c.y, w, s.Cg);
+    s.Cb = fmaf(c.z, w, s.Cb);
+    s.Dp = fmaf(c.w, w, s.Dp);
+    s.last = (w > 0.0f) ? pos : s.last;
 }
 
 template <bool STORE>
@@ -222,6 +234,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     __shared__ float4 s_g2[64];
 
     const int lane = threadIdx.x;
+#ifdef EXA_PROBE_FWD
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    const unsigned long long w0 = wall_clock64();
+#endif
     const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty range on overflow
     const SubTile sub = decode_subtile((int)slot.z, a.grid);
     const int st = sub.st;
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     const int n = (int)(range.y - range.x);
 
     PixelState s;
-    s.T = 1.0f; s.Cr = 0.f; s.Cg = 0.f; s.Cb = 0.f; s.Dp = 0.f; s.last = 0; s.done = !inside;
+    s.T = 1.0f; s.Cr = 0.f; s.Cg = 0.f; s.Cb = 0.f; s.Dp = 0.f; s.last = 0; s.live = inside ? 1.0f : 0.0f;
     const Splat* __restrict__ splats = a.splats;
     const uint32_t* __restrict__ sorted = a.bw.sorted + range.x;
 
@@ -253,12 +269,13 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     float* ckpt = a.bw.ckpt + (size_t)(range.x / BATCH) * (5 * 64) + lane;
     int entered = 0;
     for (int base = 0; base < n; base += 64) {
-        if (__all(s.done)) break;
+        if (__all(s.live == 0.0f)) break;
         if (STORE && base > 0) {
             float* c = ckpt + (size_t)entered * (5 * 64);
             c[0] = s.T; c[64] = s.Cr; c[128] = s.Cg; c[192] = s.Cb; c[256] = s.Dp;
         }
         ++entered;
+        r2.w = r0.z;                                   // colour + depth in one row: the blend reads one float4
         s_g0[lane] = r0;
         s_g1[lane] = r1;
         s_g2[lane] = r2;
@@ -276,31 +293,18 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         int k = 0;
         for (; k + 4 <= cnt; k += 4) {
             float al[4];
-            bool va[4];
-            float4 q0[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                q0[u] = s_g0[k + u];
-                const float4 q1 = s_g1[k + u];
-                const float dx = q0[u].x - fx, dy = q0[u].y - fy;
-                const float p2 = gauss_power2(q1.x, q1.y, q1.z, dx, dy);
-                al[u] = fminf(ALPHA_MAX, q1.w * gauss_falloff2(p2));
-                va[u] = (p2 <= 0.0f) && (al[u] >= ALPHA_MIN);
-            }
-            if (__any((va[0] || va[1] || va[2] || va[3]) && !s.done)) {
+            for (int u = 0; u < 4; ++u) al[u] = splat_alpha(s_g0[k + u], s_g1[k + u], fx, fy);
+            const float amax = fmaxf(fmaxf(al[0], al[1]), fmaxf(al[2], al[3])) * s.live;
+            if (__any(amax > 0.0f)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) blend_one(s, al[u], va[u], q0[u], s_g2[k + u], (uint32_t)(base + k + u + 1));
-                if (__all(s.done)) break;
+                for (int u = 0; u < 4; ++u) blend_one(s, al[u], s_g2[k + u], (uint32_t)(base + k + u + 1));
+                if (__all(s.live == 0.0f)) break;
             }
         }
         for (; k < cnt; ++k) {
-            const float4 q0 = s_g0[k];
-            const float4 q1 = s_g1[k];
-            const float dx = q0.x - fx, dy = q0.y - fy;
-            const float p2 = gauss_power2(q1.x, q1.y, q1.z, dx, dy);
-            const float al = fminf(ALPHA_MAX, q1.w * gauss_falloff2(p2));
-            const bool va = (p2 <= 0.0f) && (al >= ALPHA_MIN);
-            if (__any(va && !s.done)) blend_one(s, al, va, q0, s_g2[k], (uint32_t)(base + k + 1));
+            const float al = splat_alpha(s_g0[k], s_g1[k], fx, fy);
+            if (__any(al * s.live > 0.0f)) blend_one(s, al, s_g2[k], (uint32_t)(base + k + 1));
         }
         wave_lds_fence();
     }
@@ -325,6 +329,13 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
         if (lane == 0) a.tw.fwd_exit[st] = make_uint2(wl, (uint32_t)entered);
+#ifdef EXA_PROBE_FWD
+        if (lane == 0) {
+            a.tw.slots[blockIdx.x].w = (uint32_t)(__builtin_readcyclecounter() - t0);
+            a.tw.slots[blockIdx.x].z = (uint32_t)w0;           // start time in 100 MHz ticks (probe build only!)
+            a.tw.slots[blockIdx.x].y = wl + slot.x;            // end := begin + n_eff (probe build only)
+        }
+#endif
         if (n > 0) {   // exit state = end state of the last batch entered
             float* c = ckpt + (size_t)entered * (5 * 64);
             c[0] = s.T; c[64] = s.Cr; c[128] = s.Cg; c[192] = s.Cb; c[256] = s.Dp;

@@ -14,13 +14,15 @@ tanx, tany, view, proj, cpos = make_raster_matrices(scenes.ring_camera(H, W, k, 
 st = GaussianRasterizationSettings(H, W, tanx, tany, torch.ones(3, device=dev), 1.0, view.to(dev), proj.to(dev), 0, cpos.to(dev), False, False)
 exa.config.mode = 'exact'
 for rep in range(3):
-    with torch.no_grad():
+    if True:
         m3, sc, rot, op, rgb = params
-        rasterize_gaussians(m3, torch.zeros(P, 3, device=dev), None, rgb, op, sc, rot, None, st)
+        m2 = torch.zeros(P, 3, device=dev, requires_grad=True)
+        rasterize_gaussians(m3, m2, None, rgb, op, sc, rot, None, st)
     torch.cuda.synchronize()
 tile = _debug_last['tile']
 cells = 256; chunks = (P + 511) // 512
 a256 = lambda v: (v + 255) & ~255
+chunks = (P + 1023) // 1024
 off = 256 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4) + a256(cells * 4) + a256(cells * 64 * 8)
 slots = tile[off: off + cells * 64 * 16].view(torch.int32).view(-1, 4).cpu().numpy().astype(np.int64)
 n = slots[:, 1] - slots[:, 0]; cyc = slots[:, 3] & 0xffffffff
@@ -29,5 +31,9 @@ print('active', act.sum(), 'cycles: mean %.0f  p50 %.0f  p99 %.0f  max %.0f' % (
 for lo, hi in ((1, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 100000)):
     m = (n >= lo) & (n <= hi)
     if m.any(): print('n in [%d,%d]: count %d  mean cycles %.0f  max %.0f' % (lo, hi, m.sum(), cyc[m].mean(), cyc[m].max()))
+start = slots[:, 2] & 0xffffffff
+if act.any():
+    s0 = start[act].min(); rel = (start[act] - s0) / 100.0; end = rel + cyc[act] / 2100.0
+    print('start offsets us: p50 %.1f p99 %.1f max %.1f ; end times us: p50 %.1f p99 %.1f max %.1f' % (np.median(rel), np.percentile(rel, 99), rel.max(), np.median(end), np.percentile(end, 99), end.max()))
 order = np.argsort(-cyc)[:5]
 print('slowest slots (launch idx, n, cycles):', [(int(i), int(n[i]), int(cyc[i])) for i in order])
