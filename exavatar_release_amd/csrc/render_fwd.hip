@@ -21,7 +21,7 @@
 // Algorithmic HBM bytes: sort reads 8 B/instance, writes 4 B/instance; blend reads 4 B/instance + 48 B per
 // gathered splat per sub-tile it touches (L2-resident after the first touch), writes 20 B/pixel
 // (rgb, depth, alpha) + 8 B/pixel (final_T, n_contrib, training only).
-#include "common.h"
+#include "blend.h"
 
 namespace exa {
 
@@ -193,45 +193,10 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) 
         for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
 }
 
-// Per-pixel running state.  `live` is 1.0f while the pixel still accepts splats and 0.0f once it has
-// stopped (T * (1 - alpha) < 1e-4) or lies outside the image: a float, not a bool, so that the blend below is
-// pure VALU arithmetic with selects -- boolean state costs SGPR-mask traffic (v_cmp -> s_and/s_or ->
-// v_cndmask) that more than doubled the instruction count of this loop (measured ~60 issue slots per splat).
-struct PixelState {
-    float T, Cr, Cg, Cb, Dp, live;
-    uint32_t last;
-};
-
-// alpha of one splat at this pixel, 0 when the splat is skipped (power > 0 or alpha < 1/255)
-__device__ __forceinline__ float splat_alpha(const float4& q0, const float4& q1, float fx, float fy) {
-    const float dx = q0.x - fx, dy = q0.y - fy;
-    const float p2 = gauss_power2(q1.x, q1.y, q1.z, dx, dy);
-    float al = fminf(ALPHA_MAX, q1.w * gauss_falloff2(p2));
-    al = (al >= ALPHA_MIN) ? al : 0.0f;
-    return (p2 <= 0.0f) ? al : 0.0f;
-}
-
-// Blend one splat (alpha = 0: no-op).  Exactly the sequential rule: skip dead pixels, stop (without blending)
-// when T (1 - alpha) < 1e-4, else accumulate with weight alpha * T.
-__device__ __forceinline__ void blend_one(PixelState& s, float alpha, const float4& c /* r g b depth */, uint32_t pos) {
-    const float a = alpha * s.live;                    // exact: live is 1 or 0
-    const float tT = fmaf(-a, s.T, s.T);               // T (1 - a); equals T when a == 0, and T >= 1e-4 always
-    const bool stop = tT < T_EPS;
-    const float w = stop ? 0.0f : a * s.T;
-    s.live = stop ? 0.0f : s.live;
-    s.T = stop ? s.T : tT;
-    s.Cr = fmaf(c.x, w, s.Cr);
-    s.Cg = fmaf(c.y, w, s.Cg);
-    s.Cb = fmaf(c.z, w, s.Cb);
-    s.Dp = fmaf(c.w, w, s.Dp);
-    s.last = (w > 0.0f) ? pos : s.last;
-}
-
+// ---- blend ---------------------------------------------------------------------------------------------
 template <bool STORE>
 __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
-    __shared__ float4 s_g0[64];
-    __shared__ float4 s_g1[64];
-    __shared__ float4 s_g2[64];
+    __shared__ BatchLds s_b;
 
     const int lane = threadIdx.x;
 #ifdef EXA_PROBE_FWD
@@ -248,8 +213,8 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     const uint2 range = make_uint2(slot.x, slot.y);
     const int n = (int)(range.y - range.x);
 
-    PixelState s;
-    s.T = 1.0f; s.Cr = 0.f; s.Cg = 0.f; s.Cb = 0.f; s.Dp = 0.f; s.last = 0; s.live = inside ? 1.0f : 0.0f;
+    float T = 1.0f, live = inside ? 1.0f : 0.0f;
+    v2f Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};                     // (r, g) and (b, depth) accumulators
     const Splat* __restrict__ splats = a.splats;
     const uint32_t* __restrict__ sorted = a.bw.sorted + range.x;
 
@@ -265,20 +230,17 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         }
     }
     // training: per-pixel state at the START of every batch slot (and at the exit), so that the backward
-    // pass can give every batch its own wave (render_bwd.hip)
+    // pass can give every batch its own wave (render_bwd.hip).  A stopped pixel is stored as -T.
     float* ckpt = a.bw.ckpt + (size_t)(range.x / BATCH) * (5 * 64) + lane;
     int entered = 0;
     for (int base = 0; base < n; base += 64) {
-        if (__all(s.live == 0.0f)) break;
+        if (__all(live == 0.0f)) break;
         if (STORE && base > 0) {
             float* c = ckpt + (size_t)entered * (5 * 64);
-            c[0] = s.T; c[64] = s.Cr; c[128] = s.Cg; c[192] = s.Cb; c[256] = s.Dp;
+            c[0] = live != 0.0f ? T : -T; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
         }
         ++entered;
-        r2.w = r0.z;                                   // colour + depth in one row: the blend reads one float4
-        s_g0[lane] = r0;
-        s_g1[lane] = r1;
-        s_g2[lane] = r2;
+        stage_splat(s_b, lane, r0, r1, r2);
         // issue the next batch's gathers and the ids of the batch after it
         {
             const int jn = base + 64 + lane;
@@ -292,19 +254,30 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         const int cnt = min(64, n - base);
         int k = 0;
         for (; k + 4 <= cnt; k += 4) {
-            float al[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) al[u] = splat_alpha(s_g0[k + u], s_g1[k + u], fx, fy);
-            const float amax = fmaxf(fmaxf(al[0], al[1]), fmaxf(al[2], al[3])) * s.live;
+            const Alpha4 e = splat_alpha4(s_b, k, fx, fy);
+            const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
             if (__any(amax > 0.0f)) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) blend_one(s, al[u], s_g2[k + u], (uint32_t)(base + k + u + 1));
-                if (__all(s.live == 0.0f)) break;
+                for (int u = 0; u < 4; ++u) {
+                    float aeff;
+                    const float w = blend_step(T, live, e.alpha[u], aeff);
+                    const float4 c = s_b.col[k + u];
+                    Crg = __builtin_elementwise_fma(v2f{c.x, c.y}, v2f{w, w}, Crg);
+                    Cbd = __builtin_elementwise_fma(v2f{c.z, c.w}, v2f{w, w}, Cbd);
+                }
+                if (__all(live == 0.0f)) break;
             }
         }
         for (; k < cnt; ++k) {
-            const float al = splat_alpha(s_g0[k], s_g1[k], fx, fy);
-            if (__any(al * s.live > 0.0f)) blend_one(s, al, s_g2[k], (uint32_t)(base + k + 1));
+            float al, G;
+            splat_alpha1(s_b, k, fx, fy, al, G);
+            if (__any(al * live > 0.0f)) {
+                float aeff;
+                const float w = blend_step(T, live, al, aeff);
+                const float4 c = s_b.col[k];
+                Crg = __builtin_elementwise_fma(v2f{c.x, c.y}, v2f{w, w}, Crg);
+                Cbd = __builtin_elementwise_fma(v2f{c.z, c.w}, v2f{w, w}, Cbd);
+            }
         }
         wave_lds_fence();
     }
@@ -314,31 +287,23 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     if (inside) {
         const size_t pix = (size_t)pyi * a.grid.W + pxi;
         const float* __restrict__ bg = a.bg;
-        a.out_color[pix] = s.Cr + s.T * bg[0];
-        a.out_color[HW + pix] = s.Cg + s.T * bg[1];
-        a.out_color[2 * HW + pix] = s.Cb + s.T * bg[2];
-        a.out_depth[pix] = s.Dp;
-        a.out_alpha[pix] = 1.0f - s.T;
-        if (STORE) {
-            a.iw.final_T[pix] = s.T;
-            a.iw.n_contrib[pix] = s.last;
-        }
+        a.out_color[pix] = Crg.x + T * bg[0];
+        a.out_color[HW + pix] = Crg.y + T * bg[1];
+        a.out_color[2 * HW + pix] = Cbd.x + T * bg[2];
+        a.out_depth[pix] = Cbd.y;
+        a.out_alpha[pix] = 1.0f - T;
     }
     if (STORE) {
-        uint32_t wl = s.last;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
-        if (lane == 0) a.tw.fwd_exit[st] = make_uint2(wl, (uint32_t)entered);
+        if (lane == 0) a.tw.fwd_exit[st] = make_uint2((uint32_t)n, (uint32_t)entered);
 #ifdef EXA_PROBE_FWD
         if (lane == 0) {
             a.tw.slots[blockIdx.x].w = (uint32_t)(__builtin_readcyclecounter() - t0);
             a.tw.slots[blockIdx.x].z = (uint32_t)w0;           // start time in 100 MHz ticks (probe build only!)
-            a.tw.slots[blockIdx.x].y = wl + slot.x;            // end := begin + n_eff (probe build only)
         }
 #endif
         if (n > 0) {   // exit state = end state of the last batch entered
             float* c = ckpt + (size_t)entered * (5 * 64);
-            c[0] = s.T; c[64] = s.Cr; c[128] = s.Cg; c[192] = s.Cb; c[256] = s.Dp;
+            c[0] = T; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
         }
     }
 }
