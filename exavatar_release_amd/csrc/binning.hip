@@ -215,8 +215,6 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid
         s_off[tid] = begin;
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
         for (uint32_t bq = 0; bq + 1 < nslot; ++bq) b.owner[begin / BATCH + bq] = (uint32_t)(cell * SUBS_PER_CELL + tid) + 1u;
-        // launch-order record: workgroup (blockIdx.x * 64 + tid) of the per-pixel kernels handles this sub-tile
-        w.slots[blockIdx.x * SUBS_PER_CELL + tid] = make_uint4(begin, begin + n, (uint32_t)(cell * SUBS_PER_CELL + tid), 0u);
     }
     __syncthreads();
     for (uint32_t e = e0 + tid; e < e1; e += BIN_THREADS) {

@@ -23,7 +23,7 @@ constexpr int SUBS_PER_CELL = CELL_SUBS * CELL_SUBS;   // 64
 constexpr int BLOCK = 256;                 // threads per workgroup (4 waves)
 constexpr int CHUNK = 1024;                // Gaussians per workgroup in the per-Gaussian binning kernels
 constexpr int MAX_CELLS = 4096;            // LDS histogram budget (48 KiB of counters) -> images up to 4096x4096
-constexpr int HEADER_BYTES = 256;
+constexpr int HEADER_BYTES = 512;      // ExaRasterHeader at 0, length-class cursors at 256
 
 constexpr float NEAR_CULL = 0.2f;
 constexpr float LOWPASS = 0.3f;
@@ -82,6 +82,7 @@ __host__ __device__ inline int num_chunks(int P) { return (P + CHUNK - 1) / CHUN
 // first kernel of every forward.
 struct TileWs {
     ExaRasterHeader* header;          // [1]                      [zeroed]
+    uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class [zeroed] (in the header block)
     unsigned long long* cell_cnt;     // [cells]  inst << 32 | entries            [zeroed]
     uint32_t* cell_cursor;            // [cells]  entries already placed per cell [zeroed]
     uint2* cell_off;                  // [cells + 1]  exclusive prefix (entries, instances)
@@ -104,7 +105,9 @@ __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
     TileWs w;
-    w.header = reinterpret_cast<ExaRasterHeader*>(p); p += HEADER_BYTES;
+    w.header = reinterpret_cast<ExaRasterHeader*>(p);
+    w.cls_cur = reinterpret_cast<uint32_t*>(p + 256);
+    p += HEADER_BYTES;
     w.cell_cnt = reinterpret_cast<unsigned long long*>(p); p += align256(uint64_t(cells) * 8);
     w.cell_cursor = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.cell_off = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells + 1) * 8);
@@ -157,6 +160,14 @@ __host__ __device__ inline ImgWs carve_img_ws(void* base, int W, int H) {
 
 // backward scratch: one Partial per instance.
 __host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * sizeof(Partial)); }
+
+// Launch order of the forward blend: sub-tiles by DESCENDING list length (64 classes of 16 entries), empty ones
+// last.  All non-empty sub-tiles are resident at once (~3.7 waves per SIMD) and the hardware deals consecutive
+// workgroups round-robin over XCDs / CUs / SIMDs, so a length-sorted launch gives every SIMD one list of each
+// size class instead of a random draw (measured on C3: the busiest SIMD had 2.06x the mean work with a
+// cell-major order, and that SIMD set the kernel time).
+constexpr int ORDER_CLASSES = 64;
+__device__ __forceinline__ int length_class(uint32_t n) { return n ? min(ORDER_CLASSES - 1, (int)((n + 15) / 16)) : 0; }
 
 // cell-major sub-tile index st = cell * 64 + local  ->  coordinates
 struct SubTile { int st, cell, local, ox, oy, gsx, gsy; };

@@ -27,7 +27,7 @@ namespace exa {
 
 constexpr int RBLOCK = 64;            // threads per workgroup of the per-pixel kernels: ONE wave
 
-constexpr int SORT_TILE = 1024;       // keys of the LDS buffer (8 KiB)
+constexpr int SORT_TILE = 2048;       // keys of the LDS buffer (16 KiB)
 constexpr int SBLOCK = 256;           // threads of a sort workgroup: four waves co-operate on ONE list
 
 // ---- sort of lists up to SORT_TILE keys: rank-sorted runs of 64 + rank-based merges, in place in LDS -----
@@ -172,14 +172,104 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
         if (first + r * SBLOCK + tid < n) sorted[rank[r]] = (uint32_t)mine[r];
 }
 
+// ---- launch order of the forward blend (see length_class in common.h) ------------------------------------
+// Runs as the first ORDER_WGS workgroups of the sort launch, i.e. concurrently with the sorting and off the
+// critical path.  Every ordering workgroup histograms the list-length classes of ALL sub-tiles (128 KiB of
+// L2-resident ranges), then ranks its own share inside LDS, reserves one contiguous range per class with a
+// single device atomic, and writes the records.
+constexpr int ORDER_WGS = 16;
+__device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int part, int tid) {
+    __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
+    const int lane = tid & 63;
+    if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
+    __syncthreads();
+    for (int base = 0; base < subtiles; base += SBLOCK * 8) {
+        uint2 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int st = base + i * SBLOCK + tid;
+            r[i] = st < subtiles ? w.ranges[st] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int cls = length_class(r[i].y - r[i].x);
+            const unsigned long long empty = __ballot(base + i * SBLOCK + tid < subtiles && cls == 0);
+            if (cls) atomicAdd(&s_cnt[cls], 1u);
+            else if (empty && lane == __ffsll((long long)empty) - 1) atomicAdd(&s_cnt[0], (uint32_t)__popcll(empty));
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
+        const int cls = tid == 63 ? 0 : 63 - tid;
+        uint32_t v = s_cnt[cls], incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        s_off[cls] = incl - v;
+        s_cnt[cls] = 0u;
+    }
+    __syncthreads();
+    const int per = (subtiles + ORDER_WGS - 1) / ORDER_WGS;
+    const int lo = part * per, hi = min(subtiles, lo + per);
+    for (int base = lo; base < hi; base += SBLOCK * 4) {
+        uint2 r[4];
+        uint32_t rank[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int st = base + i * SBLOCK + tid;
+            r[i] = st < hi ? w.ranges[st] : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = base + i * SBLOCK + tid < hi;
+            const int cls = length_class(r[i].y - r[i].x);
+            const unsigned long long empty = __ballot(valid && cls == 0);
+            rank[i] = 0;
+            if (cls) rank[i] = atomicAdd(&s_cnt[cls], 1u);
+            else if (empty) {       // one LDS atomic per wave for the (many) empty sub-tiles
+                const int leader = __ffsll((long long)empty) - 1;
+                uint32_t b0 = 0;
+                if (lane == leader) b0 = atomicAdd(&s_cnt[0], (uint32_t)__popcll(empty));
+                b0 = (uint32_t)__shfl((int)b0, leader, 64);
+                rank[i] = b0 + (uint32_t)__popcll(empty & ((1ull << lane) - 1ull));
+            }
+        }
+        __syncthreads();
+        if (tid < ORDER_CLASSES) {
+            const uint32_t c = s_cnt[tid];
+            s_base[tid] = s_off[tid] + (c ? atomicAdd(&w.cls_cur[tid], c) : 0u);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int st = base + i * SBLOCK + tid;
+            if (st < hi) {
+                const int cls = length_class(r[i].y - r[i].x);
+                w.slots[s_base[cls] + rank[i]] = make_uint4(r[i].x, r[i].y, (uint32_t)st, 0u);
+            }
+        }
+        __syncthreads();
+        if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
     const int tid = threadIdx.x;
-    const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty on overflow
-    const uint2 range = make_uint2(slot.x, slot.y);
-    const int n = (int)(range.y - range.x);                     // workgroup-uniform
+    if (blockIdx.x < ORDER_WGS) {
+        order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid);
+        return;
+    }
+    // heaviest cells first (cell_order), sub-tiles of a cell consecutive
+    const int wg = (int)blockIdx.x - ORDER_WGS;
+    const int st = (int)a.tw.cell_order[wg >> 6] * SUBS_PER_CELL + (wg & 63);
+    const uint2 range = a.tw.ranges[st];
+    const int n = (int)(range.y - range.x);                     // workgroup-uniform; empty on overflow
     if (n == 0) {
-        if (blockIdx.x == 0 && tid == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
+        if (wg == 0 && tid == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
         return;
     }
     const unsigned long long* gkeys = a.bw.keys + range.x;
@@ -189,6 +279,7 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) 
     } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);
     else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);
     else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
+    else if (n <= 2048) lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
     else   // longer lists: 2048 own keys at a time against the whole list (any length)
         for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
 }
@@ -201,7 +292,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     const int lane = threadIdx.x;
 #ifdef EXA_PROBE_FWD
     const unsigned long long t0 = __builtin_readcyclecounter();
-    const unsigned long long w0 = wall_clock64();
+    unsigned long long t_first = t0;
 #endif
     const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty range on overflow
     const SubTile sub = decode_subtile((int)slot.z, a.grid);
@@ -241,6 +332,9 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         }
         ++entered;
         stage_splat(s_b, lane, r0, r1, r2);
+#ifdef EXA_PROBE_FWD
+        if (base == 0) t_first = __builtin_readcyclecounter();
+#endif
         // issue the next batch's gathers and the ids of the batch after it
         {
             const int jn = base + 64 + lane;
@@ -298,7 +392,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
 #ifdef EXA_PROBE_FWD
         if (lane == 0) {
             a.tw.slots[blockIdx.x].w = (uint32_t)(__builtin_readcyclecounter() - t0);
-            a.tw.slots[blockIdx.x].z = (uint32_t)w0;           // start time in 100 MHz ticks (probe build only!)
+            // placement: HW_ID[15:0] (wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) | XCC_ID << 16
+            const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            a.tw.slots[blockIdx.x].z = (hw & 0xffffu) | ((xcc & 0xfu) << 16);   // probe build only!
+            (void)t_first;
         }
 #endif
         if (n > 0) {   // exit state = end state of the last batch entered
@@ -310,7 +407,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
 
 hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s) {
     if (a.grid.subtiles == 0) return hipSuccess;
-    sort_subtiles_kernel<<<a.grid.subtiles, SBLOCK, 0, s>>>(a);
+    sort_subtiles_kernel<<<a.grid.subtiles + ORDER_WGS, SBLOCK, 0, s>>>(a);
     return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ tile = _debug_last['tile']
 cells = 256; chunks = (P + 511) // 512
 a256 = lambda v: (v + 255) & ~255
 chunks = (P + 1023) // 1024
-off = 256 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4) + a256(cells * 4) + a256(cells * 64 * 8)
+off = 512 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4) + a256(cells * 4) + a256(cells * 64 * 8)
 slots = tile[off: off + cells * 64 * 16].view(torch.int32).view(-1, 4).cpu().numpy().astype(np.int64)
 n = slots[:, 1] - slots[:, 0]; cyc = slots[:, 3] & 0xffffffff
 act = n > 0
@@ -31,9 +31,18 @@ print('active', act.sum(), 'cycles: mean %.0f  p50 %.0f  p99 %.0f  max %.0f' % (
 for lo, hi in ((1, 64), (65, 128), (129, 256), (257, 512), (513, 1024), (1025, 100000)):
     m = (n >= lo) & (n <= hi)
     if m.any(): print('n in [%d,%d]: count %d  mean cycles %.0f  max %.0f' % (lo, hi, m.sum(), cyc[m].mean(), cyc[m].max()))
-start = slots[:, 2] & 0xffffffff
-if act.any():
-    s0 = start[act].min(); rel = (start[act] - s0) / 100.0; end = rel + cyc[act] / 2100.0
-    print('start offsets us: p50 %.1f p99 %.1f max %.1f ; end times us: p50 %.1f p99 %.1f max %.1f' % (np.median(rel), np.percentile(rel, 99), rel.max(), np.median(end), np.percentile(end, 99), end.max()))
+hw = slots[:, 2] & 0xffffffff
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 16) & 15
+key = ((((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd)
+ka = key[act]
+uniq, inv = np.unique(ka, return_inverse=True)
+work = np.bincount(inv, weights=cyc[act].astype(np.float64) * 0 + n[act]); cnt = np.bincount(inv)
+print('SIMDs with active waves: %d ; active waves per SIMD: mean %.2f max %d ; sum n per SIMD: mean %.0f p90 %.0f max %.0f' % (len(uniq), cnt.mean(), cnt.max(), work.mean(), np.percentile(work, 90), work.max()))
+cuk = ka // 4; u2, inv2 = np.unique(cuk, return_inverse=True); w2 = np.bincount(inv2, weights=n[act].astype(np.float64))
+print('CUs with active waves: %d ; sum n per CU: mean %.0f p90 %.0f max %.0f min %.0f' % (len(u2), w2.mean(), np.percentile(w2, 90), w2.max(), w2.min()))
+xk = xcc[act]; print('per XCC sum n:', [int(n[act][xk == x].sum()) for x in range(8)])
+endc = np.zeros(len(uniq)); np.maximum.at(endc, inv, cyc[act]); print('per-SIMD last wave end cycles: mean %.0f p90 %.0f max %.0f' % (endc.mean(), np.percentile(endc, 90), endc.max()))
+idx = np.argsort(-work)[:5]; print('heaviest SIMDs (sum n, waves, end):', [(int(work[i]), int(cnt[i]), int(endc[i])) for i in idx])
+print('first 24 launch idx -> (xcc,se,sh,cu,simd):', [(int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i])) for i in np.nonzero(act)[0][:24]])
 order = np.argsort(-cyc)[:5]
 print('slowest slots (launch idx, n, cycles):', [(int(i), int(n[i]), int(cyc[i])) for i in order])
