@@ -56,45 +56,66 @@ __device__ __forceinline__ Alpha2 splat_alpha2(v2f px, v2f py, v2f ca, v2f cb, v
     return r;
 }
 
-// alphas (and falloffs) of splats k .. k+3 of the staged batch at pixel (fx, fy); k is a multiple of 4
+// Operands of four consecutive splats k .. k+3 (k a multiple of 4): six broadcast ds_read_b128.
+struct Ops4 { v4f px, py, ca, cb, cc, op; };
+__device__ __forceinline__ Ops4 load_ops4(const BatchLds& s, int k) {
+    Ops4 o;
+    o.px = *reinterpret_cast<const v4f*>(&s.px[k]);
+    o.py = *reinterpret_cast<const v4f*>(&s.py[k]);
+    o.ca = *reinterpret_cast<const v4f*>(&s.ca[k]);
+    o.cb = *reinterpret_cast<const v4f*>(&s.cb[k]);
+    o.cc = *reinterpret_cast<const v4f*>(&s.cc[k]);
+    o.op = *reinterpret_cast<const v4f*>(&s.op[k]);
+    return o;
+}
+// alphas (and falloffs) of four splats at pixel (fx, fy)
 struct Alpha4 { float alpha[4], G[4]; };
-__device__ __forceinline__ Alpha4 splat_alpha4(const BatchLds& s, int k, float fx, float fy) {
-    const v4f px = *reinterpret_cast<const v4f*>(&s.px[k]);
-    const v4f py = *reinterpret_cast<const v4f*>(&s.py[k]);
-    const v4f ca = *reinterpret_cast<const v4f*>(&s.ca[k]);
-    const v4f cb = *reinterpret_cast<const v4f*>(&s.cb[k]);
-    const v4f cc = *reinterpret_cast<const v4f*>(&s.cc[k]);
-    const v4f op = *reinterpret_cast<const v4f*>(&s.op[k]);
-    const Alpha2 lo = splat_alpha2(px.xy, py.xy, ca.xy, cb.xy, cc.xy, op.xy, fx, fy);
-    const Alpha2 hi = splat_alpha2(px.zw, py.zw, ca.zw, cb.zw, cc.zw, op.zw, fx, fy);
+__device__ __forceinline__ Alpha4 splat_alpha4(const Ops4& o, float fx, float fy) {
+    const Alpha2 lo = splat_alpha2(o.px.xy, o.py.xy, o.ca.xy, o.cb.xy, o.cc.xy, o.op.xy, fx, fy);
+    const Alpha2 hi = splat_alpha2(o.px.zw, o.py.zw, o.ca.zw, o.cb.zw, o.cc.zw, o.op.zw, fx, fy);
     Alpha4 r;
     r.alpha[0] = lo.alpha.x; r.alpha[1] = lo.alpha.y; r.alpha[2] = hi.alpha.x; r.alpha[3] = hi.alpha.y;
     r.G[0] = lo.G.x; r.G[1] = lo.G.y; r.G[2] = hi.G.x; r.G[3] = hi.G.y;
     return r;
 }
-// tail of a batch (k not a multiple of 4 away from the end): one splat
-__device__ __forceinline__ void splat_alpha1(const BatchLds& s, int k, float fx, float fy, float& alpha, float& G) {
-    const float one = 1.0f;
-    const Alpha2 r = splat_alpha2(v2f{s.px[k], one}, v2f{s.py[k], one}, v2f{s.ca[k], one}, v2f{s.cb[k], one},
-                                  v2f{s.cc[k], one}, v2f{s.op[k], 0.0f}, fx, fy);
-    alpha = r.alpha.x;
-    G = r.G.x;
-}
 
-// One step of the front-to-back recurrence.  `live` is 1.0f while the pixel accepts splats, 0.0f after it
-// stopped (or for a pixel outside the image).  Returns the blend weight w = a T (0 when nothing is blended)
-// and the effective alpha `a`; updates T and live.  Exactly the sequential rule: a dead pixel and a skipped
-// splat (alpha == 0) blend nothing; the splat that would push T (1 - a) under 1e-4 is NOT blended and kills
-// the pixel.  (T >= 1e-4 is an invariant, so a == 0 can never trigger the stop.)
-__device__ __forceinline__ float blend_step(float& T, float& live, float alpha, float& a) {
+// Four steps of the front-to-back recurrence at once.  `live` is 1.0f while the pixel accepts splats, 0.0f
+// after it stopped (or for a pixel outside the image).  Outputs per splat j: the effective alpha a[j], the
+// transmittance in front of it Tb[j] and the blend weight w[j] = a[j] Tb[j] (0 when nothing is blended).
+//
+// The sequential rule -- skip alpha == 0, and the splat that would push T (1 - a) under 1e-4 is NOT blended
+// and kills the pixel -- is evaluated through the partial products P_j = prod_{i <= j} (1 - a_i), which depend
+// on the alphas only: the loop-carried dependency is ONE multiply (T P_4) per four splats instead of a
+// mul / fma / compare / select chain per splat (the kernels are latency bound: ~3.7 waves per SIMD).  T P_j is
+// non-increasing in j, so "stopped at or before j" is simply T P_j < 1e-4; a dead pixel has a = 0, P = 1.
+// T >= 1e-4 is an invariant.
+__device__ __forceinline__ void blend_group4(float& T, float& live, const float (&alpha)[4], float (&a)[4],
+                                             float (&Tb)[4], float (&w)[4]) {
 #pragma clang fp contract(off)
-    a = alpha * live;                                 // exact
-    const float tT = __builtin_fmaf(-a, T, T);        // T (1 - a)
-    const bool stop = tT < T_EPS;
-    const float w = stop ? 0.0f : a * T;
-    live = stop ? 0.0f : live;
-    T = stop ? T : tT;
-    return w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = alpha[j] * live;          // exact
+    const float P1 = 1.0f - a[0];
+    const float P2 = P1 * (1.0f - a[1]);
+    const float P3 = P2 * (1.0f - a[2]);
+    const float P4 = P3 * (1.0f - a[3]);
+    Tb[0] = T; Tb[1] = T * P1; Tb[2] = T * P2; Tb[3] = T * P3;
+    const float T4 = T * P4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = a[j] * Tb[j];
+    if (__any(T4 < T_EPS)) {                                     // some pixel stops inside this group (rare)
+        const float after[4] = {Tb[1], Tb[2], Tb[3], T4};
+        float Tn = T;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool stop = after[j] < T_EPS;
+            w[j] = stop ? 0.0f : w[j];
+            Tn = stop ? Tn : after[j];
+        }
+        live = (T4 < T_EPS) ? 0.0f : live;
+        T = Tn;
+    } else {
+        T = T4;
+    }
 }
 
 }  // namespace exa

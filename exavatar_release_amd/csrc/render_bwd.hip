@@ -79,6 +79,8 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
             stage_splat(s_b, lane, rec[0], rec[1], rec[2]);
             s_pslot[lane] = pslot;
         }
+    } else if (bq < entered) {                                  // past the end of the list: all-zero record (alpha 0)
+        stage_splat(s_b, lane, zero4, zero4, zero4);
     }
     if (bq >= entered) {                                        // every pixel had stopped before this batch
         if (lane < cnt) {
@@ -121,51 +123,38 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
     float R = (cf[64] - sr) * gr + (cf[128] - sg) * gg + (cf[192] - sb) * gb + (cf[256] - sd) * gd - tail;
     wave_lds_fence();
 
-    // one (pixel, splat) step of phase A; row = splat index inside the chunk
-    auto pair_step = [&](int k, int row, float alpha, float G) {
-        const float Tb = T;
-        float aeff;
-        const float w = blend_step(T, live, alpha, aeff);
-        const float4 c = s_b.col[k];
-        const float cg = fmaf(c.w, gd, fmaf(c.z, gb, fmaf(c.y, gg, c.x * gr)));
-        R = fmaf(-cg, w, R);                                            // R_{i+1}
-        const float inv = __builtin_amdgcn_rcpf(1.0f - aeff);
-        const float dLda = fmaf(Tb, cg, -(R * inv));
-        s_xa[row * XS + lane] = w > 0.0f ? G * dLda : 0.0f;
-        s_xw[row * XS + lane] = w;
-    };
-
     const int g = lane % GC, h = lane / GC;
     for (int c0 = 0; c0 < cnt; c0 += GC) {
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
         bool any_contrib = false;
         if (!__all(live == 0.0f)) {
-            int k = c0;
-            for (; k + 4 <= cend; k += 4) {
-                const Alpha4 e = splat_alpha4(s_b, k, fx, fy);
+            Ops4 cur = load_ops4(s_b, c0);
+            for (int k = c0; k < cend; k += 4) {
+                const Ops4 nxt = load_ops4(s_b, (k + 4) & 63);   // next group's operands: in flight during this one
+                const float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
+                const Alpha4 e = splat_alpha4(cur, fx, fy);
+                cur = nxt;
                 const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
+                float* xa = s_xa + (k - c0) * XS + lane;
+                float* xw = s_xw + (k - c0) * XS + lane;
                 if (__any(amax > 0.0f)) {
                     any_contrib = true;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) pair_step(k + u, k + u - c0, e.alpha[u], e.G[u]);
-                } else {
+                    float aeff[4], Tb[4], w[4];
+                    blend_group4(T, live, e.alpha, aeff, Tb, w);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        s_xa[(k + u - c0) * XS + lane] = 0.0f;
-                        s_xw[(k + u - c0) * XS + lane] = 0.0f;
+                        const float4 c = col[u];
+                        const float cg = fmaf(c.w, gd, fmaf(c.z, gb, fmaf(c.y, gg, c.x * gr)));
+                        R = fmaf(-cg, w[u], R);                                  // R_{i+1}
+                        const float inv = __builtin_amdgcn_rcpf(1.0f - aeff[u]);
+                        const float dLda = fmaf(Tb[u], cg, -(R * inv));
+                        xa[u * XS] = w[u] > 0.0f ? e.G[u] * dLda : 0.0f;
+                        xw[u * XS] = w[u];
                     }
-                }
-            }
-            for (; k < cend; ++k) {
-                float al, G;
-                splat_alpha1(s_b, k, fx, fy, al, G);
-                if (__any(al * live > 0.0f)) {
-                    any_contrib = true;
-                    pair_step(k, k - c0, al, G);
                 } else {
-                    s_xa[(k - c0) * XS + lane] = 0.0f;
-                    s_xw[(k - c0) * XS + lane] = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { xa[u * XS] = 0.0f; xw[u * XS] = 0.0f; }
                 }
             }
         }

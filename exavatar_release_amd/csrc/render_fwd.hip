@@ -335,9 +335,11 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
 #ifdef EXA_PROBE_FWD
         if (base == 0) t_first = __builtin_readcyclecounter();
 #endif
-        // issue the next batch's gathers and the ids of the batch after it
+        // issue the next batch's gathers and the ids of the batch after it; lanes past the end of the list
+        // stage an all-zero record (opacity 0 -> alpha 0), so the blend below always runs whole groups of four
         {
             const int jn = base + 64 + lane;
+            r0 = make_float4(0.f, 0.f, 0.f, 0.f); r1 = r0; r2 = r0;
             if (jn < n) {
                 const float4* rec = reinterpret_cast<const float4*>(splats + id_next);
                 r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
@@ -346,31 +348,25 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         }
         wave_lds_fence();
         const int cnt = min(64, n - base);
-        int k = 0;
-        for (; k + 4 <= cnt; k += 4) {
-            const Alpha4 e = splat_alpha4(s_b, k, fx, fy);
+        Ops4 cur = load_ops4(s_b, 0);
+        for (int k = 0; k < cnt; k += 4) {
+            const Ops4 nxt = load_ops4(s_b, (k + 4) & 63);       // operands of the next group: in flight during this one
+            const float4 c0 = s_b.col[k], c1 = s_b.col[k + 1], c2 = s_b.col[k + 2], c3 = s_b.col[k + 3];
+            const Alpha4 e = splat_alpha4(cur, fx, fy);
+            cur = nxt;
             const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
             if (__any(amax > 0.0f)) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float aeff;
-                    const float w = blend_step(T, live, e.alpha[u], aeff);
-                    const float4 c = s_b.col[k + u];
-                    Crg = __builtin_elementwise_fma(v2f{c.x, c.y}, v2f{w, w}, Crg);
-                    Cbd = __builtin_elementwise_fma(v2f{c.z, c.w}, v2f{w, w}, Cbd);
-                }
+                float aeff[4], Tb[4], w[4];
+                blend_group4(T, live, e.alpha, aeff, Tb, w);
+                Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
+                Cbd = __builtin_elementwise_fma(v2f{c0.z, c0.w}, v2f{w[0], w[0]}, Cbd);
+                Crg = __builtin_elementwise_fma(v2f{c1.x, c1.y}, v2f{w[1], w[1]}, Crg);
+                Cbd = __builtin_elementwise_fma(v2f{c1.z, c1.w}, v2f{w[1], w[1]}, Cbd);
+                Crg = __builtin_elementwise_fma(v2f{c2.x, c2.y}, v2f{w[2], w[2]}, Crg);
+                Cbd = __builtin_elementwise_fma(v2f{c2.z, c2.w}, v2f{w[2], w[2]}, Cbd);
+                Crg = __builtin_elementwise_fma(v2f{c3.x, c3.y}, v2f{w[3], w[3]}, Crg);
+                Cbd = __builtin_elementwise_fma(v2f{c3.z, c3.w}, v2f{w[3], w[3]}, Cbd);
                 if (__all(live == 0.0f)) break;
-            }
-        }
-        for (; k < cnt; ++k) {
-            float al, G;
-            splat_alpha1(s_b, k, fx, fy, al, G);
-            if (__any(al * live > 0.0f)) {
-                float aeff;
-                const float w = blend_step(T, live, al, aeff);
-                const float4 c = s_b.col[k];
-                Crg = __builtin_elementwise_fma(v2f{c.x, c.y}, v2f{w, w}, Crg);
-                Cbd = __builtin_elementwise_fma(v2f{c.z, c.w}, v2f{w, w}, Cbd);
             }
         }
         wave_lds_fence();
