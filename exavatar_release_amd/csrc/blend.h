@@ -8,13 +8,18 @@
 // Follows oracle/raster_oracle.py steps 9/10 (the per-pixel rule of the rasterizer behind reference
 // avatar/common/nets/module.py:632-640).
 //
-// Why it looks the way it does (measured on MI355X, tools/probe + EXA_PROBE_FWD builds):
-//  * the render kernels are bound by VALU ISSUE SLOTS, not memory: a wave64 VALU op occupies its SIMD for 4
-//    cycles, so (waves x splats x instructions) / 1024 SIMDs is the floor.  Hence
-//  * splats are evaluated two at a time on packed fp32 (v_pk_add/mul/fma_f32: same 4 cycles, two results),
-//    which needs the staged batch in SoA form (px[64], py[64], ...) so that a pair is one aligned 8 bytes;
+// Why it looks the way it does (measured on MI355X: tools/probe/valu_probe.hip, EXA_PROBE_FWD builds, SQ PMC
+// passes in profiles/):
+//  * the render kernels are bound by per-wave LATENCY and VALU issue, not by memory: only ~3.7 waves per SIMD
+//    exist (one per non-empty 8x8 sub-tile), VALU-active is 55-60 % of the wave cycles.  One SIMD retires a
+//    plain fp32 VALU op per ~2.5 cycles, a packed v_pk_*_f32 per ~5 (two results: same throughput, half the
+//    issue slots), v_exp_f32 per ~8, and a broadcast ds_read_b128 costs 4 LDS cycles of the whole CU.  Hence
+//  * the staged batch is SoA (px[64], py[64], ...): four splats are ONE ds_read_b128 per field, and pairs of
+//    splats form packed operands;
 //  * per-pixel state is arithmetic (`live` = 1.0f / 0.0f), never boolean: boolean state becomes SGPR-mask
-//    traffic (v_cmp -> s_and/s_or -> v_cndmask) that doubled the instruction count of the blend.
+//    traffic (v_cmp -> s_and/s_or -> v_cndmask) that doubled the instruction count of the blend;
+//  * the recurrence is advanced four splats at a time through partial products (blend_group4), so the
+//    loop-carried dependency is one multiply per group.
 #pragma once
 #include "common.h"
 

@@ -111,6 +111,31 @@ def test_large_and_offscreen_gaussians(dev):
     assert int((out['radius'][40:60] > 0).sum()) == 0
 
 
+@pytest.mark.parametrize('n_deep,o_min', [(1500, 0.004), (2600, 0.008)])
+def test_deep_lists(dev, n_deep, o_min):
+    """Thousands of faint splats stacked on one 8x8 sub-tile: list lengths beyond the 1024- and 2048-key LDS sorts
+    (upstream has no such limit), dozens of 64-splat batches per sub-tile in the per-batch backward, and -- for
+    the longer stack -- pixels that stop (T < 1e-4) deep inside the list."""
+    H, W = 96, 128        # large enough that the stack's near-threshold pixels stay under the ambiguity budget
+    f = 90.0
+    g = torch.Generator().manual_seed(n_deep)
+    a = scenes.dist_a_random(n_deep + 300, H, W, seed=n_deep, focal=f)
+    # centres inside a 6 x 6 px patch in the middle of sub-tile (8, 6); faint, so that nothing saturates early
+    depth = 2.0 + 4.0 * torch.rand(n_deep, generator=g)
+    a['mean_3d'][:n_deep, 0] = (4.0 + (torch.rand(n_deep, generator=g) - 0.5) * 6.0) / f * depth
+    a['mean_3d'][:n_deep, 1] = (4.0 + (torch.rand(n_deep, generator=g) - 0.5) * 6.0) / f * depth
+    a['mean_3d'][:n_deep, 2] = depth
+    a['scale'][:n_deep] = (0.02 + 0.02 * torch.rand(n_deep, 3, generator=g)) * depth.view(-1, 1)
+    a['opacity'][:n_deep] = o_min + 0.004 * torch.rand(n_deep, 1, generator=g)
+    cam = scenes.neutral_camera(H, W, focal=f)
+    out, ref = _cmp_render(a, (H, W), cam, torch.rand(3, generator=g), dev, torch.randn(3, H, W, generator=g))
+    # the stack really is deep: the oracle's 16x16 tile holding that sub-tile lists (almost) all of it
+    ranges = ref['aux']['ranges']
+    assert int((ranges[:, 1] - ranges[:, 0]).max()) >= n_deep * 0.9
+    if n_deep > 2048:
+        assert float(ref['aux']['final_T'].min()) < 2e-4          # some pixels ran into the T < 1e-4 stop
+
+
 def test_empty_and_all_culled(dev):
     H, W = 40, 72
     cam = {k: v.to(dev) for k, v in scenes.neutral_camera(H, W).items()}
@@ -126,7 +151,7 @@ def test_empty_and_all_culled(dev):
     out = exa.GaussianRenderer()(a_gpu, (H, W), cam, bg)
     out['img'].sum().backward()
     assert torch.equal(out['img'].detach(), bg.view(3, 1, 1).expand(3, H, W))
-    assert float(out['mask'].abs().max()) == 0.0 and int(out['radius'].abs().max()) == 0
+    assert float(out["mask"].detach().abs().max()) == 0.0 and int(out["radius"].abs().max()) == 0
     for k in KEYS:
         assert float(a_gpu[k].grad.abs().max()) == 0.0
 
