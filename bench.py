@@ -111,15 +111,23 @@ def main():
     # ---- this rank's shard of the ring views ------------------------------------------------------
     my_views = list(range(rank, N_VIEWS, world)) if args.config != 'c1' else [0]
     vs = [view_settings(k, shape, device, args.config) for k in my_views]
-    view_tab = torch.stack([v['view'] for v in vs]).to(device)
-    proj_tab = torch.stack([v['proj'] for v in vs]).to(device)
-    cpos_tab = torch.stack([v['campos'] for v in vs]).to(device)
+    # one 48-float row per view: viewmatrix (16) | projmatrix (16) | campos (3) | pad -- a view switch is ONE copy
+    cam_tab = torch.zeros(len(vs), 48)
+    for j, v in enumerate(vs):
+        cam_tab[j, 0:16] = v['view'].reshape(-1).cpu()
+        cam_tab[j, 16:32] = v['proj'].reshape(-1).cpu()
+        cam_tab[j, 32:35] = v['campos'].reshape(-1).cpu()
+    cam_tab = cam_tab.to(device)
+
+    def make_cam():
+        cam = cam_tab[0].clone()
+        return dict(cam=cam, view=cam[0:16].view(4, 4), proj=cam[16:32].view(4, 4), cpos=cam[32:35])
     S = max(1, args.streams)
     if world > 1 and S > 1:
         raise SystemExit('bench.py: --streams > 1 is only implemented for --gpus 1')
     ctxs = []
     for _ in range(S):
-        c = dict(view=view_tab[0].clone(), proj=proj_tab[0].clone(), cpos=cpos_tab[0].clone())
+        c = make_cam()
         c['settings'] = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'], bg=bg,
             scale_modifier=1.0, viewmatrix=c['view'], projmatrix=c['proj'], sh_degree=0, campos=c['cpos'],
@@ -133,9 +141,7 @@ def main():
 
     def set_view(i, c=None):
         c = c or ctxs[0]
-        c['view'].copy_(view_tab[i])
-        c['proj'].copy_(proj_tab[i])
-        c['cpos'].copy_(cpos_tab[i])
+        c['cam'].copy_(cam_tab[i])
 
     def raster_step(c=None):
         """forward + backward of the rasterizer; for N > 1 the gradients are packed for the all-reduce."""
@@ -274,7 +280,7 @@ def main():
     if rank == 0 and world == 1 and S == 1 and graph is not None and not args.no_concurrent:
         try:
             result['extra_views_in_flight'] = concurrent_throughput(
-                4, args, params, P, H, W, bg, vs, view_tab, proj_tab, cpos_tab, dL_dimg, rasterize_gaussians,
+                4, args, params, P, H, W, bg, vs, cam_tab, make_cam, dL_dimg, rasterize_gaussians,
                 GaussianRasterizationSettings, device)
         except Exception as e:  # noqa: BLE001
             result['extra_views_in_flight'] = {'error': str(e)[:200]}
@@ -341,13 +347,13 @@ def pmc_traffic(kernel):
         return None
 
 
-def concurrent_throughput(S, args, params, P, H, W, bg, vs, view_tab, proj_tab, cpos_tab, dL_dimg, rasterize_gaussians,
+def concurrent_throughput(S, args, params, P, H, W, bg, vs, cam_tab, make_cam, dL_dimg, rasterize_gaussians,
                           Settings, device):
     """Same step, S independent views in flight (one HIP stream + hipGraph each).  Reported next to the headline
     value, never instead of it: ExAvatar's own loop runs one view at a time (batch size 1, config.py:45)."""
     ctxs = []
     for _ in range(S):
-        c = dict(view=view_tab[0].clone(), proj=proj_tab[0].clone(), cpos=cpos_tab[0].clone())
+        c = make_cam()
         c['settings'] = Settings(image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'],
                                  bg=bg, scale_modifier=1.0, viewmatrix=c['view'], projmatrix=c['proj'], sh_degree=0,
                                  campos=c['cpos'], prefiltered=False, debug=False)
@@ -370,13 +376,13 @@ def concurrent_throughput(S, args, params, P, H, W, bg, vs, view_tab, proj_tab, 
         with torch.cuda.graph(c['graph']):
             one(c)
     torch.cuda.synchronize()
-    nv = view_tab.shape[0]
+    nv = cam_tab.shape[0]
 
     def run(k0, k1):
         for i in range(k0, k1):
             c = ctxs[i % S]
             with torch.cuda.stream(c['stream']):
-                c['view'].copy_(view_tab[i % nv]); c['proj'].copy_(proj_tab[i % nv]); c['cpos'].copy_(cpos_tab[i % nv])
+                c['cam'].copy_(cam_tab[i % nv])
                 c['graph'].replay()
     run(0, 4 * S)
     torch.cuda.synchronize()

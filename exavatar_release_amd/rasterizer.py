@@ -222,6 +222,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                                   cov3Ds_precomp if cov3Ds_precomp is not None else empty,
                                   radii, geom, tile, bins, img)
         ctx.mark_non_differentiable(radii)
+        # outputs nobody differentiates (radii, and depth / alpha when the loss ignores them) reach backward as None
+        # instead of freshly zero-filled 4 MB tensors: the kernels take a null pointer for "no gradient"
+        ctx.set_materialize_grads(False)
         return color, radii, depth, alpha
 
     @staticmethod
