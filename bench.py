@@ -337,9 +337,9 @@ def main():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_hbm_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_final_hbm_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate rocprofv3 --pmc runs of the same C3 workload); None if not available."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_final_hbm_traffic.json')
     try:
         with open(path) as f:
             return float(json.load(f)['kernels'][kernel]['hbm_bytes'])

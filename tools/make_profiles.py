@@ -1,0 +1,95 @@
+"""Turns the raw output of tools/profile_round.sh (gpurun_out/<tag>/) into the committed summaries under profiles/:
+   <prefix>_kernel_stats.md, <prefix>_hbm_traffic.{md,json}, <prefix>_pmc.md, <prefix>_bench.json.
+   Usage: python tools/make_profiles.py gpurun_out/r01b r01_final"""
+import sys, os, csv, glob, json, collections
+
+src, prefix = sys.argv[1], sys.argv[2]
+out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+SHORT = {'zero_kernel': 'zero', 'preprocess_fwd_kernel': 'preprocess_fwd', 'cell_scan_kernel': 'cell_scan',
+         'cell_scatter_kernel': 'cell_scatter', 'subtile_bin_kernel': 'subtile_bin', 'sort_subtiles_kernel': 'sort_subtiles',
+         'render_fwd_kernel': 'render_fwd', 'render_bwd_kernel': 'render_bwd', 'preprocess_bwd_kernel': 'preprocess_bwd'}
+
+
+def short(name):
+    for k, v in SHORT.items():
+        if k in name:
+            return v
+    return None
+
+
+def counters(d):
+    rows = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(os.path.join(src, d, '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                k = short(r['Kernel_Name'])
+                if k:
+                    rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in rows.items()}
+
+
+bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+with open(os.path.join(out, prefix + '_bench.json'), 'w') as f:
+    json.dump(bench, f, indent=1)
+
+# ---- kernel stats ----------------------------------------------------------------------------------------
+stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+with open(os.path.join(out, prefix + '_kernel_stats.md'), 'w') as f:
+    f.write('# %s: rocprofv3 kernel statistics of the bench command\n\n' % prefix)
+    f.write('Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 '
+            '--no-cpu-baseline --no-concurrent` (C3, 1 x MI355X, hipGraph replay; includes the untimed calibration / warm-up '
+            'launches of bench.py, hence more calls than steps).\n\n')
+    f.write('Bench line of the same build (default `python bench.py`): %.1f it/s, %.4f ms/step; roofline kernel %s '
+            'avg %.1f us (HIP events) .\n\n' % (bench['value'], bench['ms_per_step'], bench['roofline']['kernel'],
+                                                  bench['roofline']['avg_launch_us']))
+    f.write('| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n')
+    if stats:
+        with open(stats[0]) as g:
+            for r in csv.DictReader(g):
+                f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3,
+                                                                  float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+
+# ---- HBM traffic -----------------------------------------------------------------------------------------
+fe, wr = counters('pmc_fetch'), counters('pmc_write')
+alg = bench['roofline'].get('algorithmic_bytes_per_launch')
+tr = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes), python '
+                'tools/gpu_kernel_times.py 0 (C3, ring view 0, eager, mean of the launches); bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, '
+                'no gfx950 wide-read x2 correction applied (access pattern is 16-B gathers, uncalibrated)', 'kernels': {}}
+with open(os.path.join(out, prefix + '_hbm_traffic.md'), 'w') as f:
+    f.write('# %s: HBM-side traffic per kernel launch (PMC)\n\n' % prefix)
+    f.write('Two separate PMC passes (no other trace domains): `rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- '
+            'python tools/gpu_kernel_times.py 0` and the same with `--pmc WRITE_SIZE`. Config C3, ring view 0. '
+            'bytes = (FETCH_SIZE + WRITE_SIZE) x 1024. MI355X_MICROARCH.md notes FETCH_SIZE under-reports wide coalesced '
+            '16-B/lane streams by 2x on gfx950 and is uncalibrated for other patterns; these kernels mostly gather 64-byte '
+            'records, so the raw value is listed (read side may be up to 2x higher).\n\n')
+    f.write('| kernel | FETCH_SIZE (KB) | WRITE_SIZE (KB) | HBM bytes |\n|---|---|---|---|\n')
+    for k in SHORT.values():
+        if k in fe and k in wr:
+            a, b = fe[k].get('FETCH_SIZE', 0.0), wr[k].get('WRITE_SIZE', 0.0)
+            tr['kernels'][k] = {'fetch_KB': a, 'write_KB': b, 'hbm_bytes': (a + b) * 1024}
+            f.write('| %s | %.0f | %.0f | %.3g |\n' % (k, a, b, (a + b) * 1024))
+with open(os.path.join(out, prefix + '_hbm_traffic.json'), 'w') as f:
+    json.dump(tr, f, indent=1)
+
+# ---- SQ counters -----------------------------------------------------------------------------------------
+s1, s2 = counters('pmc_sq1'), counters('pmc_sq2')
+with open(os.path.join(out, prefix + '_pmc.md'), 'w') as f:
+    f.write('# %s: SQ counters per kernel (mean per dispatch; SQ_*_CYCLES / ACTIVE / WAIT in quad-cycles)\n\n' % prefix)
+    f.write('Two PMC passes of `python tools/gpu_kernel_times.py 0` (C3, ring view 0, eager), counters only with --kernel-trace.\n\n')
+    for tab in (s1, s2):
+        names = sorted({c for k in tab.values() for c in k})
+        if not names:
+            continue
+        f.write('| kernel | ' + ' | '.join(names) + ' |\n|---|' + '---|' * len(names) + '\n')
+        for k in SHORT.values():
+            if k in tab:
+                f.write('| %s | ' % k + ' | '.join('%.3g' % tab[k].get(c, float('nan')) for c in names) + ' |\n')
+        f.write('\n')
+    f.write('| kernel | VALU-active / wave-cycles | parked (WAIT_ANY) | issue-stalled (WAIT_INST_ANY) | LDS-active / wave-cycles |\n|---|---|---|---|---|\n')
+    for k in SHORT.values():
+        if k in s1 and s1[k].get('SQ_WAVE_CYCLES'):
+            wc = s1[k]['SQ_WAVE_CYCLES']
+            f.write('| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% |\n' % (
+                k, 100 * s1[k].get('SQ_ACTIVE_INST_VALU', 0) / wc, 100 * s1[k].get('SQ_WAIT_ANY', 0) / wc,
+                100 * s1[k].get('SQ_WAIT_INST_ANY', 0) / wc, 100 * s2.get(k, {}).get('SQ_ACTIVE_INST_LDS', 0) / wc))
+print('wrote profiles/%s_*' % prefix)
