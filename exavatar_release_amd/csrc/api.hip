@@ -151,7 +151,7 @@ int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void*
     BinWs bw = carve_bin_ws(bin_ws, capacity);
     if (capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
     Splat* splats = static_cast<Splat*>(const_cast<void*>(geom_ws));   // cell_scatter fills Splat::inst_off
-    EXA_HIP(launch_zero(bw.owner, (capacity / BATCH + 1) * 4, st), "zero(batch owners)");
+    EXA_HIP(launch_zero(bw.owner, (capacity / BATCH + 1) * 16, st), "zero(batch owners)");
     EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(P, splats, tw, g, bw, capacity, st), "cell_scatter");
     if ((rc = debug_sync(s, st, "cell_scatter"))) return rc;
     EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(splats, tw, g, bw, capacity, st), "subtile_bin");
@@ -197,7 +197,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Grid g = make_grid(s->image_width, s->image_height);
     RenderBwdArgs r;
-    r.grid = g; r.capacity = capacity; r.splats = static_cast<const Splat*>(geom_ws);
+    r.grid = g; r.capacity = capacity; r.P = P; r.splats = static_cast<const Splat*>(geom_ws);
     r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.cells, num_chunks(P));
     r.bw = carve_bin_ws(const_cast<void*>(bin_ws), capacity);
     r.iw = carve_img_ws(const_cast<void*>(img_ws), g.W, g.H);

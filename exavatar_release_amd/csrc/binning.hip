@@ -214,7 +214,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid
         const uint32_t begin = overflow ? 0u : o0.y + (incl - nslot) * BATCH;
         s_off[tid] = begin;
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
-        for (uint32_t bq = 0; bq + 1 < nslot; ++bq) b.owner[begin / BATCH + bq] = (uint32_t)(cell * SUBS_PER_CELL + tid) + 1u;
+        for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
+            b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
     }
     __syncthreads();
     for (uint32_t e = e0 + tid; e < e1; e += BIN_THREADS) {

@@ -126,20 +126,21 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
 constexpr int BATCH = 64;
 // bin workspace: keys[cap] (u64: depth bits << 32 | gaussian id), sorted ids[cap], cell buckets[cap]
 // (16-byte entries {id, depth bits, sub-tile rect x, y} so the second digit reads them coalesced),
-// batch owner[cap / 64] (sub-tile + 1, 0 = unused; zeroed by stage 2), per-pixel forward checkpoints
-// ckpt[cap / 64][5][64] floats (T, Cr, Cg, Cb, depth at the START of every batch slot / at the forward's exit).
+// batch owner[cap / 64] ({sub-tile + 1, list begin, list length, 0}; all-zero = unused; zeroed by stage 2: the ONE
+// load a backward workgroup needs to find its work), per-pixel forward checkpoints ckpt[cap / 64][5][64] floats
+// (T, Cr, Cg, Cb, depth at the START of every batch slot; the sub-tile's END slot holds the state at the forward's exit).
 __host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) {
-    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16) + align256((cap / BATCH + 1) * 4) +
+    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16) + align256((cap / BATCH + 1) * 16) +
            align256((cap / BATCH + 1) * 5 * 64 * 4);
 }
-struct BinWs { unsigned long long* keys; uint32_t* sorted; uint4* bucket; uint32_t* owner; float* ckpt; };
+struct BinWs { unsigned long long* keys; uint32_t* sorted; uint4* bucket; uint4* owner; float* ckpt; };
 __host__ __device__ inline BinWs carve_bin_ws(void* base, uint64_t cap) {
     BinWs b;
     char* p = static_cast<char*>(base);
     b.keys = reinterpret_cast<unsigned long long*>(p); p += align256(cap * 8);
     b.sorted = reinterpret_cast<uint32_t*>(p); p += align256(cap * 4);
     b.bucket = reinterpret_cast<uint4*>(p); p += align256(cap * 16);
-    b.owner = reinterpret_cast<uint32_t*>(p); p += align256((cap / BATCH + 1) * 4);
+    b.owner = reinterpret_cast<uint4*>(p); p += align256((cap / BATCH + 1) * 16);
     b.ckpt = reinterpret_cast<float*>(p);
     return b;
 }
@@ -231,7 +232,7 @@ hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s);
 hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
 
 struct RenderBwdArgs {
-    Grid grid; uint64_t capacity;
+    Grid grid; uint64_t capacity; int P;
     const Splat* splats; TileWs tw; BinWs bw; ImgWs iw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
     Partial* partials;

@@ -52,43 +52,30 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
     __shared__ float s_xw[GC * XS];             // w[splat][pixel]
 
     const int lane = threadIdx.x;
-    const uint32_t own = a.bw.owner[blockIdx.x];
-    if (own == 0) return;                                       // unused batch slot
-    const int st = (int)own - 1;
-    const uint2 range = a.tw.ranges[st];
-    const int n = (int)(range.y - range.x);
-    const int b0 = (int)(range.x / BATCH);                      // first slot of the sub-tile
+    // Round trip 1: the owner record and -- speculatively, the instance space being 64-aligned per sub-tile --
+    // this slot's 64 sorted ids (garbage past the end of the list; clamped before use).
+    const uint4 own = a.bw.owner[blockIdx.x];
+    const uint32_t id_raw = a.bw.sorted[(size_t)blockIdx.x * BATCH + lane];
+    if (own.x == 0) return;                                     // unused batch slot
+    const int st = (int)own.x - 1;
+    const int n = (int)own.z;
+    const int b0 = (int)(own.y / BATCH);                        // first slot of the sub-tile
     const int bq = (int)blockIdx.x - b0;                        // batch index inside the sub-tile
     const int bstart = bq * BATCH;
     const int cnt = min(BATCH, n - bstart);
+    // Round trip 2: everything else (records, batches entered, checkpoints, pixel gradients) is issued together.
     const int entered = (int)a.tw.fwd_exit[st].y;               // batches the forward pass walked into
     const SubTile sub = decode_subtile(st, a.grid);
     float4* __restrict__ partials = reinterpret_cast<float4*>(a.partials);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // stage this batch: ids -> records; every lane also computes its splat's Partial slot
-    const Splat* __restrict__ splats = a.splats;
-    uint32_t pslot = 0;
-    if (lane < cnt) {
-        const uint32_t id = a.bw.sorted[range.x + bstart + lane];
-        const float4* rec = reinterpret_cast<const float4*>(splats + id);
-        const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
-        const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
-        pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
-        if (bq < entered) {
-            stage_splat(s_b, lane, rec[0], rec[1], rec[2]);
-            s_pslot[lane] = pslot;
-        }
-    } else if (bq < entered) {                                  // past the end of the list: all-zero record (alpha 0)
-        stage_splat(s_b, lane, zero4, zero4, zero4);
-    }
-    if (bq >= entered) {                                        // every pixel had stopped before this batch
-        if (lane < cnt) {
-            float4* dst = partials + (size_t)pslot * 3;
-            dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
-        }
-        return;
-    }
+    const float4* rec = reinterpret_cast<const float4*>(a.splats + min(id_raw, (uint32_t)(a.P - 1)));
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
+    // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
+    const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;
+    const float* cs = a.bw.ckpt + (size_t)blockIdx.x * (5 * 64) + lane;
+    const float cs0 = cs[0], cs1 = cs[64], cs2 = cs[128], cs3 = cs[192], cs4 = cs[256];    // unused for batch 0
+    const float cf0 = cf[0], cf1 = cf[64], cf2 = cf[128], cf3 = cf[192], cf4 = cf[256];
 
     // ---- per-pixel set-up --------------------------------------------------------------------------
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
@@ -104,23 +91,39 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
         if (a.dL_ddepth) gd = a.dL_ddepth[pix];
         if (a.dL_dalpha) ga = a.dL_dalpha[pix];
     }
+
+    uint32_t pslot = 0;
+    if (lane < cnt) {
+        const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
+        pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
+    }
+    if (bq >= entered) {                                        // every pixel had stopped before this batch
+        if (lane < cnt) {
+            float4* dst = partials + (size_t)pslot * 3;
+            dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
+        }
+        return;
+    }
+    if (lane < cnt) {
+        stage_splat(s_b, lane, r0, r1, r2);
+        s_pslot[lane] = pslot;
+    } else {                                                    // past the end of the list: all-zero record (alpha 0)
+        stage_splat(s_b, lane, zero4, zero4, zero4);
+    }
+
     s_pg[lane] = make_float4(gr, gg, gb, gd);
-    // state at the START of this batch and at the forward's exit
-    const float* cf = a.bw.ckpt + (size_t)(b0 + entered) * (5 * 64) + lane;
     float T = 1.0f, live = inside ? 1.0f : 0.0f;
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
     if (bq > 0) {
-        const float* cs = a.bw.ckpt + (size_t)blockIdx.x * (5 * 64) + lane;
-        const float t = cs[0];
-        T = fabsf(t);
-        live = t > 0.0f ? 1.0f : 0.0f;
-        sr = cs[64]; sg = cs[128]; sb = cs[192]; sd = cs[256];
+        T = fabsf(cs0);
+        live = cs0 > 0.0f ? 1.0f : 0.0f;
+        sr = cs1; sg = cs2; sb = cs3; sd = cs4;
     }
-    const float T_final = cf[0];
+    const float T_final = cf0;
     const float* __restrict__ bg = a.bg;
     // d/d(alpha_i) of [T_final * bg . g] and of [ga * (1 - T_final)]:  (T_final / (1 - alpha_i)) * (ga - bg.g)
     const float tail = T_final * (ga - (bg[0] * gr + bg[1] * gg + bg[2] * gb));
-    float R = (cf[64] - sr) * gr + (cf[128] - sg) * gg + (cf[192] - sb) * gb + (cf[256] - sd) * gd - tail;
+    float R = (cf1 - sr) * gr + (cf2 - sg) * gg + (cf3 - sb) * gb + (cf4 - sd) * gd - tail;
     wave_lds_fence();
 
     const int g = lane % GC, h = lane / GC;

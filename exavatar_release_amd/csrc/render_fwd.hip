@@ -394,8 +394,8 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
             (void)t_first;
         }
 #endif
-        if (n > 0) {   // exit state = end state of the last batch entered
-            float* c = ckpt + (size_t)entered * (5 * 64);
+        if (n > 0) {   // exit state -> the sub-tile's END slot (a fixed place the backward finds without `entered`)
+            float* c = ckpt + (size_t)((n + BATCH - 1) / BATCH) * (5 * 64);
             c[0] = T; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
         }
     }
