@@ -118,7 +118,6 @@ int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, 
     const Grid g = make_grid(s->image_width, s->image_height);
     TileWs tw = carve_tile_ws(tile_ws, g.cells, num_chunks(P));
     // header + cell counters + cell cursors are contiguous: one zero-fill
-    EXA_TIMED(K_ZERO, launch_zero(tile_ws, tile_ws_zero_bytes(g.cells), st), "zero(tile counters)");
     PreprocessArgs a;
     a.P = P; a.sh_M = sh_M; a.sh_degree = s->sh_degree; a.grid = g;
     a.tanfovx = s->tanfovx; a.tanfovy = s->tanfovy;
@@ -151,7 +150,8 @@ int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void*
     BinWs bw = carve_bin_ws(bin_ws, capacity);
     if (capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
     Splat* splats = static_cast<Splat*>(const_cast<void*>(geom_ws));   // cell_scatter fills Splat::inst_off
-    EXA_HIP(launch_zero(bw.owner, (capacity / BATCH + 1) * 16, st), "zero(batch owners)");
+    // the batch-owner array is cleared by cell_scatter_kernel itself (no Gaussians: nobody else would)
+    if (P == 0) EXA_TIMED(K_ZERO, launch_zero(bw.owner, (capacity / BATCH + 1) * 16, st), "zero(batch owners)");
     EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(P, splats, tw, g, bw, capacity, st), "cell_scatter");
     if ((rc = debug_sync(s, st, "cell_scatter"))) return rc;
     EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(splats, tw, g, bw, capacity, st), "subtile_bin");

@@ -54,8 +54,41 @@ __global__ __launch_bounds__(BLOCK) void zero_kernel(uint4* __restrict__ p, size
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0, 0, 0, 0);
 }
 
-// One workgroup: exclusive prefix of the per-cell (entries, instances) totals and of the per-chunk
-// instance counts; header.num_rendered = total instances.
+// Column pass over the (chunk, cell) count matrix written by preprocess_fwd: 32 columns (cells) per workgroup,
+// 32 row blocks.  Produces the column totals (cell_cnt) and replaces the low word of every entry by the number of
+// entries the EARLIER chunks put into that cell, so that cell_scatter_kernel needs no atomic cursor and places
+// entries deterministically (by chunk, then by LDS rank).
+constexpr int COL_W = 32, COL_RB = SCAN_THREADS / COL_W;
+__global__ __launch_bounds__(SCAN_THREADS) void col_scan_kernel(TileWs w, int cells, int chunks) {
+    __shared__ unsigned long long s_part[COL_RB][COL_W];
+    const int tid = threadIdx.x, col = tid & (COL_W - 1), rb = tid / COL_W;
+    const int c = blockIdx.x * COL_W + col;
+    const int rows_per = (chunks + COL_RB - 1) / COL_RB;
+    const int r0 = min(chunks, rb * rows_per), r1 = min(chunks, r0 + rows_per);
+    unsigned long long* m = w.chunk_cell + c;
+    unsigned long long sum = 0ull;
+    if (c < cells)
+        for (int r = r0; r < r1; ++r) sum += m[(size_t)r * cells];
+    s_part[rb][col] = sum;
+    __syncthreads();
+    if (c >= cells) return;
+    unsigned long long before = 0ull, total = 0ull;
+    for (int q = 0; q < COL_RB; ++q) {
+        const unsigned long long v = s_part[q][col];
+        if (q < rb) before += v;
+        total += v;
+    }
+    if (rb == 0) w.cell_cnt[c] = total;
+    uint32_t run = (uint32_t)before;
+    for (int r = r0; r < r1; ++r) {
+        const unsigned long long v = m[(size_t)r * cells];
+        m[(size_t)r * cells] = (v & 0xffffffff00000000ull) | run;
+        run += (uint32_t)v;
+    }
+}
+
+// One workgroup: exclusive prefix of the per-cell (entries, instances) totals and of the per-chunk instance
+// counts, the header, the LPT order of the cells.
 __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int cells, int chunks) {
     __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
     const int tid = threadIdx.x;
@@ -80,8 +113,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
     if (tid == 0) {
         w.cell_off[cells] = make_uint2(carry_e, carry_i);
         w.header->num_rendered = carry_i;
+        w.header->overflow = 0u;
         w.header->max_tile_list = carry_e;     // reused slot: number of (Gaussian, cell) entries
     }
+    if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
     // Launch order of the per-pixel kernels: cells bucketed by floor(log2(instances)) (33 buckets),
     // heaviest bucket first, so the longest lists start early and the tail of the launch is light.
     __shared__ uint32_t s_bucket[34];
@@ -101,24 +136,36 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
         const uint32_t n = (uint32_t)(w.cell_cnt[c] >> 32);
         w.cell_order[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = (uint32_t)c;
     }
-    uint32_t carry = 0;
+    uint32_t carry = 0, vis = 0;
     for (int base = 0; base < chunks; base += SCAN_THREADS) {
         const int c = base + tid;
         const uint32_t v = c < chunks ? w.chunk_inst[c] : 0u;
+        vis += c < chunks ? w.chunk_vis[c] : 0u;
         uint32_t t;
         const uint32_t x = block_excl_scan(v, s_tmp, t);
         if (c < chunks) w.chunk_off[c] = carry + x;
         carry += t;
+    }
+    {
+        uint32_t tot;
+        block_excl_scan(vis, s_tmp, tot);
+        if (tid == 0) w.header->num_visible = tot;
     }
 }
 
 // CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
 // into the splat record, (b) Gaussian ids scattered into their cells' buckets; bucket ranges are reserved
 // with one returning atomic per (chunk, non-empty cell), ranks inside the reservation come from LDS atomics.
-__global__ __launch_bounds__(BLOCK) void cell_scatter_kernel(int P, Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
+constexpr int SC_BLOCK = CHUNK;        // one Gaussian per thread
+__global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(int P, Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
                                                              uint64_t capacity) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // cnt[cells] | base[cells] | cnt2[cells]
-    __shared__ uint32_t s_tmp[BLOCK / 64];
+    __shared__ uint32_t s_tmp[SC_BLOCK / 64];
+    {   // this workgroup's slice of the batch-owner array (written by subtile_bin_kernel, the next launch)
+        const size_t n16 = capacity / BATCH + 1, per = (n16 + gridDim.x - 1) / gridDim.x;
+        const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+        for (size_t i = lo + threadIdx.x; i < hi; i += SC_BLOCK) b.owner[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const uint32_t D = w.header->num_rendered;
     if ((uint64_t)D > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) w.header->overflow = 1u;
@@ -128,17 +175,17 @@ __global__ __launch_bounds__(BLOCK) void cell_scatter_kernel(int P, Splat* __res
     uint32_t* s_base = s_dyn + g.cells;
     uint32_t* s_cnt2 = s_dyn + 2 * g.cells;
     const int tid = threadIdx.x;
-    for (int c = tid; c < 3 * g.cells; c += BLOCK) s_dyn[c] = 0u;
+    for (int c = tid; c < 3 * g.cells; c += SC_BLOCK) s_dyn[c] = 0u;
     __syncthreads();
 
-    constexpr int PER = CHUNK / BLOCK;
+    constexpr int PER = CHUNK / SC_BLOCK;
     uint4 r3[PER];
     int ids[PER];
     uint32_t depth_bits[PER];
     uint32_t mine = 0;
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
-        ids[it] = blockIdx.x * CHUNK + it * BLOCK + tid;
+        ids[it] = blockIdx.x * CHUNK + it * SC_BLOCK + tid;
         r3[it] = make_uint4(0, 0, 0, 0);
         depth_bits[it] = 0;
         if (ids[it] < P) {
@@ -161,12 +208,8 @@ __global__ __launch_bounds__(BLOCK) void cell_scatter_kernel(int P, Splat* __res
         }
     }
     __syncthreads();
-    for (int c = tid; c < g.cells; c += BLOCK) {
-        const uint32_t n = s_cnt[c];
-        if (n)
-            s_base[c] = w.cell_off[c].x +
-                        __hip_atomic_fetch_add(&w.cell_cursor[c], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int c = tid; c < g.cells; c += SC_BLOCK)
+        s_base[c] = w.cell_off[c].x + (uint32_t)w.chunk_cell[(size_t)blockIdx.x * g.cells + c];
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
@@ -241,6 +284,7 @@ hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
 }
 
 hipError_t launch_cell_scan(const TileWs& w, const Grid& g, int chunks, hipStream_t s) {
+    if (g.cells > 0) col_scan_kernel<<<(g.cells + COL_W - 1) / COL_W, SCAN_THREADS, 0, s>>>(w, g.cells, chunks);
     cell_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(w, g.cells, chunks);
     return hipGetLastError();
 }
@@ -248,7 +292,7 @@ hipError_t launch_cell_scan(const TileWs& w, const Grid& g, int chunks, hipStrea
 hipError_t launch_cell_scatter(int P, Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
                                hipStream_t s) {
     if (P == 0) return hipSuccess;
-    cell_scatter_kernel<<<num_chunks(P), BLOCK, (size_t)g.cells * 12, s>>>(P, splats, w, g, b, capacity);
+    cell_scatter_kernel<<<num_chunks(P), SC_BLOCK, (size_t)g.cells * 12, s>>>(P, splats, w, g, b, capacity);
     return hipGetLastError();
 }
 

@@ -78,27 +78,29 @@ __host__ __device__ inline Grid make_grid(int W, int H) {
 __host__ __device__ inline uint64_t align256(uint64_t v) { return (v + 255) & ~uint64_t(255); }
 __host__ __device__ inline int num_chunks(int P) { return (P + CHUNK - 1) / CHUNK; }
 
-// Layout of the tile workspace (all sections 256-byte aligned).  [zeroed] sections are cleared by the
-// first kernel of every forward.
+// Layout of the tile workspace (all sections 256-byte aligned).  Nothing in it needs zeroing by the caller or by
+// a memset: every section is fully written by the kernel that produces it before anyone reads it.
 struct TileWs {
-    ExaRasterHeader* header;          // [1]                      [zeroed]
-    uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class [zeroed] (in the header block)
-    unsigned long long* cell_cnt;     // [cells]  inst << 32 | entries            [zeroed]
-    uint32_t* cell_cursor;            // [cells]  entries already placed per cell [zeroed]
+    ExaRasterHeader* header;          // [1]          written by cell_scan_kernel
+    uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class (zeroed by cell_scan)
+    unsigned long long* chunk_cell;   // [chunks][cells]  per-(chunk, cell) counts inst << 32 | entries, plain stores by
+                                      //              preprocess (NO atomics: same-address device atomics of ~150 chunks
+                                      //              serialise at the memory side); cell_scan replaces the low word by the
+                                      //              chunk's first entry slot inside the cell bucket
+    unsigned long long* cell_cnt;     // [cells]      column totals inst << 32 | entries
     uint2* cell_off;                  // [cells + 1]  exclusive prefix (entries, instances)
-    uint32_t* chunk_inst;             // [chunks]     instances emitted by each 512-Gaussian chunk
+    uint32_t* chunk_inst;             // [chunks]     instances emitted by each chunk
+    uint32_t* chunk_vis;              // [chunks]     Gaussians of the chunk that passed the culls
     uint32_t* chunk_off;              // [chunks]     exclusive prefix of chunk_inst
     uint32_t* cell_order;             // [cells]      cells by descending instance count (heavy work first)
     uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays, cell-major
     uint4* slots;                     // [subtiles]   launch-order records {begin, end, st, 0}: ONE load gives a
                                       //              per-pixel-kernel workgroup everything it needs
-    uint2* fwd_exit;                  // [subtiles]   {last list position any pixel blended, batches the forward entered}
+    uint2* fwd_exit;                  // [subtiles]   {list length, batches the forward entered}
 };
-__host__ __device__ inline uint64_t tile_ws_zero_bytes(int cells) {
-    return HEADER_BYTES + align256(uint64_t(cells) * 8) + align256(uint64_t(cells) * 4);
-}
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
-    return tile_ws_zero_bytes(cells) + align256(uint64_t(cells + 1) * 8) + 2 * align256(uint64_t(chunks + 1) * 4) +
+    return HEADER_BYTES + align256(uint64_t(chunks) * cells * 8) + align256(uint64_t(cells) * 8) +
+           align256(uint64_t(cells + 1) * 8) + 3 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 4) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8);
 }
@@ -108,10 +110,11 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.header = reinterpret_cast<ExaRasterHeader*>(p);
     w.cls_cur = reinterpret_cast<uint32_t*>(p + 256);
     p += HEADER_BYTES;
+    w.chunk_cell = reinterpret_cast<unsigned long long*>(p); p += align256(uint64_t(chunks) * cells * 8);
     w.cell_cnt = reinterpret_cast<unsigned long long*>(p); p += align256(uint64_t(cells) * 8);
-    w.cell_cursor = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.cell_off = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells + 1) * 8);
     w.chunk_inst = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
+    w.chunk_vis = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.chunk_off = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.cell_order = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);

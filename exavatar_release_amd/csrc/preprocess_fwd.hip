@@ -211,9 +211,10 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
 }
 
 // CHUNK Gaussians per workgroup.  Besides the per-Gaussian work, builds this chunk's histogram over the
-// 64x64-pixel cells in LDS (entries and instances packed in one u64) and flushes it with ONE 64-bit
-// atomic per (chunk, non-empty cell): device-scope atomics run at only ~12 G/s chip-wide on MI355X,
-// so they are spent per cell, never per instance.
+// 64x64-pixel cells in LDS (entries and instances packed in one u64) and stores it as one row of the
+// (chunk, cell) count matrix -- no global atomics at all: device-scope atomics run at only ~12 G/s chip-wide on
+// MI355X and ~150 chunks adding into the same few dozen cell counters serialise at the memory side
+// (that tail was ~8 us of this kernel).  cell_scan_kernel sums the columns.
 __global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_cell[];   // [cells]
     __shared__ uint32_t s_red[BLOCK / 64];
@@ -251,15 +252,16 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
         inst_sum += __shfl_xor(inst_sum, d, 64);
         nvis += __shfl_xor(nvis, d, 64);
     }
-    if ((tid & 63) == 0) s_red[tid >> 6] = inst_sum;
+    __shared__ uint32_t s_vis[BLOCK / 64];
+    if ((tid & 63) == 0) { s_red[tid >> 6] = inst_sum; s_vis[tid >> 6] = nvis; }
     __syncthreads();
-    if (tid == 0) a.tw.chunk_inst[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    if ((tid & 63) == 0 && nvis)
-        __hip_atomic_fetch_add(&a.tw.header->num_visible, nvis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int c = tid; c < a.grid.cells; c += BLOCK) {
-        const unsigned long long v = s_cell[c];
-        if (v) __hip_atomic_fetch_add(&a.tw.cell_cnt[c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+        a.tw.chunk_inst[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+        a.tw.chunk_vis[blockIdx.x] = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
     }
+    // this chunk's row of the (chunk, cell) count matrix: plain coalesced stores, zeros included
+    unsigned long long* row = a.tw.chunk_cell + (size_t)blockIdx.x * a.grid.cells;
+    for (int c = tid; c < a.grid.cells; c += BLOCK) row[c] = s_cell[c];
 }
 
 __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float* __restrict__ means3D,
