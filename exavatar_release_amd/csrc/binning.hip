@@ -230,53 +230,74 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(int P, Splat* __
 // LDS, turns the counts into [begin, end) ranges (cell-major sub-tile order) and scatters the sort keys.
 // Entries are 16-byte records read coalesced; no gather from the splat array.
 constexpr int BIN_THREADS = 1024;
-// The kernel is bound by its scattered 8-byte key stores (one per instance), and an avatar's instances sit in a
-// few dozen cells: with one workgroup per cell only those few CUs store.  Every cell is therefore handled by
-// BIN_PARTS workgroups: each COUNTS the whole cell (cheap: coalesced 16-byte reads + LDS atomics), which gives it
-// the sub-tile ranges and the number of entries the earlier parts put into every sub-tile, and SCATTERS only its
-// own quarter of the entries.  No cross-workgroup communication; part 0 publishes the ranges and batch owners.
-constexpr int BIN_PARTS = 4;
-__global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid g, BinWs b, uint64_t capacity) {
-    __shared__ uint32_t s_cnt[SUBS_PER_CELL];       // entries of the whole cell per sub-tile
-    __shared__ uint32_t s_before[SUBS_PER_CELL];    // ... of the parts before this one
-    __shared__ uint32_t s_off[SUBS_PER_CELL];
-    __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
-    const int cell = (int)w.cell_order[blockIdx.x / BIN_PARTS], part = (int)(blockIdx.x % BIN_PARTS), tid = threadIdx.x;
-    const bool overflow = (uint64_t)w.header->num_rendered > capacity;
-    const uint2 o0 = w.cell_off[cell], o1 = w.cell_off[cell + 1];
-    const uint32_t e0 = o0.x, e1 = overflow ? o0.x : o1.x;
-    const uint32_t per = (e1 - e0 + BIN_PARTS - 1) / BIN_PARTS;
-    const uint32_t my_lo = min(e1, e0 + (uint32_t)part * per), my_hi = min(e1, my_lo + per);
-    if (tid < SUBS_PER_CELL) { s_cnt[tid] = 0u; s_cnt2[tid] = 0u; s_before[tid] = 0u; }
+// An avatar's instances sit in a few dozen cells, and both halves of this digit -- LDS counting atomics and the
+// scattered 8-byte key stores, one per instance -- are throughput limits of ONE CU.  Every cell is therefore
+// handled by BIN_PARTS workgroups in two launches:
+//   subtile_count_kernel  part p counts its quarter of the cell's entries per sub-tile -> part_cnt[cell][p][64]
+//   subtile_bin_kernel    reads the cell's BIN_PARTS x 64 counts (totals -> 64-aligned ranges; earlier parts ->
+//                         its own first slot in every sub-tile) and scatters its quarter of the keys.
+// Plain stores and a kernel boundary instead of any cross-workgroup atomics; part 0 publishes ranges and owners.
+struct CellPart { int cell, part; uint32_t e0, e1, lo, hi; bool overflow; };
+__device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {
+    CellPart c;
+    c.cell = (int)w.cell_order[blockIdx.x / BIN_PARTS];
+    c.part = (int)(blockIdx.x % BIN_PARTS);
+    c.overflow = (uint64_t)w.header->num_rendered > capacity;
+    const uint2 o0 = w.cell_off[c.cell], o1 = w.cell_off[c.cell + 1];
+    c.e0 = o0.x;
+    c.e1 = c.overflow ? o0.x : o1.x;
+    const uint32_t per = (c.e1 - c.e0 + BIN_PARTS - 1) / BIN_PARTS;
+    c.lo = min(c.e1, c.e0 + (uint32_t)c.part * per);
+    c.hi = min(c.e1, c.lo + per);
+    return c;
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(TileWs w, Grid g, BinWs b, uint64_t capacity) {
+    __shared__ uint32_t s_cnt[SUBS_PER_CELL];
+    const CellPart cp = cell_part(w, capacity);
+    const int tid = threadIdx.x;
+    if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
-    const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
-    for (uint32_t e = e0 + tid; e < e1; e += BIN_THREADS) {
+    const int csx0 = (cp.cell % g.cx) * CELL_SUBS, csy0 = (cp.cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
         const uint4 en = b.bucket[e];
         const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
         const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
-        const bool earlier = e < my_lo;
         for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) {
+            for (int x = x0; x < x1; ++x)
                 __hip_atomic_fetch_add(&s_cnt[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (earlier)
-                    __hip_atomic_fetch_add(&s_before[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
     }
     __syncthreads();
+    if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * BIN_PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid g, BinWs b, uint64_t capacity) {
+    __shared__ uint32_t s_off[SUBS_PER_CELL];
+    __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
+    const CellPart cp = cell_part(w, capacity);
+    const int cell = cp.cell, tid = threadIdx.x;
     if (tid < 64) {
-        const uint32_t n = s_cnt[tid];
+        uint32_t n = 0, before = 0;
+#pragma unroll
+        for (int p = 0; p < BIN_PARTS; ++p) {
+            const uint32_t v = w.part_cnt[((size_t)cell * BIN_PARTS + p) * SUBS_PER_CELL + tid];
+            before += p < cp.part ? v : 0u;
+            n += v;
+        }
         const uint32_t nslot = n ? (n + BATCH - 1) / BATCH + 1 : 0u;       // real batches + one end slot
         const uint32_t incl = wave_incl_scan(nslot);
-        const uint32_t begin = overflow ? 0u : o0.y + (incl - nslot) * BATCH;
-        s_off[tid] = begin + s_before[tid];
-        if (part == 0) {
+        const uint32_t begin = cp.overflow ? 0u : w.cell_off[cell].y + (incl - nslot) * BATCH;
+        s_off[tid] = begin + before;
+        s_cnt2[tid] = 0u;
+        if (cp.part == 0) {
             w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
             for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
                 b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
         }
     }
     __syncthreads();
-    for (uint32_t e = my_lo + tid; e < my_hi; e += BIN_THREADS) {
+    const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
         const uint4 en = b.bucket[e];
         const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
         const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
@@ -315,6 +336,7 @@ hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& 
                               hipStream_t s) {
     if (g.cells == 0) return hipSuccess;
     (void)splats;
+    subtile_count_kernel<<<g.cells * BIN_PARTS, BIN_THREADS, 0, s>>>(w, g, b, capacity);
     subtile_bin_kernel<<<g.cells * BIN_PARTS, BIN_THREADS, 0, s>>>(w, g, b, capacity);
     return hipGetLastError();
 }

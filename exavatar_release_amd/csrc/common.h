@@ -80,6 +80,7 @@ __host__ __device__ inline int num_chunks(int P) { return (P + CHUNK - 1) / CHUN
 
 // Layout of the tile workspace (all sections 256-byte aligned).  Nothing in it needs zeroing by the caller or by
 // a memset: every section is fully written by the kernel that produces it before anyone reads it.
+constexpr int BIN_PARTS = 4;           // workgroups per cell in the sub-tile binning (binning.hip)
 struct TileWs {
     ExaRasterHeader* header;          // [1]          written by cell_scan_kernel
     uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class (zeroed by cell_scan)
@@ -97,12 +98,14 @@ struct TileWs {
     uint4* slots;                     // [subtiles]   launch-order records {begin, end, st, 0}: ONE load gives a
                                       //              per-pixel-kernel workgroup everything it needs
     uint2* fwd_exit;                  // [subtiles]   {list length, batches the forward entered}
+    uint32_t* part_cnt;               // [cells][BIN_PARTS][64]  entries per sub-tile counted by each part of a cell
 };
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return HEADER_BYTES + align256(uint64_t(chunks) * cells * 8) + align256(uint64_t(cells) * 8) +
            align256(uint64_t(cells + 1) * 8) + 3 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 4) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
-           align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8);
+           align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
+           align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -119,7 +122,8 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.cell_order = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.slots = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 16);
-    w.fwd_exit = reinterpret_cast<uint2*>(p);
+    w.fwd_exit = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
+    w.part_cnt = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 
