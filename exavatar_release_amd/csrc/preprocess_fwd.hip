@@ -215,17 +215,18 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
 // (chunk, cell) count matrix -- no global atomics at all: device-scope atomics run at only ~12 G/s chip-wide on
 // MI355X and ~150 chunks adding into the same few dozen cell counters serialise at the memory side
 // (that tail was ~8 us of this kernel).  cell_scan_kernel sums the columns.
-__global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
+constexpr int PBLOCK = 1024;           // threads per chunk: one Gaussian each (no atomics left to contend on)
+__global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_cell[];   // [cells]
-    __shared__ uint32_t s_red[BLOCK / 64];
+    __shared__ uint32_t s_red[PBLOCK / 64];
     const int tid = threadIdx.x;
-    for (int c = tid; c < a.grid.cells; c += BLOCK) s_cell[c] = 0ull;
+    for (int c = tid; c < a.grid.cells; c += PBLOCK) s_cell[c] = 0ull;
     __syncthreads();
     uint32_t inst_sum = 0;
     uint32_t nvis = 0;
 #pragma unroll 1
-    for (int it = 0; it < CHUNK / BLOCK; ++it) {
-        const int idx = blockIdx.x * CHUNK + it * BLOCK + tid;
+    for (int it = 0; it < CHUNK / PBLOCK; ++it) {
+        const int idx = blockIdx.x * CHUNK + it * PBLOCK + tid;
         if (idx < a.P) {
             int sxy[4];
             bool vis;
@@ -252,16 +253,16 @@ __global__ __launch_bounds__(BLOCK) void preprocess_fwd_kernel(PreprocessArgs a)
         inst_sum += __shfl_xor(inst_sum, d, 64);
         nvis += __shfl_xor(nvis, d, 64);
     }
-    __shared__ uint32_t s_vis[BLOCK / 64];
+    __shared__ uint32_t s_vis[PBLOCK / 64];
     if ((tid & 63) == 0) { s_red[tid >> 6] = inst_sum; s_vis[tid >> 6] = nvis; }
     __syncthreads();
     if (tid == 0) {
-        a.tw.chunk_inst[blockIdx.x] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-        a.tw.chunk_vis[blockIdx.x] = s_vis[0] + s_vis[1] + s_vis[2] + s_vis[3];
+        { uint32_t t = 0; for (int i = 0; i < PBLOCK / 64; ++i) t += s_red[i]; a.tw.chunk_inst[blockIdx.x] = t; }
+        { uint32_t t = 0; for (int i = 0; i < PBLOCK / 64; ++i) t += s_vis[i]; a.tw.chunk_vis[blockIdx.x] = t; }
     }
     // this chunk's row of the (chunk, cell) count matrix: plain coalesced stores, zeros included
     unsigned long long* row = a.tw.chunk_cell + (size_t)blockIdx.x * a.grid.cells;
-    for (int c = tid; c < a.grid.cells; c += BLOCK) row[c] = s_cell[c];
+    for (int c = tid; c < a.grid.cells; c += PBLOCK) row[c] = s_cell[c];
 }
 
 __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float*
 
 hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
     if (a.P == 0) return hipSuccess;
-    preprocess_fwd_kernel<<<num_chunks(a.P), BLOCK, (size_t)a.grid.cells * 8, s>>>(a);
+    preprocess_fwd_kernel<<<num_chunks(a.P), PBLOCK, (size_t)a.grid.cells * 8, s>>>(a);
     return hipGetLastError();
 }
 
