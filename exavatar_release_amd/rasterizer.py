@@ -206,6 +206,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     _pending.append((ev, host, key, capacity))
 
         _debug_last['tile'] = tile
+        _debug_last['geom'] = geom
         _debug_last['capacity'] = capacity
         ctx.raster_settings = rs
         ctx.need_ctx = need_ctx
