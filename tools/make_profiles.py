@@ -5,7 +5,8 @@ import sys, os, csv, glob, json, collections
 
 src, prefix = sys.argv[1], sys.argv[2]
 out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
-SHORT = {'zero_kernel': 'zero', 'preprocess_fwd_kernel': 'preprocess_fwd', 'cell_scan_kernel': 'cell_scan',
+SHORT = {'zero_kernel': 'zero', 'preprocess_fwd_kernel': 'preprocess_fwd', 'col_scan_kernel': 'col_scan', 'cell_scan_kernel': 'cell_scan',
+         'subtile_count_kernel': 'subtile_count',
          'cell_scatter_kernel': 'cell_scatter', 'subtile_bin_kernel': 'subtile_bin', 'sort_subtiles_kernel': 'sort_subtiles',
          'render_fwd_kernel': 'render_fwd', 'render_bwd_kernel': 'render_bwd', 'preprocess_bwd_kernel': 'preprocess_bwd'}
 
