@@ -1,18 +1,19 @@
 // Binning for gfx950: the "duplicate then radix sort" of the upstream rasterizer restructured as an
-// MSD radix sort with LDS-resident histograms:
-//   digit 1 = 64x64-px cell     histogram in preprocess_fwd.hip (one u64 atomic per (chunk, cell)),
-//                               prefix in cell_scan_kernel, scatter of Gaussian ids in cell_scatter_kernel
-//   digit 2 = 8x8-px sub-tile   subtile_bin_kernel: one workgroup per cell, counts / prefix / ranks in LDS,
-//                               emits (depth bits << 32 | id) keys grouped by sub-tile
-//   digit 3 = depth (+ id)      sorted per sub-tile inside LDS by the render kernel (render_fwd.hip)
+// MSD radix sort with LDS-resident histograms and NO global atomics:
+//   digit 1 = 64x64-px cell     per-chunk histogram in preprocess_fwd.hip, stored as a row of the (chunk, cell)
+//                               count matrix; col_scan_kernel (column totals + per-chunk offsets),
+//                               cell_scan_kernel (prefix over cells), cell_scatter_kernel (entries -> buckets)
+//   digit 2 = 8x8-px sub-tile   subtile_count_kernel + subtile_bin_kernel: four workgroups per cell, counts and
+//                               ranks in LDS, emits (depth bits << 32 | id) keys grouped by sub-tile
+//   digit 3 = depth (+ id)      sorted per sub-tile inside LDS by sort_subtiles_kernel (render_fwd.hip)
 // which reproduces the order of upstream's stable global sort on (tile << 32 | depth bits): ascending
-// depth, ties by ascending Gaussian id.  Device-scope atomics (slow on MI355X) are used once per
-// (512-Gaussian chunk, cell) pair, never per instance.
+// depth, ties by ascending Gaussian id.  Counts travel between workgroups through plain-store matrices and
+// kernel boundaries: device-scope atomics run at ~12 G/s on MI355X and serialise per address.
 //
 // Replaces upstream InclusiveSum + duplicateWithKeys + SortPairs(tile digit) + identifyTileRanges of the
 // rasterizer behind reference avatar/common/nets/module.py:632-640.
-// HBM traffic: reads 16 B of every visible splat record twice, writes 4 B per cell entry and 8 B per
-// instance, 4 B inst_off per Gaussian; scans are O(cells + chunks).
+// HBM traffic: reads 16 B of every visible splat record twice, writes 16 B per cell entry and 8 B per
+// instance, 4 B inst_off per Gaussian; scans are O(chunks x cells).
 #include "common.h"
 
 namespace exa {
@@ -154,8 +155,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
 }
 
 // CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
-// into the splat record, (b) Gaussian ids scattered into their cells' buckets; bucket ranges are reserved
-// with one returning atomic per (chunk, non-empty cell), ranks inside the reservation come from LDS atomics.
+// into the splat record, (b) 16-byte entries scattered into their cells' buckets: the chunk's first slot in
+// every cell comes from the scanned count matrix, ranks inside it from LDS atomics, (c) clears this
+// workgroup's slice of the batch-owner array.
 constexpr int SC_BLOCK = CHUNK;        // one Gaussian per thread
 __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(int P, Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
                                                              uint64_t capacity) {

@@ -1,18 +1,17 @@
-// Per-sub-tile depth sort and front-to-back alpha compositing for gfx950 -- two barrier-free kernels.
+// Per-sub-tile depth sort and front-to-back alpha compositing for gfx950.
 //
-// ONE WAVE per 8x8-pixel sub-tile (lane l -> pixel (l & 7, l >> 3)), one wave per workgroup, no
-// __syncthreads anywhere: a wave owns its list, its LDS slice and its 64 pixels, and frees its slot the
-// moment it is done.  Split in two launches so each gets the occupancy it needs:
-//   sort_subtiles_kernel  (256 threads, 8 KiB LDS): four waves co-operate on one sub-tile's bucket of
+// The blend runs ONE WAVE per 8x8-pixel sub-tile (lane l -> pixel (l & 7, l >> 3)), one wave per workgroup,
+// no __syncthreads: a wave owns its list, its LDS slice and its 64 pixels, and frees its slot the moment
+// it is done.  Split in two launches so each gets the shape it needs:
+//   sort_subtiles_kernel  (256 threads, 16 KiB LDS): four waves co-operate on one sub-tile's bucket of
 //       (depth bits << 32 | id) keys -- rank sorted runs of 64 merged by rank (binary search) in place in
-//       LDS; lists > 1024 keys fall back to a register rank sort -- and write the sorted ids.
-//       Third radix digit of the binning (binning.hip).
-//   render_fwd_kernel     (3 KiB LDS / wave, <= 64 VGPRs -> 8 waves / SIMD): streams the sorted ids in
-//       batches of 64; each lane gathers ONE 64-byte splat record (48 B used) into the wave's LDS slice --
-//       ids are fetched two batches ahead and records one batch ahead, so the two dependent global
-//       round trips hide behind the blend of the current batch -- then the 64 pixels blend the batch from
-//       LDS broadcast reads, four Gaussians per iteration so four exp2 are in flight while the serial
-//       T recurrence of the previous ones retires.
+//       LDS; lists > 2048 keys fall back to a register rank sort -- and write the sorted ids.
+//       Third radix digit of the binning (binning.hip).  Its first 16 workgroups build the length-sorted
+//       launch order of the blend.
+//   render_fwd_kernel     (2.5 KiB LDS / wave): streams the sorted ids in batches of 64; each lane gathers ONE
+//       64-byte splat record (48 B used) into the wave's LDS slice, SoA -- ids are fetched two batches ahead
+//       and records one batch ahead, so the two dependent global round trips hide behind the blend of the
+//       current batch -- then the 64 pixels blend the batch four splats at a time (blend.h).
 //
 // Replaces upstream SortPairs(depth digit) + renderCUDA (forward) of the rasterizer the reference
 // calls at avatar/common/nets/module.py:632-640; per-pixel rule = oracle step 9/10
@@ -20,7 +19,7 @@
 //
 // Algorithmic HBM bytes: sort reads 8 B/instance, writes 4 B/instance; blend reads 4 B/instance + 48 B per
 // gathered splat per sub-tile it touches (L2-resident after the first touch), writes 20 B/pixel
-// (rgb, depth, alpha) + 8 B/pixel (final_T, n_contrib, training only).
+// (rgb, depth, alpha) + 20 B/pixel of checkpoint per batch entered (training only).
 #include "blend.h"
 
 namespace exa {
