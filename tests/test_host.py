@@ -144,3 +144,16 @@ def test_scenes_are_seeded_and_shaped():
     assert torch.all(b['scale'][:, 0] == b['scale'][:, 1])
     sh = scenes.sh_from_rgb(a1['rgb'][:7], 3)
     assert sh.shape == (7, 16, 3)
+
+
+def test_dev_layout_helper_matches_library():
+    """tools/_layout.py (used by the developer probes) mirrors carve_tile_ws(): same total size as the C ABI reports."""
+    import importlib.util
+    import os
+    from exavatar_release_amd import _lib
+    spec = importlib.util.spec_from_file_location(
+        '_layout', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', '_layout.py'))
+    lay = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lay)
+    for P, W, H in ((150000, 1024, 1024), (1000, 540, 960), (0, 64, 64), (70001, 1920, 1080)):
+        assert lay.tile_offsets(P, W, H)['total'] == int(_lib.workspace_sizes(P, W, H, 0).tile_bytes)

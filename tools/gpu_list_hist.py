@@ -10,9 +10,8 @@ dev = torch.device('cuda:0'); H = W = 1024; P = 150000
 assets = scenes.dist_b_avatar(P, seed=0)
 params = [assets[k].to(dev) for k in ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')]
 exa.config.mode = 'exact'
-a256 = lambda v: (v + 255) & ~255
-cells = 256; chunks = (P + 1023) // 1024
-off = 512 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4) + a256(cells * 4) + a256(cells * 64 * 8)
+cells = 256; from _layout import tile_offsets
+lay = tile_offsets(P, W, H); cells = lay['cells']; off = lay['slots'][0]
 for k in [int(v) for v in (sys.argv[1:] or [0, 25, 50])]:
     tanx, tany, view, proj, cpos = make_raster_matrices(scenes.ring_camera(H, W, k, 200), (H, W))
     st = GaussianRasterizationSettings(H, W, tanx, tany, torch.ones(3, device=dev), 1.0, view.to(dev), proj.to(dev), 0, cpos.to(dev), False, False)

@@ -20,10 +20,8 @@ for rep in range(3):
         rasterize_gaussians(m3, m2, None, rgb, op, sc, rot, None, st)
     torch.cuda.synchronize()
 tile = _debug_last['tile']
-cells = 256; chunks = (P + 511) // 512
-a256 = lambda v: (v + 255) & ~255
-chunks = (P + 1023) // 1024
-off = 512 + a256(cells * 8) + a256(cells * 4) + a256((cells + 1) * 8) + 2 * a256((chunks + 1) * 4) + a256(cells * 4) + a256(cells * 64 * 8)
+from _layout import tile_offsets
+lay = tile_offsets(P, W, H); cells = lay['cells']; off = lay['slots'][0]
 slots = tile[off: off + cells * 64 * 16].view(torch.int32).view(-1, 4).cpu().numpy().astype(np.int64)
 n = slots[:, 1] - slots[:, 0]; cyc = slots[:, 3] & 0xffffffff
 act = n > 0
