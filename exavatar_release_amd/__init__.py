@@ -7,7 +7,8 @@ Public surface (drop-in for ``diff_gaussian_rasterization_depth`` as used at ref
 """
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, check_overflow, config,
                          rasterize_gaussians)
-from .renderer import GaussianRenderer
+from .densify import track_densify_stats
+from .renderer import GaussianRenderer, render_many
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
-           'config', 'check_overflow']
+           'config', 'check_overflow', 'track_densify_stats', 'render_many']

@@ -233,6 +233,16 @@ int exa_raster_mark_visible(const ExaRasterSettings* s, int32_t P, const float* 
     return debug_sync(s, st, "mark_visible");
 }
 
+int exa_raster_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii, float* xyz_grad_accum,
+                             float* track_cnt, float* radius_max, void* stream) {
+    if (P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
+    if (P > 0 && !radii) return fail(EXA_RASTER_E_NULLPTR, "radii is NULL");
+    if (P > 0 && xyz_grad_accum && !dL_dmeans2D) return fail(EXA_RASTER_E_NULLPTR, "dL_dmeans2D is NULL");
+    EXA_HIP(launch_densify_stats(P, dL_dmeans2D, radii, xyz_grad_accum, track_cnt, radius_max,
+                                 static_cast<hipStream_t>(stream)), "densify_stats");
+    return 0;
+}
+
 int exa_raster_timing_enable(int32_t on) {
     if (on && !g_t.created) {
         for (int i = 0; i < K_COUNT; ++i)

@@ -258,5 +258,7 @@ struct PreprocessBwdArgs {
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
 };
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, float* accum, float* cnt, float* rmax,
+                                hipStream_t s);
 
 }  // namespace exa

@@ -281,6 +281,30 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
     }
 }
 
+// Fused densification statistics (include/exa_raster.h: exa_raster_densify_stats; reference
+// avatar/main/model.py:279-285 + avatar/common/nets/module.py:155-157).  Pure streaming: 16 B in, <= 12 B
+// read-modify-write per Gaussian.
+__global__ __launch_bounds__(BLOCK) void densify_stats_kernel(int P, const float* __restrict__ g2d,
+                                                              const int32_t* __restrict__ radii, float* accum,
+                                                              float* cnt, float* rmax) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    if (accum) {
+        const float gx = g2d[3 * i], gy = g2d[3 * i + 1];
+        accum[i] += sqrtf(gx * gx + gy * gy);
+    }
+    if (cnt) cnt[i] += 1.0f;
+    if (rmax) rmax[i] = fmaxf(rmax[i], (float)r);
+}
+hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, float* accum, float* cnt, float* rmax,
+                                hipStream_t s) {
+    if (P == 0) return hipSuccess;
+    densify_stats_kernel<<<(P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(P, g2d, radii, accum, cnt, rmax);
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
     if (a.P == 0) return hipSuccess;
     preprocess_bwd_kernel<<<(a.P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(a);

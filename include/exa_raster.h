@@ -153,6 +153,19 @@ int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const 
                             uint8_t* present, void* stream);
 
 /*
+ * Fused densification statistics.  Replaces the PyTorch bookkeeping the reference runs after
+ * every backward on the scene Gaussians -- avatar/main/train.py:49-54 (stack mean_2d.grad),
+ * avatar/main/model.py:279-285 (radius_max), avatar/common/nets/module.py:155-157 (track_stats) -- whose
+ * boolean-mask indexing costs a host synchronisation per statement.  For every Gaussian i with radii[i] > 0:
+ *     xyz_grad_accum[i] += sqrt(g.x^2 + g.y^2)   with g = dL_dmeans2D[i] (the NDC-scaled screen gradient)
+ *     track_cnt[i]      += 1
+ *     radius_max[i]      = max(radius_max[i], (float)radii[i])
+ * All arrays are device pointers of P elements ([P,3] for dL_dmeans2D); any of the three outputs may be NULL.
+ */
+int exa_raster_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii,
+                             float* xyz_grad_accum, float* track_cnt, float* radius_max, void* stream);
+
+/*
  * Optional per-kernel timing for benchmarks (the only state the library ever keeps, process-wide,
  * off by default, not thread-safe).  While enabled, every kernel / memset the library enqueues is bracketed by a
  * pair of hipEvents recorded on the caller's stream.  exa_raster_timing_read() synchronises on the

@@ -447,3 +447,15 @@ def render(gaussian_assets, img_shape, cam_param, bg=None, dtype=torch.float32, 
     if return_aux:
         out['aux'] = res[4]
     return out
+
+
+def densify_stats_reference(mean_2d_grad, radius, xyz_grad_accum, track_cnt, radius_max):
+    """The reference's densification bookkeeping for ONE render, statement by statement
+    (avatar/main/model.py:279-285 and SceneGaussian.track_stats, avatar/common/nets/module.py:155-157), on clones:
+    ``is_vis = radius > 0`` (module.py:645), returns the three updated statistics."""
+    is_vis = radius > 0
+    xyz_grad_accum, track_cnt, radius_max = xyz_grad_accum.clone(), track_cnt.clone(), radius_max.clone()
+    radius_max[is_vis] = torch.maximum(radius_max[is_vis], radius[is_vis].to(radius_max.dtype))
+    xyz_grad_accum[is_vis, :] += torch.norm(mean_2d_grad[is_vis, :2], dim=1, keepdim=True)
+    track_cnt[is_vis, :] += 1
+    return xyz_grad_accum, track_cnt, radius_max

@@ -379,3 +379,59 @@ def test_hipgraph_replay_equals_eager(dev):
     finally:
         exa.config.mode = 'exact'
         exa.config.fixed_capacity = None
+
+
+def test_fused_densify_stats_match_reference_bookkeeping(dev):
+    """one HIP kernel instead of the reference's boolean-mask statements, on a real render's outputs,
+    accumulated over three views like a training run does."""
+    H, W = 120, 160
+    a = scenes.dist_a_random(4000, H, W, seed=31, focal=180.0)
+    a['mean_3d'][:500, 2] = -1.0                                   # never visible: statistics must stay untouched
+    P = 4000
+    acc = torch.rand(P, 1)
+    cnt = torch.randint(0, 5, (P, 1)).float()
+    rmax = torch.rand(P) * 3
+    acc_g, cnt_g, rmax_g = acc.to(dev), cnt.to(dev), rmax.to(dev)
+    for v in range(3):
+        cam = scenes.ring_camera(H, W, v, 12, radius=3.0, center=(0, 0, 4.0), focal=180.0)
+        ag = _to(a, dev)
+        out = exa.GaussianRenderer()(ag, (H, W), {k: t.to(dev) for k, t in cam.items()}, torch.ones(3, device=dev))
+        out['img'].square().sum().backward()
+        g2d, radius = out['mean_2d'].grad, out['radius']
+        exa.track_densify_stats(g2d, radius, acc_g, cnt_g, rmax_g)
+        acc, cnt, rmax = ro.densify_stats_reference(g2d.cpu(), radius.cpu(), acc, cnt, rmax)
+    assert torch.equal(cnt_g.cpu(), cnt) and torch.equal(rmax_g.cpu(), rmax)
+    assert torch.allclose(acc_g.cpu(), acc, rtol=1e-6, atol=0)
+    assert float(cnt[:500].max()) <= 4.0 and torch.equal(cnt_g.cpu()[:500], cnt[:500])
+
+
+def test_render_many_is_bit_identical_to_sequential_renders(dev):
+    """the five same-camera renders of one ExAvatar iteration (model.py:129-167: scene, human,
+    scene+human, human refined, scene+human refined) issued concurrently on five streams -- images and every
+    gradient equal the sequential result bit for bit."""
+    H, W = 128, 160
+    f = 170.0
+    scene = scenes.dist_a_random(3000, H, W, seed=41, focal=f)
+    human = scenes.dist_a_random(1500, H, W, seed=42, focal=f)
+    refined = {k: (v + 0.01 * torch.randn(v.shape, generator=torch.Generator().manual_seed(43)) if k == 'mean_3d' else v.clone())
+               for k, v in human.items()}
+    cam = {k: t.to(dev) for k, t in scenes.neutral_camera(H, W, focal=f).items()}
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    g = torch.Generator().manual_seed(44)
+    G = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(5)]
+
+    def run(concurrent):
+        s, h, r = _to(scene, dev), _to(human, dev), _to(refined, dev)
+        cat = lambda a_, b_: {k: torch.cat((a_[k].detach(), b_[k])) for k in KEYS}      # scene detached, like the reference
+        jobs = [(s, (H, W), cam), (h, (H, W), cam, bg), (cat(s, h), (H, W), cam), (r, (H, W), cam, bg), (cat(s, r), (H, W), cam)]
+        rend = exa.GaussianRenderer()
+        outs = exa.render_many(rend, jobs) if concurrent else [rend(*j) for j in jobs]
+        sum((o['img'] * Gi).sum() + o['mask'].sum() for o, Gi in zip(outs, G)).backward()
+        torch.cuda.synchronize()
+        grads = [t[k].grad.clone() for t in (s, h, r) for k in KEYS] + [o['mean_2d'].grad.clone() for o in outs]
+        return [o['img'].detach().clone() for o in outs] + [o['radius'].clone() for o in outs], grads
+
+    imgs_a, grads_a = run(False)
+    imgs_b, grads_b = run(True)
+    for x, y in zip(imgs_a + grads_a, imgs_b + grads_b):
+        assert torch.equal(x, y)

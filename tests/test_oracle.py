@@ -288,3 +288,13 @@ def test_float32_and_float64_oracles_agree_away_from_thresholds():
     d = (o32['img'].double() - o64['img']).abs()
     d[:, amb] = 0
     assert float(d.max()) < 5e-5
+
+
+def test_densify_stats_reference_semantics():
+    """Known-answer check of the restated densification bookkeeping (reference model.py:279-285, module.py:155-157)."""
+    g = torch.tensor([[3.0, 4.0, 9.0], [1.0, 0.0, 0.0], [0.0, 2.0, 5.0]])
+    radius = torch.tensor([7, 0, 2], dtype=torch.int32)
+    acc, cnt, rmax = ro.densify_stats_reference(g, radius, torch.ones(3, 1), torch.zeros(3, 1), torch.tensor([9.0, 1.0, 1.0]))
+    assert acc.flatten().tolist() == [6.0, 1.0, 3.0]          # + ||(3,4)|| = 5, untouched, + ||(0,2)|| = 2
+    assert cnt.flatten().tolist() == [1.0, 0.0, 1.0]
+    assert rmax.tolist() == [9.0, 1.0, 2.0]

@@ -1,0 +1,24 @@
+import sys, os, time, cProfile, pstats
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import torch
+import exavatar_release_amd as exa
+from exavatar_release_amd import scenes
+dev = torch.device('cuda:0'); H = W = 1024
+human = {k: v.to(dev).requires_grad_(True) for k, v in scenes.dist_b_avatar(150000, seed=2).items()}
+cam = {k: t.to(dev) for k, t in scenes.ring_camera(H, W, 7, 200).items()}
+bg = torch.ones(3, device=dev); G = torch.randn(3, H, W, device=dev)
+rend = exa.GaussianRenderer()
+exa.config.mode = 'capacity'
+def it():
+    o = rend(human, (H, W), cam, bg)
+    for v in human.values(): v.grad = None
+    (o['img'] * G).sum().backward()
+for _ in range(10): it()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): it()
+torch.cuda.synchronize(); print('eager render fwd+bwd: %.3f ms' % ((time.perf_counter() - t0) / 50 * 1e3))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(50): it()
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
