@@ -158,7 +158,6 @@ int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void*
     if ((rc = debug_sync(s, st, "subtile_bin"))) return rc;
     RenderFwdArgs r;
     r.grid = g; r.splats = static_cast<const Splat*>(geom_ws); r.tw = tw; r.bw = bw; r.capacity = capacity;
-    r.iw = carve_img_ws(img_ws, g.W, g.H);
     r.bg = s->bg; r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha; r.store_ctx = store_ctx;
     EXA_TIMED(K_SORT, launch_sort_subtiles(r, st), "sort_subtiles");
     if ((rc = debug_sync(s, st, "sort_subtiles"))) return rc;
@@ -200,7 +199,6 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     r.grid = g; r.capacity = capacity; r.P = P; r.splats = static_cast<const Splat*>(geom_ws);
     r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.cells, num_chunks(P));
     r.bw = carve_bin_ws(const_cast<void*>(bin_ws), capacity);
-    r.iw = carve_img_ws(const_cast<void*>(img_ws), g.W, g.H);
     r.bg = s->bg; r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
     r.partials = static_cast<Partial*>(grad_ws);
     EXA_TIMED(K_RENDER_BWD, launch_render_bwd(r, st), "render_bwd");

@@ -156,15 +156,9 @@ __host__ __device__ inline uint32_t cell_slots(uint32_t inst) {
     return inst ? (inst + BATCH - 1) / BATCH + 2 * SUBS_PER_CELL : 0u;
 }
 
-// image workspace: final_T[H*W] f32, n_contrib[H*W] u32.
-__host__ __device__ inline uint64_t img_ws_bytes(int W, int H) { return 2 * align256(uint64_t(W) * H * 4); }
-struct ImgWs { float* final_T; uint32_t* n_contrib; };
-__host__ __device__ inline ImgWs carve_img_ws(void* base, int W, int H) {
-    ImgWs i;
-    i.final_T = static_cast<float*>(base);
-    i.n_contrib = reinterpret_cast<uint32_t*>(static_cast<char*>(base) + align256(uint64_t(W) * H * 4));
-    return i;
-}
+// image workspace: reserved.  The per-pixel context of the backward pass (final T, contributor count) moved into
+// the per-batch checkpoints of the bin workspace; the ABI keeps the argument, 256 bytes are enough.
+__host__ __device__ inline uint64_t img_ws_bytes(int, int) { return 256; }
 
 // backward scratch: one Partial per instance.
 __host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * sizeof(Partial)); }
@@ -232,7 +226,7 @@ hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& 
 
 struct RenderFwdArgs {
     Grid grid;
-    const Splat* splats; TileWs tw; BinWs bw; uint64_t capacity; ImgWs iw;
+    const Splat* splats; TileWs tw; BinWs bw; uint64_t capacity;
     const float* bg; float* out_color; float* out_depth; float* out_alpha; int store_ctx;
 };
 hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s);
@@ -240,7 +234,7 @@ hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
 
 struct RenderBwdArgs {
     Grid grid; uint64_t capacity; int P;
-    const Splat* splats; TileWs tw; BinWs bw; ImgWs iw; const float* bg;
+    const Splat* splats; TileWs tw; BinWs bw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
     Partial* partials;
 };

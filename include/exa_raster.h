@@ -60,9 +60,9 @@ typedef struct ExaRasterSettings {
 /* Byte sizes of the caller-allocated workspaces. */
 typedef struct ExaRasterWorkspaceSizes {
     uint64_t geom_bytes;   /* per-Gaussian splat records, 64 B * P                         */
-    uint64_t tile_bytes;   /* per-cell counters / prefixes, per-sub-tile ranges + the header */
-    uint64_t bin_bytes;    /* per-instance keys + sorted ids + cell buckets, 16 B * capacity */
-    uint64_t img_bytes;    /* per-pixel final_T + n_contrib, 8 B * W * H                    */
+    uint64_t tile_bytes;   /* header, (chunk, cell) count matrix, prefixes, per-sub-tile ranges   */
+    uint64_t bin_bytes;    /* keys, sorted ids, cell buckets, batch owners, checkpoints: ~48 B * capacity */
+    uint64_t img_bytes;    /* reserved (256): the per-pixel context lives in the batch checkpoints */
     uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
