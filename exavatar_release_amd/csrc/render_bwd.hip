@@ -5,8 +5,9 @@
 // start of every batch and at its exit, so every batch of every sub-tile runs concurrently and the longest
 // dependent chain is 64 splats (a kernel that walks whole lists with one wave is bound by its longest list).
 //
-// The kernel is bound by VALU issue slots (a wave64 VALU op holds its SIMD for 4 cycles), so the design
-// minimises instructions per (pixel, splat) pair.  Two phases per chunk of GC splats:
+// The kernel is bound by VALU issue and per-wave latency (profiles/: VALU-active ~29 % of the wave cycles at ~3
+// waves per SIMD; HBM < 10 % of peak), so the design minimises instructions per (pixel, splat) pair.  Two phases
+// per chunk of GC = 16 splats (8 and 32 measured slower):
 //
 //  Phase A  (lane = pixel, splats in list order): REPLAY the forward recurrence from the checkpoint with the
 //           forward's own code (blend.h) -- no 1/(1-alpha) reconstruction of T, no `n_contrib` array -- and
@@ -19,8 +20,9 @@
 //           sums over the 64 pixels (five screen-space moments of aG, sum aG, and w-weighted pixel gradients)
 //           into plain per-lane accumulation: ~14 VALU per pixel step for GC splats at once, versus a
 //           ~58-instruction cross-lane butterfly PER SPLAT in the previous version of this kernel
-//           (measured 120 -> see profiles/).  64 / GC pixel groups run side by side and are combined with
-//           64/GC - 1 shuffle steps.
+//           (120 -> 90 us).  64 / GC pixel groups run side by side and are combined with log2(64 / GC) shuffle
+//           steps.  (The same phase as a GEMM on v_mfma_f32_16x16x4_f32 was tried: fp32 MFMA runs at the vector
+//           rate, 32 cycles per instruction, and the wave waits for it -- 20 % slower.)
 //
 // Every instance gets its 48-byte Gaussian-major `Partial` written exactly once (zeros when nothing
 // contributed): no memset, NO atomic in the whole backward pass (device-scope fp32 atomics run at ~12 G/s on

@@ -104,8 +104,8 @@ int exa_raster_forward_bin(const ExaRasterSettings* settings, int32_t P, int32_t
  * scatter Gaussians into cell buckets and then sub-tile buckets, depth-sort every bucket in LDS,
  * blend front to back.  (geom_ws is logically const; the call fills one reserved field per record.)
  * If the header's num_rendered > capacity nothing is rendered and header.overflow is set.
- * `store_ctx` != 0 additionally writes what the backward pass needs (sorted ids, final_T,
- * n_contrib); pass 0 for inference.
+ * `store_ctx` != 0 additionally writes what the backward pass needs (per-batch pixel checkpoints,
+ * batches entered per sub-tile); pass 0 for inference.
  */
 int exa_raster_forward_render(const ExaRasterSettings* settings, int32_t P,
                               const void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity,
