@@ -83,7 +83,13 @@ def main():
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group('nccl', device_id=device)
+        # RCCL ("nccl") in production; EXA_BENCH_BACKEND=gloo lets the multi-rank code path be exercised with several
+        # ranks sharing one GPU (RCCL refuses duplicate devices), which is how it is smoke-tested on a 1-GPU box
+        backend = os.environ.get('EXA_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     import exavatar_release_amd as exa
     from exavatar_release_amd import _lib
@@ -97,12 +103,14 @@ def main():
     names = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
     params = [assets[k].to(device).contiguous().requires_grad_(True) for k in names]
     n_float = sum(p.numel() for p in params)
-    flat_grad = torch.zeros(n_float, device=device)
     offs, o = [], 0
     for p_ in params:
         offs.append((o, o + p_.numel()))
         o += p_.numel()
-    grad_views = [flat_grad[a_:b_].view_as(p_) for (a_, b_), p_ in zip(offs, params)]
+
+    def make_flat():
+        flat = torch.zeros(n_float, device=device)
+        return flat, [flat[a_:b_].view_as(p_) for (a_, b_), p_ in zip(offs, params)]
 
     g = torch.Generator().manual_seed(1)
     dL_dimg = torch.randn(3, H, W, generator=g).to(device)
@@ -125,9 +133,14 @@ def main():
     S = max(1, args.streams)
     if world > 1 and S > 1:
         raise SystemExit('bench.py: --streams > 1 is only implemented for --gpus 1')
+    # N > 1: two contexts on the SAME stream, each with its own flat gradient buffer, used alternately -- the
+    # all-reduce of step i reads buffer i % 2 while step i + 1 computes into the other one (a single buffer would
+    # be overwritten by the next step's backward while RCCL still reads it)
+    n_ctx = S if world == 1 else 2
     ctxs = []
-    for _ in range(S):
+    for _ in range(n_ctx):
         c = make_cam()
+        c['flat'], c['grad_views'] = make_flat()
         c['settings'] = GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'], bg=bg,
             scale_modifier=1.0, viewmatrix=c['view'], projmatrix=c['proj'], sh_degree=0, campos=c['cpos'],
@@ -153,7 +166,7 @@ def main():
         if world > 1:
             # pack for the all-reduce with elementwise kernels (copy_ would become hipMemcpyAsync graph nodes,
             # which break stream capture in the ROCm runtime bundled with torch 2.10)
-            for v_, g_ in zip(grad_views, grads[:5]):
+            for v_, g_ in zip(c['grad_views'], grads[:5]):
                 torch.add(g_, 0.0, out=v_)
         return None
 
@@ -213,10 +226,11 @@ def main():
             graph = None
             launch = 'eager'
 
-    pending = [None]
+    pending = [None] * n_ctx
 
     def step(i):
-        c = ctxs[i % S]
+        k = i % n_ctx
+        c = ctxs[k]
         if c['stream'] is not None:
             with torch.cuda.stream(c['stream']):
                 set_view(i % len(my_views), c)
@@ -225,20 +239,22 @@ def main():
                 else:
                     raster_step(c)
             return
-        set_view(i % len(my_views))
-        if graph is not None:
-            graph.replay()
+        if pending[k] is not None:          # the all-reduce that last read this context's buffer (two steps ago)
+            pending[k].wait()
+            pending[k] = None
+        set_view(i % len(my_views), c)
+        if c['graph'] is not None:
+            c['graph'].replay()
         else:
-            raster_step()
+            raster_step(c)
         if world > 1:
-            if pending[0] is not None:
-                pending[0].wait()
-            pending[0] = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, async_op=True)
+            pending[k] = dist.all_reduce(c['flat'], op=dist.ReduceOp.SUM, async_op=True)
 
     def finish():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        for k in range(n_ctx):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
 
     for i in range(args.warmup):
         step(i)

@@ -435,3 +435,22 @@ def test_render_many_is_bit_identical_to_sequential_renders(dev):
     imgs_b, grads_b = run(True)
     for x, y in zip(imgs_a + grads_a, imgs_b + grads_b):
         assert torch.equal(x, y)
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py's N > 1 path (view sharding, double-buffered flat gradients, async all-reduce around hipGraph replays,
+    max-over-ranks timing) with two ranks sharing this GPU over gloo -- RCCL itself refuses duplicate devices, and a
+    1-GPU box is all the tests get."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXA_BENCH_BACKEND='gloo', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29541', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+           '--config', 'c2', '--no-kernel-timing', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 2 and res['steps'] == 6 and res['value'] > 0 and res['scaling'] == 'weak'
