@@ -8,7 +8,8 @@ Public surface (drop-in for ``diff_gaussian_rasterization_depth`` as used at ref
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, check_overflow, config,
                          rasterize_gaussians)
 from .densify import track_densify_stats
+from .losses import SSIM, RGBLoss
 from .renderer import GaussianRenderer, render_many
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
-           'config', 'check_overflow', 'track_densify_stats', 'render_many']
+           'config', 'check_overflow', 'track_densify_stats', 'render_many', 'SSIM', 'RGBLoss']

@@ -60,6 +60,8 @@ SIGNATURES = {
                             + [c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),
+    'exa_ssim_backward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 8),
     'exa_raster_timing_enable': (ctypes.c_int, [_I32]),
     'exa_raster_timing_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _I32]),
     'exa_raster_timing_name': (ctypes.c_char_p, [_I32]),

@@ -26,6 +26,7 @@ SOURCES = {
     'render_fwd.hip': [],
     'render_bwd.hip': [],
     'preprocess_bwd.hip': [],
+    'ssim.hip': [],
     'api.hip': [],
 }
 

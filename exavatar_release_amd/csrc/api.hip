@@ -241,6 +241,28 @@ int exa_raster_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t*
     return 0;
 }
 
+int exa_ssim_forward(int32_t N, int32_t H, int32_t W, const float* img1, const float* img2, float* ssim_map,
+                     float* dm_dmu1, float* dm_dE11, float* dm_dE12, void* stream) {
+    if (N < 0 || H < 0 || W < 0) return fail(EXA_RASTER_E_INVALID, "negative size");
+    if ((int64_t)N * H * W > 0 && (!img1 || !img2 || !ssim_map)) return fail(EXA_RASTER_E_NULLPTR, "img / map is NULL");
+    if ((dm_dmu1 != nullptr) != (dm_dE11 != nullptr) || (dm_dmu1 != nullptr) != (dm_dE12 != nullptr))
+        return fail(EXA_RASTER_E_INVALID, "pass all three derivative maps or none");
+    EXA_HIP(launch_ssim_fwd(N, H, W, img1, img2, ssim_map, dm_dmu1, dm_dE11, dm_dE12, static_cast<hipStream_t>(stream)),
+            "ssim_fwd");
+    return 0;
+}
+
+int exa_ssim_backward(int32_t N, int32_t H, int32_t W, const float* img1, const float* img2, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dE11, const float* dm_dE12, float* dL_dimg1,
+                      void* stream) {
+    if (N < 0 || H < 0 || W < 0) return fail(EXA_RASTER_E_INVALID, "negative size");
+    if ((int64_t)N * H * W > 0 && (!img1 || !img2 || !dL_dmap || !dm_dmu1 || !dm_dE11 || !dm_dE12 || !dL_dimg1))
+        return fail(EXA_RASTER_E_NULLPTR, "ssim backward: NULL argument");
+    EXA_HIP(launch_ssim_bwd(N, H, W, img1, img2, dL_dmap, dm_dmu1, dm_dE11, dm_dE12, dL_dimg1,
+                            static_cast<hipStream_t>(stream)), "ssim_bwd");
+    return 0;
+}
+
 int exa_raster_timing_enable(int32_t on) {
     if (on && !g_t.created) {
         for (int i = 0; i < K_COUNT; ++i)

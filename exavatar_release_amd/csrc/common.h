@@ -252,6 +252,11 @@ struct PreprocessBwdArgs {
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
 };
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+hipError_t launch_ssim_fwd(int N, int H, int W, const float* img1, const float* img2, float* map, float* dm_dmu1,
+                           float* dm_dE11, float* dm_dE12, hipStream_t s);
+hipError_t launch_ssim_bwd(int N, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
+                           const float* dm_dmu1, const float* dm_dE11, const float* dm_dE12, float* dL_dimg1,
+                           hipStream_t s);
 hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, float* accum, float* cnt, float* rmax,
                                 hipStream_t s);
 

@@ -166,6 +166,21 @@ int exa_raster_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t*
                              float* xyz_grad_accum, float* track_cnt, float* radius_max, void* stream);
 
 /*
+ * Fused SSIM map (the image-loss gradient producer in front of the rasterizer's backward).
+ * Replaces class SSIM of reference avatar/common/nets/loss.py:31-74 -- five grouped 11x11 conv2d (Gaussian window,
+ * sigma 1.5, zero padding 5) + elementwise ops + their autograd graph -- for N = batch * channels planes of H x W
+ * floats.  forward writes ssim_map and, when the three dm_* pointers are non-NULL, the partial derivatives of
+ * the map w.r.t. (mu1, E[x^2], E[x y]) that backward consumes; backward writes dL/d(img1) (the rendered image;
+ * the target gets no gradient).  The mask / bbox options of the reference are plain tensor ops in the Python mirror
+ * (exavatar_release_amd/losses.py).
+ */
+int exa_ssim_forward(int32_t N, int32_t H, int32_t W, const float* img1, const float* img2, float* ssim_map,
+                     float* dm_dmu1, float* dm_dE11, float* dm_dE12, void* stream);
+int exa_ssim_backward(int32_t N, int32_t H, int32_t W, const float* img1, const float* img2, const float* dL_dmap,
+                      const float* dm_dmu1, const float* dm_dE11, const float* dm_dE12, float* dL_dimg1,
+                      void* stream);
+
+/*
  * Optional per-kernel timing for benchmarks (the only state the library ever keeps, process-wide,
  * off by default, not thread-safe).  While enabled, every kernel / memset the library enqueues is bracketed by a
  * pair of hipEvents recorded on the caller's stream.  exa_raster_timing_read() synchronises on the

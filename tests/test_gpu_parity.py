@@ -454,3 +454,47 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
     res = json.loads(line)
     assert res['n_gpus'] == 2 and res['steps'] == 6 and res['value'] > 0 and res['scaling'] == 'weak'
+
+
+SSIM_MAP_TOL = 1e-5          # |ssim| <= 1; separable fp32 filtering vs the reference's 2-D conv2d
+SSIM_GRAD_TOL = 2e-4         # relative to max |grad|
+
+
+def test_fused_ssim_and_rgb_loss_match_reference_golden(dev, golden_dir):
+    """SURVEY 8f-4, PINNED parity: the fused SSIM kernels and the RGBLoss mirror against outputs and autograd gradients
+    of the reference's own class source (tests/golden/ref_ssim.npz), incl. the mask and (clamped) bbox options."""
+    z = np.load(os.path.join(golden_dir, 'ref_ssim.npz'))
+    t = lambda k: torch.tensor(z[k]).to(dev)
+    x, y, mask, bbox, bg, G = t('x'), t('y'), t('mask'), torch.tensor(z['bbox']), t('bg'), t('G')
+    ssim, rgb = exa.SSIM(), exa.RGBLoss()
+    for name, kw in (('plain', {}), ('mask', {'mask': mask}), ('bbox', {'bbox': bbox})):
+        xi = x.clone().requires_grad_(True)
+        m = ssim(xi, y, **kw)
+        (m * G[:, :, :m.shape[2], :m.shape[3]]).sum().backward()
+        ref_m, ref_g = t('ssim_' + name), t('ssim_' + name + '_grad')
+        assert float((m.detach() - ref_m).abs().max()) <= SSIM_MAP_TOL, name
+        assert float((xi.grad - ref_g).abs().max()) <= SSIM_GRAD_TOL * float(ref_g.abs().max()), name
+    for name, kw in (('plain', {}), ('bbox', {'bbox': bbox}), ('maskbg', {'mask': mask, 'bg': bg})):
+        xi = x.clone().requires_grad_(True)
+        m = rgb(xi, y, **kw)
+        (m * G[:, :, :m.shape[2], :m.shape[3]]).sum().backward()
+        assert torch.allclose(m.detach(), t('rgb_' + name), rtol=0, atol=1e-7)
+        assert torch.equal(xi.grad, t('rgb_' + name + '_grad'))
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 256, 256), (2, 3, 61, 130), (1, 1, 7, 5)])
+def test_fused_ssim_matches_oracle_at_other_sizes(dev, shape):
+    """Ragged sizes (tiles cut by the border, images smaller than the 11-tap window) against the pinned oracle."""
+    from oracle import loss_oracle as lo
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.rand(*shape, generator=g)
+    y = (x + 0.1 * torch.randn(*shape, generator=g)).clamp(0, 1)
+    G = torch.randn(*shape, generator=g)
+    xc = x.clone().requires_grad_(True)
+    mc = lo.ssim_map(xc, y)
+    (mc * G).sum().backward()
+    xg = x.to(dev).requires_grad_(True)
+    mg = exa.SSIM()(xg, y.to(dev))
+    (mg * G.to(dev)).sum().backward()
+    assert float((mg.detach().cpu() - mc.detach()).abs().max()) <= SSIM_MAP_TOL
+    assert float((xg.grad.cpu() - xc.grad).abs().max()) <= SSIM_GRAD_TOL * float(xc.grad.abs().max())

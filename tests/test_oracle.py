@@ -298,3 +298,26 @@ def test_densify_stats_reference_semantics():
     assert acc.flatten().tolist() == [6.0, 1.0, 3.0]          # + ||(3,4)|| = 5, untouched, + ||(0,2)|| = 2
     assert cnt.flatten().tolist() == [1.0, 0.0, 1.0]
     assert rmax.tolist() == [9.0, 1.0, 2.0]
+
+
+def test_loss_oracle_matches_reference_class_outputs(golden_dir):
+    """PINNED: oracle/loss_oracle.py against tests/golden/ref_ssim.npz, which was produced by executing the reference's
+    own RGBLoss / SSIM class source (tests/golden/make_golden_ssim.py)."""
+    import os
+    import numpy as np
+    from oracle import loss_oracle as lo
+    z = np.load(os.path.join(golden_dir, 'ref_ssim.npz'))
+    x, y = torch.tensor(z['x']), torch.tensor(z['y'])
+    mask, bbox, bg, G = torch.tensor(z['mask']), torch.tensor(z['bbox']), torch.tensor(z['bg']), torch.tensor(z['G'])
+    for name, kw in (('plain', {}), ('mask', {'mask': mask}), ('bbox', {'bbox': bbox})):
+        xi = x.clone().requires_grad_(True)
+        m = lo.ssim_map(xi, y, **kw)
+        (m * G[:, :, :m.shape[2], :m.shape[3]]).sum().backward()
+        assert torch.allclose(m.detach(), torch.tensor(z['ssim_' + name]), rtol=0, atol=1e-6)
+        assert torch.allclose(xi.grad, torch.tensor(z['ssim_' + name + '_grad']), rtol=1e-5, atol=1e-6)
+    for name, kw in (('plain', {}), ('bbox', {'bbox': bbox}), ('maskbg', {'mask': mask, 'bg': bg})):
+        xi = x.clone().requires_grad_(True)
+        m = lo.rgb_loss(xi, y, **kw)
+        (m * G[:, :, :m.shape[2], :m.shape[3]]).sum().backward()
+        assert torch.equal(m.detach(), torch.tensor(z['rgb_' + name]))
+        assert torch.equal(xi.grad, torch.tensor(z['rgb_' + name + '_grad']))
