@@ -42,62 +42,66 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
     const float* __restrict__ p = a.projmatrix;
     const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
 
-    // ---- gather this Gaussian's instances (contiguous, Gaussian-major, written exactly once each) -------------
-    // A typical avatar splat has ~6 instances and fetches them itself, four per trip (12 independent 16-byte
-    // loads in flight).  Large splats (scene Gaussians: hundreds to > 1000 sub-tiles) would turn that into a
-    // serial tail of hundreds of trips in ONE lane, so from COOP_MIN instances on the whole wave fetches the
-    // Gaussian's partials together -- lane l takes instances l, l + 64, ... (contiguous 48-byte records:
-    // coalesced) -- and the ten sums are reduced across the wave (c5: 286 -> see profiles/).
-    constexpr uint32_t COOP_MIN = 24;
-    float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
-    const uint32_t n_inst = vis ? r3.z : 0u;
-    if (n_inst > 0 && n_inst < COOP_MIN) {
-        const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)r3.w * 3;
-        for (uint32_t i = 0; i < n_inst; i += 4) {
-            float4 q[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = i + u < n_inst;
-                const float4* src = pp + (size_t)(ok ? i + u : i) * 3;
-                q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2];
-                if (!ok) { q[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); q[u][1] = q[u][0]; q[u][2] = q[u][0]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                mx += q[u][0].x; my += q[u][0].y; mxx += q[u][0].z; mxy += q[u][0].w;
-                myy += q[u][1].x; dop += q[u][1].y; dcol[0] += q[u][1].z; dcol[1] += q[u][1].w;
-                dcol[2] += q[u][2].x; dz_view += q[u][2].y;
-            }
-        }
-    }
+    // Large splats (scene Gaussians: hundreds to > 1000 sub-tiles) would turn the per-lane gather below into a
+    // serial tail of hundreds of trips in ONE lane: from COOP_MIN instances on, the whole wave fetches that
+    // Gaussian's partials together -- lane l takes instances l, l + 64, ... (contiguous 48-byte records: coalesced)
+    // -- and the ten sums are reduced across the wave (c5: 286 -> 148 us; no such splat exists in C3).
+    constexpr uint32_t COOP_MIN = 64;
+    float co[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {
-        const int lane = threadIdx.x & 63;
-        unsigned long long heavy = __ballot(n_inst >= COOP_MIN);
-        while (heavy) {                                             // wave-uniform loop
-            const int L = __ffsll((long long)heavy) - 1;
-            heavy &= heavy - 1ull;
-            const uint32_t off = (uint32_t)__shfl((int)r3.w, L, 64), nn = (uint32_t)__shfl((int)n_inst, L, 64);
-            const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)off * 3;
-            float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
-                const float4 q0 = pp[(size_t)j * 3], q1 = pp[(size_t)j * 3 + 1], q2 = pp[(size_t)j * 3 + 2];
-                acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
-                acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
-                acc[8] += q2.x; acc[9] += q2.y;
-            }
+        unsigned long long heavy = __ballot(vis && r3.z >= COOP_MIN);
+        if (__builtin_expect(heavy != 0ull, 0)) {
+            const int lane = threadIdx.x & 63;
+            while (heavy) {                                         // wave-uniform loop
+                const int L = __ffsll((long long)heavy) - 1;
+                heavy &= heavy - 1ull;
+                const uint32_t off = (uint32_t)__shfl((int)r3.w, L, 64), nn = (uint32_t)__shfl((int)r3.z, L, 64);
+                const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)off * 3;
+                float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
+                    const float4 q0 = pp[(size_t)j * 3], q1 = pp[(size_t)j * 3 + 1], q2 = pp[(size_t)j * 3 + 2];
+                    acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
+                    acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
+                    acc[8] += q2.x; acc[9] += q2.y;
+                }
 #pragma unroll
-            for (int k = 0; k < 10; ++k) {
+                for (int k = 0; k < 10; ++k) {
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) acc[k] += __shfl_xor(acc[k], d, 64);
-            }
-            if (lane == L) {
-                mx += acc[0]; my += acc[1]; mxx += acc[2]; mxy += acc[3]; myy += acc[4];
-                dop += acc[5]; dcol[0] += acc[6]; dcol[1] += acc[7]; dcol[2] += acc[8]; dz_view += acc[9];
+                    for (int d = 32; d > 0; d >>= 1) acc[k] += __shfl_xor(acc[k], d, 64);
+                    if (lane == L) co[k] = acc[k];
+                }
             }
         }
     }
 
     if (vis) {
+        // ---- gather this Gaussian's instances (contiguous, written exactly once each) -----------------
+        float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
+        {
+            const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)r3.w * 3;
+            // four instances per trip: 12 independent 16-byte loads in flight (a typical avatar splat has ~6)
+            const uint32_t n_own = r3.z < COOP_MIN ? r3.z : 0u;     // larger ones were fetched by the whole wave above
+            for (uint32_t i = 0; i < n_own; i += 4) {
+                float4 q[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = i + u < n_own;
+                    const float4* src = pp + (size_t)(ok ? i + u : i) * 3;
+                    q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2];
+                    if (!ok) { q[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); q[u][1] = q[u][0]; q[u][2] = q[u][0]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    mx += q[u][0].x; my += q[u][0].y; mxx += q[u][0].z; mxy += q[u][0].w;
+                    myy += q[u][1].x; dop += q[u][1].y; dcol[0] += q[u][1].z; dcol[1] += q[u][1].w;
+                    dcol[2] += q[u][2].x; dz_view += q[u][2].y;
+                }
+            }
+        }
+
+        mx += co[0]; my += co[1]; mxx += co[2]; mxy += co[3]; myy += co[4];
+        dop += co[5]; dcol[0] += co[6]; dcol[1] += co[7]; dcol[2] += co[8]; dz_view += co[9];
+
         // ---- recompute the forward quantities ---------------------------------------------------
         const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
         const float pvy = ((v[1] * x + v[5] * y) + v[9] * z) + v[13];
