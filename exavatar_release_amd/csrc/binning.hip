@@ -90,41 +90,85 @@ __global__ __launch_bounds__(SCAN_THREADS) void col_scan_kernel(TileWs w, int ce
 
 // One workgroup: exclusive prefix of the per-cell (entries, instances) totals and of the per-chunk instance
 // counts, the header, the LPT order of the cells.
+__device__ __forceinline__ unsigned long long wave_incl_scan64(unsigned long long v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long n = __shfl_up(v, d, 64);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+// exclusive scan of two 32-bit counters packed in one u64 (no carry between the halves: both sums stay < 2^32)
+__device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long long v, unsigned long long* s_tmp,
+                                                                unsigned long long& total) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const unsigned long long incl = wave_incl_scan64(v);
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+    for (int i = 0; i < nw; ++i) {
+        const unsigned long long ws = s_tmp[i];
+        if (i < wave) base += ws;
+        tot += ws;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int cells, int chunks) {
-    __shared__ uint32_t s_tmp[SCAN_THREADS / 64];
+    __shared__ unsigned long long s_tmp[SCAN_THREADS / 64];
     const int tid = threadIdx.x;
-    uint32_t carry_e = 0, carry_i = 0, true_inst = 0;
+    // every global input of the first trip is requested up front: the kernel is one workgroup of pure latency
+    const unsigned long long v0 = tid < cells ? w.cell_cnt[tid] : 0ull;
+    const uint32_t ci0 = tid < chunks ? w.chunk_inst[tid] : 0u, cv0 = tid < chunks ? w.chunk_vis[tid] : 0u;
+    unsigned long long carry = 0ull;                            // slots * 64 << 32 | entries
+    uint32_t true_inst = 0;
     for (int base = 0; base < cells; base += SCAN_THREADS) {
         const int c = base + tid;
-        const unsigned long long v = c < cells ? w.cell_cnt[c] : 0ull;
+        const unsigned long long v = base == 0 ? v0 : (c < cells ? w.cell_cnt[c] : 0ull);
         true_inst += (uint32_t)(v >> 32);
-        const uint32_t e = (uint32_t)v, n = cell_slots((uint32_t)(v >> 32)) * BATCH;   // instance space in 64-slots
-        uint32_t te, ti;
-        const uint32_t xe = block_excl_scan(e, s_tmp, te);
-        const uint32_t xi = block_excl_scan(n, s_tmp, ti);
-        if (c < cells) w.cell_off[c] = make_uint2(carry_e + xe, carry_i + xi);
-        carry_e += te;
-        carry_i += ti;
+        const unsigned long long packed =
+            ((unsigned long long)(cell_slots((uint32_t)(v >> 32)) * BATCH) << 32) | (uint32_t)v;   // instance space in 64-slots
+        unsigned long long tot;
+        const unsigned long long x = carry + block_excl_scan64(packed, s_tmp, tot);
+        if (c < cells) w.cell_off[c] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
+        carry += tot;
     }
-    {
-        uint32_t tot;
-        block_excl_scan(true_inst, s_tmp, tot);
-        if (tid == 0) w.header->num_instances = tot;
+    // prefix of the per-chunk instance counts; totals of true instances and visible Gaussians ride along
+    unsigned long long ccarry = 0ull, totals = 0ull;
+    uint32_t vis = 0;
+    for (int base = 0; base < chunks || base == 0; base += SCAN_THREADS) {
+        const int c = base + tid;
+        const uint32_t v = base == 0 ? ci0 : (c < chunks ? w.chunk_inst[c] : 0u);
+        vis += base == 0 ? cv0 : (c < chunks ? w.chunk_vis[c] : 0u);
+        const bool last = base + SCAN_THREADS >= chunks;
+        // high word: on the last trip the per-thread (true_inst, vis) partial sums are folded in as a second scan
+        unsigned long long tot;
+        const unsigned long long x = block_excl_scan64((unsigned long long)v | ((unsigned long long)(last ? vis : 0u) << 32), s_tmp, tot);
+        if (c < chunks) w.chunk_off[c] = (uint32_t)ccarry + (uint32_t)x;
+        ccarry += tot & 0xffffffffull;
+        if (last) totals = tot >> 32;
     }
+    unsigned long long ti_tot;
+    block_excl_scan64((unsigned long long)true_inst, s_tmp, ti_tot);
     if (tid == 0) {
-        w.cell_off[cells] = make_uint2(carry_e, carry_i);
-        w.header->num_rendered = carry_i;
+        w.cell_off[cells] = make_uint2((uint32_t)carry, (uint32_t)(carry >> 32));
+        w.header->num_rendered = (uint32_t)(carry >> 32);
         w.header->overflow = 0u;
-        w.header->max_tile_list = carry_e;     // reused slot: number of (Gaussian, cell) entries
+        w.header->max_tile_list = (uint32_t)carry;     // reused slot: number of (Gaussian, cell) entries
+        w.header->num_visible = (uint32_t)totals;
+        w.header->num_instances = (uint32_t)ti_tot;
     }
     if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
-    // Launch order of the per-pixel kernels: cells bucketed by floor(log2(instances)) (33 buckets),
-    // heaviest bucket first, so the longest lists start early and the tail of the launch is light.
+    // Launch order of the per-cell kernels: cells bucketed by floor(log2(instances)) (33 buckets),
+    // heaviest bucket first, so the heaviest cells start early and the tail of the launch is light.
     __shared__ uint32_t s_bucket[34];
     if (tid < 34) s_bucket[tid] = 0u;
     __syncthreads();
     for (int c = tid; c < cells; c += SCAN_THREADS) {
-        const uint32_t n = (uint32_t)(w.cell_cnt[c] >> 32);
+        const uint32_t n = (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32);
         atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u);       // bucket 0 = empty, 32 = largest
     }
     __syncthreads();
@@ -134,23 +178,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
     }
     __syncthreads();
     for (int c = tid; c < cells; c += SCAN_THREADS) {
-        const uint32_t n = (uint32_t)(w.cell_cnt[c] >> 32);
+        const uint32_t n = (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32);
         w.cell_order[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = (uint32_t)c;
-    }
-    uint32_t carry = 0, vis = 0;
-    for (int base = 0; base < chunks; base += SCAN_THREADS) {
-        const int c = base + tid;
-        const uint32_t v = c < chunks ? w.chunk_inst[c] : 0u;
-        vis += c < chunks ? w.chunk_vis[c] : 0u;
-        uint32_t t;
-        const uint32_t x = block_excl_scan(v, s_tmp, t);
-        if (c < chunks) w.chunk_off[c] = carry + x;
-        carry += t;
-    }
-    {
-        uint32_t tot;
-        block_excl_scan(vis, s_tmp, tot);
-        if (tid == 0) w.header->num_visible = tot;
     }
 }
 
