@@ -129,6 +129,20 @@ def last_header():
     return tuple(int(v) for v in _debug_last['tile'][:20].view(torch.int32).cpu())
 
 
+_size_cache = {}
+
+
+def _sizes(P, W, H, capacity):
+    """exa_raster_workspace_sizes, memoised (a ctypes round trip per call adds up in eager training loops)."""
+    key = (P, W, H, capacity)
+    sz = _size_cache.get(key)
+    if sz is None:
+        if len(_size_cache) > 256:
+            _size_cache.clear()
+        sz = _size_cache[key] = _lib.workspace_sizes(P, W, H, capacity)
+    return sz
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -156,11 +170,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             st = _make_settings(rs, device, keep)
             stream = _stream_ptr(device)
             u8 = dict(dtype=torch.uint8, device=device)
-            color = torch.empty((3, H, W), dtype=torch.float32, device=device)
-            depth = torch.empty((1, H, W), dtype=torch.float32, device=device)
-            alpha = torch.empty((1, H, W), dtype=torch.float32, device=device)
+            planes = torch.empty((5, H, W), dtype=torch.float32, device=device)      # one allocation, three views
+            color, depth, alpha = planes[0:3], planes[3:4], planes[4:5]
             radii = torch.empty((P,), dtype=torch.int32, device=device)
-            sz = _lib.workspace_sizes(P, W, H, 0)
+            sz = _sizes(P, W, H, 0)
             geom = torch.empty(int(sz.geom_bytes), **u8)
             tile = torch.empty(int(sz.tile_bytes), **u8)
             img = torch.empty(int(sz.img_bytes) if need_ctx else 0, **u8)
@@ -182,7 +195,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 hdr = tile[:16].view(torch.int32).cpu()          # D2H + sync, as upstream does
                 capacity = max(int(hdr[0]), 64)          # header reports whole 64-instance batch slots
                 _seen_D[key] = max(_seen_D.get(key, 0), int(hdr[0]))
-                bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
+                bins = torch.empty(int(_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward_render(ctypes.byref(st), P, _ptr(geom), _ptr(tile), _ptr(bins),
                                                          capacity, _ptr(img), _ptr(color), _ptr(depth), _ptr(alpha),
                                                          int(need_ctx), stream))
@@ -194,7 +207,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 else:
                     capacity = max(int(_seen_D[key] * config.capacity_growth), config.min_capacity)
                 capacity = (capacity + 63) // 64 * 64
-                bins = torch.empty(int(_lib.workspace_sizes(P, W, H, capacity).bin_bytes), **u8)
+                bins = torch.empty(int(_sizes(P, W, H, capacity).bin_bytes), **u8)
                 _lib.check(lib.exa_raster_forward(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
                                                   _ptr(tile), _ptr(bins), capacity, _ptr(img), _ptr(color),
                                                   _ptr(depth), _ptr(alpha), int(need_ctx), stream))
@@ -214,6 +227,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             ctx.sh_M = sh_M
             ctx.capacity = capacity
             ctx.keep = keep
+            ctx.settings_struct = st
             ctx.has = tuple(t is not None for t in (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
             empty = torch.empty(0, device=device)
             ctx.save_for_backward(means3D, sh if sh is not None else empty,
@@ -254,8 +268,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         g_alpha = grad_in(grad_alpha, (1, H, W))
 
         with torch.cuda.device(device):
-            keep = []
-            st = _make_settings(rs, device, keep)
+            st = ctx.settings_struct          # built in forward; the tensors it points to are kept alive by ctx.keep
+            # separate tensors on purpose: AccumulateGrad adopts a whole tensor as `.grad` without a copy, a view of a
+            # shared buffer would be cloned
             d_means3D = torch.empty((P, 3), **f32)
             d_means2D = torch.empty((P, 3), **f32)
             d_opac = torch.empty((P, 1), **f32)
@@ -264,7 +279,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             d_rot = torch.empty((P, 4), **f32) if has_rot else None
             d_sh = torch.empty((P, ctx.sh_M, 3), **f32) if has_sh else None
             d_cov = torch.empty((P, 6), **f32) if has_cov else None
-            sz = _lib.workspace_sizes(P, W, H, ctx.capacity)
+            sz = _sizes(P, W, H, ctx.capacity)
             grad_ws = torch.empty(int(sz.grad_bytes), dtype=torch.uint8, device=device)
             _lib.check(lib.exa_raster_backward(
                 ctypes.byref(st), P, ctx.sh_M,
