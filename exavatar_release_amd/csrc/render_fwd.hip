@@ -262,6 +262,9 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) 
         order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid);
         return;
     }
+#ifdef EXA_PROBE_SORT
+    const unsigned long long t0 = __builtin_readcyclecounter();
+#endif
     // heaviest cells first (cell_order), sub-tiles of a cell consecutive
     const int wg = (int)blockIdx.x - ORDER_WGS;
     const int st = (int)a.tw.cell_order[wg >> 6] * SUBS_PER_CELL + (wg & 63);
@@ -275,12 +278,16 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) 
     uint32_t* sorted = a.bw.sorted + range.x;
     if (n <= 64) {
         if (tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);
-    } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);
-    else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);
+    } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);      // (a plain O(n^2) rank sort of the whole
+    else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);        //  list was 40 % slower: LDS-pipe bound)
     else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
     else if (n <= 2048) lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
     else   // longer lists: 2048 own keys at a time against the whole list (any length)
         for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
+#ifdef EXA_PROBE_SORT
+    __syncthreads();
+    if (tid == 0) a.tw.part_cnt[st] = (uint32_t)(__builtin_readcyclecounter() - t0);      // probe build only
+#endif
 }
 
 // ---- blend ---------------------------------------------------------------------------------------------
