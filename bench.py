@@ -7,13 +7,18 @@ rasterize at 1024x1024 with ~150 k avatar-like Gaussians (config C3), view-shard
 
 One "step" = one `GaussianRasterizer` forward + its backward for one training view with a dense
 dL/dimage (inputs already resident in HBM), followed for N > 1 by the RCCL all-reduce of the
-Gaussian gradients (14 floats x P = 8.4 MB).  Views: the 200 ring cameras of config C4 dealt
-round-robin to the ranks; every rank cycles through its shard, so per-GPU work is fixed as N grows
-(weak scaling) and `value` = views rasterized fwd+bwd per second over all ranks.
+Gaussian gradients (14 floats x P = 8.4 MB) through the product's `dist.FlatGradAllReducer`.  Views: the 200
+ring cameras of config C4 dealt by the product's `dist.shard_views`; every rank cycles through its shard, so
+per-GPU work is fixed as N grows (weak scaling) and `value` = views rasterized fwd+bwd per second over all ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-`roofline` (dominant kernel, HIP-event timed inside this script) and `cpu_baseline` (the CPU oracle
-timed on a bounded sample of the same workload, rank 0 at N = 1 only).
+Other workloads: `--config c2|c1` (same step), `--config c5` = BASELINE configs[4]: 300 k Gaussians
+(200 k avatar + 100 k scene), in-kernel SH degree 3, 2048x2048, FORWARD ONLY under `torch.no_grad()` (no backward
+context stored), hipGraph-captured -- the animation / inference use case of avatar/main/animate.py:64-66.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: `roofline` (dominant kernel,
+HIP-event timed inside this script), `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
+workload, rank 0 at N = 1 only), `extra_batched_views` (K views per batched launch, next to -- never instead of --
+the single-view headline) and `extra_views_in_flight` (independent views on separate streams).
 """
 import argparse
 import json
@@ -27,6 +32,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_VIEWS = 200
+PROFILE_PREFIX = 'r02'          # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic
 
 
 def parse():
@@ -34,11 +40,15 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--config', default='c3', choices=['c3', 'c2', 'c1'])
+    ap.add_argument('--config', default='c3', choices=['c3', 'c2', 'c1', 'c5'])
+    ap.add_argument('--mode', default=None, choices=['train', 'forward'],
+                    help='train = forward + backward (default; c5 defaults to forward)')
     ap.add_argument('--launch', default='graph', choices=['graph', 'eager'])
     ap.add_argument('--streams', type=int, default=1,
                     help='independent views in flight per GPU (each on its own HIP stream + hipGraph); 1 = one '
                          'view at a time, the headline configuration')
+    ap.add_argument('--views-per-launch', type=int, default=1,
+                    help='K views of this rank\'s shard per batched launch (exa_raster_*_batch); 1 = the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-concurrent', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -51,11 +61,15 @@ def build_scene(name):
         return scenes.dist_b_avatar(150_000, seed=0), (1024, 1024), 'c3: 150k avatar-like Gaussians (Dist-B), 1024x1024'
     if name == 'c2':
         return scenes.dist_b_avatar(120_000, seed=0), (960, 540), 'c2: 120k avatar-like Gaussians (Dist-B), 540x960 (WxH)'
+    if name == 'c5':
+        a = scenes.make_config('c5')[0]
+        a['sh'] = scenes.sh_from_rgb(a['rgb'], 3, seed=5, rest_sigma=0.1)
+        return a, (2048, 2048), 'c5: 200k avatar-like + 100k scene Gaussians, SH degree 3 in-kernel, 2048x2048, forward only'
     return scenes.dist_a_random(10_000, 256, 256, seed=0), (256, 256), 'c1: 10k random Gaussians (Dist-A), 256x256'
 
 
-def view_settings(k, shape, device, cfg_name):
-    """GaussianRasterizationSettings of ring view k, built like GaussianRenderer.forward does."""
+def view_settings(k, shape, cfg_name):
+    """Raster matrices of ring view k, built like GaussianRenderer.forward does."""
     from exavatar_release_amd import scenes
     from exavatar_release_amd.camera import make_raster_matrices
     H, W = shape
@@ -93,32 +107,34 @@ def main():
 
     import exavatar_release_amd as exa
     from exavatar_release_amd import _lib
-    from exavatar_release_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians
+    from exavatar_release_amd import dist as exa_dist
+    from exavatar_release_amd.rasterizer import (GaussianRasterizationSettings, rasterize_gaussians,
+                                                 rasterize_gaussians_batch)
 
+    mode = args.mode or ('forward' if args.config == 'c5' else 'train')
+    train = mode == 'train'
     assets, shape, workload = build_scene(args.config)
     H, W = shape
     P = assets['mean_3d'].shape[0]
+    use_sh = 'sh' in assets
+    sh_degree = 3 if use_sh else 0
+    KV = max(1, args.views_per_launch)
+    S = max(1, args.streams)
+    if world > 1 and (S > 1 or KV > 1):
+        raise SystemExit('bench.py: --streams / --views-per-launch > 1 are only implemented for --gpus 1')
 
     # ---- parameters: contiguous leaves; for N > 1 their gradients are packed into ONE flat buffer ----
-    names = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
-    params = [assets[k].to(device).contiguous().requires_grad_(True) for k in names]
+    names = ('mean_3d', 'scale', 'rotation', 'opacity') + (('sh',) if use_sh else ('rgb',))
+    params = [assets[k].to(device).contiguous().requires_grad_(train) for k in names]
     n_float = sum(p.numel() for p in params)
-    offs, o = [], 0
-    for p_ in params:
-        offs.append((o, o + p_.numel()))
-        o += p_.numel()
-
-    def make_flat():
-        flat = torch.zeros(n_float, device=device)
-        return flat, [flat[a_:b_].view_as(p_) for (a_, b_), p_ in zip(offs, params)]
 
     g = torch.Generator().manual_seed(1)
     dL_dimg = torch.randn(3, H, W, generator=g).to(device)
     bg = torch.ones(3, device=device)
 
-    # ---- this rank's shard of the ring views ------------------------------------------------------
-    my_views = list(range(rank, N_VIEWS, world)) if args.config != 'c1' else [0]
-    vs = [view_settings(k, shape, device, args.config) for k in my_views]
+    # ---- this rank's shard of the ring views (the product's dealer; no shuffle so that runs are comparable) ----
+    my_views = exa_dist.shard_views(N_VIEWS, rank, world, shuffle=False) if args.config != 'c1' else [0]
+    vs = [view_settings(k, shape, args.config) for k in my_views]
     # one 48-float row per view: viewmatrix (16) | projmatrix (16) | campos (3) | pad -- a view switch is ONE copy
     cam_tab = torch.zeros(len(vs), 48)
     for j, v in enumerate(vs):
@@ -127,81 +143,93 @@ def main():
         cam_tab[j, 32:35] = v['campos'].reshape(-1).cpu()
     cam_tab = cam_tab.to(device)
 
-    def make_cam():
-        cam = cam_tab[0].clone()
-        return dict(cam=cam, view=cam[0:16].view(4, 4), proj=cam[16:32].view(4, 4), cpos=cam[32:35])
-    S = max(1, args.streams)
-    if world > 1 and S > 1:
-        raise SystemExit('bench.py: --streams > 1 is only implemented for --gpus 1')
-    # N > 1: two contexts on the SAME stream, each with its own flat gradient buffer, used alternately -- the
-    # all-reduce of step i reads buffer i % 2 while step i + 1 computes into the other one (a single buffer would
-    # be overwritten by the next step's backward while RCCL still reads it)
-    n_ctx = S if world == 1 else 2
-    ctxs = []
-    for _ in range(n_ctx):
-        c = make_cam()
-        c['flat'], c['grad_views'] = make_flat()
-        c['settings'] = GaussianRasterizationSettings(
+    def make_ctx(kv=1):
+        """One launch context: kv camera slots (static tensors the captured graph reads), settings, mean_2d probes."""
+        c = {'cam': cam_tab[:kv].clone()}
+        c['settings'] = [GaussianRasterizationSettings(
             image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'], bg=bg,
-            scale_modifier=1.0, viewmatrix=c['view'], projmatrix=c['proj'], sh_degree=0, campos=c['cpos'],
-            prefiltered=False, debug=False)
-        c['mean_2d'] = torch.zeros(P, 3, device=device, requires_grad=True)
-        c['stream'] = torch.cuda.Stream() if S > 1 else None
+            scale_modifier=1.0, viewmatrix=c['cam'][i, 0:16].view(4, 4), projmatrix=c['cam'][i, 16:32].view(4, 4),
+            sh_degree=sh_degree, campos=c['cam'][i, 32:35], prefiltered=False, debug=False) for i in range(kv)]
+        c['mean_2d'] = [torch.zeros(P, 3, device=device, requires_grad=train) for _ in range(kv)]
+        c['stream'] = None
         c['graph'] = None
-        ctxs.append(c)
-    settings = ctxs[0]['settings']
-    mean_2d = ctxs[0]['mean_2d']
+        c['kv'] = kv
+        return c
 
-    def set_view(i, c=None):
-        c = c or ctxs[0]
-        c['cam'].copy_(cam_tab[i])
+    # N > 1: gradients go through the product's double-buffered flat all-reducer: two launch contexts on the SAME
+    # stream, context i packs into buffer i (captured in its graph), the all-reduce of step i overlaps step i + 1
+    n_ctx = S if world == 1 else 2
+    reducer = exa_dist.FlatGradAllReducer(params, average=False, n_buffers=2) if world > 1 else None
+    ctxs = [make_ctx(KV) for _ in range(n_ctx)]
+    for c in ctxs:
+        if S > 1:
+            c['stream'] = torch.cuda.Stream()
 
-    def raster_step(c=None):
-        """forward + backward of the rasterizer; for N > 1 the gradients are packed for the all-reduce."""
-        c = c or ctxs[0]
-        settings, mean_2d = c['settings'], c['mean_2d']
-        m3, sc, rot, op, rgb = params
-        color, radii, depth, alpha = rasterize_gaussians(m3, mean_2d, None, rgb, op, sc, rot, None, settings)
-        grads = torch.autograd.grad([color], params + [mean_2d], grad_outputs=[dL_dimg])
-        if world > 1:
-            # pack for the all-reduce with elementwise kernels (copy_ would become hipMemcpyAsync graph nodes,
-            # which break stream capture in the ROCm runtime bundled with torch 2.10)
-            for v_, g_ in zip(c['grad_views'], grads[:5]):
-                torch.add(g_, 0.0, out=v_)
-        return None
+    def set_view(i, c):
+        """Point context c at views i .. i + kv - 1 of this rank's shard (ONE gather-copy kernel)."""
+        if c['kv'] == 1:
+            c['cam'].copy_(cam_tab[i % len(my_views)].view(1, 48))
+        else:
+            idx = torch.arange(i * c['kv'], (i + 1) * c['kv'], device=device) % len(my_views)
+            torch.index_select(cam_tab, 0, idx, out=c['cam'])
 
-    # ---- calibrate the instance-buffer capacity over this rank's views (exact mode, untimed) -------
-    probe = range(len(my_views))        # every view of the shard: the capacity below provably covers them
-    # read D and V for every probed view through the C ABI header of a fresh forward_bin
-    D_list, V_list, I_list = [], [], []
+    def raster_step(c, buf=None):
+        """forward (+ backward) of the rasterizer for the kv views of context c; N > 1: gradients packed into `buf`."""
+        m3, sc, rot, op, col = params
+        kw = dict(shs=col, colors_precomp=None) if use_sh else dict(shs=None, colors_precomp=col)
+        if c['kv'] == 1:
+            if train:
+                color, radii, depth, alpha = rasterize_gaussians(m3, c['mean_2d'][0], kw['shs'], kw['colors_precomp'], op, sc,
+                                                                 rot, None, c['settings'][0])
+                grads = torch.autograd.grad([color], params + c['mean_2d'], grad_outputs=[dL_dimg])
+                if reducer is not None:
+                    reducer.pack(grads[:5], buf)          # elementwise kernels: capturable in the hipGraph
+            else:
+                with torch.no_grad():
+                    rasterize_gaussians(m3, c['mean_2d'][0], kw['shs'], kw['colors_precomp'], op, sc, rot, None,
+                                        c['settings'][0])
+            return
+        jobs = [dict(means3D=m3, means2D=c['mean_2d'][i], opacities=op, scales=sc, rotations=rot, cov3D_precomp=None,
+                     raster_settings=c['settings'][i], **kw) for i in range(c['kv'])]
+        if train:
+            outs = rasterize_gaussians_batch(jobs)
+            torch.autograd.grad([o[0] for o in outs], params + c['mean_2d'], grad_outputs=[dL_dimg] * c['kv'])
+        else:
+            with torch.no_grad():
+                rasterize_gaussians_batch(jobs)
+
+    # ---- calibrate the instance-buffer capacity over this rank's views (stage 1 through the C ABI, untimed) -------
     import ctypes
     lib = _lib.load()
-    from exavatar_release_amd.rasterizer import _make_settings, _ptr, _stream_ptr
+    from exavatar_release_amd.rasterizer import _make_settings, _ptr, _stream_ptr, read_header
     sz = _lib.workspace_sizes(P, W, H, 0)
     geom = torch.empty(int(sz.geom_bytes), dtype=torch.uint8, device=device)
     tile = torch.empty(int(sz.tile_bytes), dtype=torch.uint8, device=device)
     radii = torch.empty(P, dtype=torch.int32, device=device)
-    for i in probe:
-        set_view(i)
+    D_list, V_list, I_list = [], [], []
+    c0 = ctxs[0]
+    for i in range(len(my_views)):        # every view of the shard: the capacity below provably covers them
+        c0['cam'][0].copy_(cam_tab[i])
         keep = []
-        st = _make_settings(settings, device, keep)
-        m3, sc, rot, op, rgb = [t.detach() for t in params]
-        _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, 0, _ptr(m3), None, _ptr(rgb), _ptr(op), _ptr(sc),
-                                              _ptr(rot), None, _ptr(radii), _ptr(geom), _ptr(tile), _stream_ptr(device)))
-        hdr = tile[:20].view(torch.int32).cpu()
-        D_list.append(int(hdr[0]))        # capacity this view needs (64 * batch slots)
-        V_list.append(int(hdr[3]))
-        I_list.append(int(hdr[4]))        # sub-tile instances actually emitted
+        st = _make_settings(c0['settings'][0], device, keep)
+        m3, sc, rot, op, col = [t.detach() for t in params]
+        _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, 16 if use_sh else 0, _ptr(m3), _ptr(col) if use_sh else None,
+                                              None if use_sh else _ptr(col), _ptr(op), _ptr(sc), _ptr(rot), None, _ptr(radii),
+                                              _ptr(geom), _ptr(tile), _stream_ptr(device)))
+        hdr = read_header(tile)
+        D_list.append(hdr[0])        # capacity this view needs (64 * batch slots)
+        V_list.append(hdr[3])
+        I_list.append(hdr[4])        # sub-tile instances actually emitted
+    del geom, tile
     D_max, D_mean, V_mean = max(D_list), sum(I_list) / len(I_list), sum(V_list) / len(V_list)
     exa.config.mode = 'capacity'
     exa.config.fixed_capacity = int(D_max) + 64      # every view of the shard was probed: D_max is exact (overflow is checked)
 
     # ---- optional hipGraph capture of the raster step --------------------------------------------------
     launch = args.launch
-    graph = None
-    set_view(0)
+    set_view(0, c0)
     for _ in range(3):
-        raster_step()
+        raster_step(c0, 0)
     torch.cuda.synchronize()
     exa.check_overflow()
     if launch == 'graph':
@@ -210,51 +238,46 @@ def main():
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    raster_step()
+                    raster_step(c0, 0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             exa.check_overflow()
-            for c in ctxs:
+            for b, c in enumerate(ctxs):
                 c['graph'] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(c['graph']):
-                    raster_step(c)
+                    raster_step(c, b)
                 c['graph'].replay()
                 torch.cuda.synchronize()
-            graph = ctxs[0]['graph']
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so in the result
             print('bench.py: hipGraph capture failed (%s); using eager launches' % e, file=sys.stderr)
-            graph = None
+            for c in ctxs:
+                c['graph'] = None
             launch = 'eager'
-
-    pending = [None] * n_ctx
 
     def step(i):
         k = i % n_ctx
         c = ctxs[k]
         if c['stream'] is not None:
             with torch.cuda.stream(c['stream']):
-                set_view(i % len(my_views), c)
+                set_view(i, c)
                 if c['graph'] is not None:
                     c['graph'].replay()
                 else:
                     raster_step(c)
             return
-        if pending[k] is not None:          # the all-reduce that last read this context's buffer (two steps ago)
-            pending[k].wait()
-            pending[k] = None
-        set_view(i % len(my_views), c)
+        if reducer is not None:
+            reducer.wait(k)                 # the all-reduce that last read this context's buffer (two steps ago)
+        set_view(i, c)
         if c['graph'] is not None:
             c['graph'].replay()
         else:
-            raster_step(c)
-        if world > 1:
-            pending[k] = dist.all_reduce(c['flat'], op=dist.ReduceOp.SUM, async_op=True)
+            raster_step(c, k)
+        if reducer is not None:
+            reducer.reduce(k)
 
     def finish():
-        for k in range(n_ctx):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        if reducer is not None:
+            reducer.finish()
 
     for i in range(args.warmup):
         step(i)
@@ -279,37 +302,44 @@ def main():
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
+        value = world * args.steps * KV / elapsed
+        metric = 'train iters/sec (fwd+bwd raster) at 1024x1024 / ~150k Gaussians' if args.config != 'c5' or train else \
+            'forward renders/sec at 2048x2048 / 300k Gaussians, SH deg 3 (BASELINE configs[4])'
         result = {
-            'metric': 'train iters/sec (fwd+bwd raster) at 1024x1024 / ~150k Gaussians',
+            'metric': metric,
             'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': workload + ', %d ring views sharded round-robin' % N_VIEWS,
-                       'P': P, 'W': W, 'H': H, 'views_per_rank': len(my_views), 'launch': launch,
-                       'views_in_flight_per_gpu': S,
-                       'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads' % (world, n_float * 4),
+            'config': {'workload': workload + ', %d ring views dealt by dist.shard_views' % N_VIEWS,
+                       'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
+                       'views_per_rank': len(my_views), 'launch': launch,
+                       'views_in_flight_per_gpu': S, 'views_per_launch': KV,
+                       'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads (dist.FlatGradAllReducer)'
+                                      % (world, n_float * 4),
                        'mean_instances_D': D_mean, 'mean_visible_V': V_mean},
         }
 
-    # ---- extra (not the headline): throughput with several independent views in flight on this GPU -------
-    if rank == 0 and world == 1 and S == 1 and graph is not None and not args.no_concurrent:
-        try:
-            result['extra_views_in_flight'] = concurrent_throughput(
-                4, args, params, P, H, W, bg, vs, cam_tab, make_cam, dL_dimg, rasterize_gaussians,
-                GaussianRasterizationSettings, device)
-        except Exception as e:  # noqa: BLE001
-            result['extra_views_in_flight'] = {'error': str(e)[:200]}
+    single = S == 1 and KV == 1 and world == 1
+    # ---- extras (not the headline): K views per batched launch; independent views on separate streams -------
+    if rank == 0 and single and launch == 'graph' and not args.no_concurrent and args.config != 'c1':
+        for name, fn in (('extra_batched_views', lambda: batched_throughput(8, args, make_ctx, set_view, raster_step)),
+                         ('extra_views_in_flight', lambda: concurrent_throughput(4, args, make_ctx, set_view, raster_step))):
+            try:
+                result[name] = fn()
+            except Exception as e:  # noqa: BLE001
+                result[name] = {'error': str(e)[:200]}
+        exa.check_overflow()
 
     # ---- per-kernel HIP-event timing (eager, on torch's stream = the stream the kernels run on) -----
     if rank == 0 and not args.no_kernel_timing:
+        c1 = make_ctx(1)
         _lib.timing_enable(True)
         acc = {}
         reps = 0
         n_t = min(len(my_views), 20)
         for i in range(n_t + 2):
-            set_view(i % len(my_views))
-            raster_step()
+            set_view(i, c1)
+            raster_step(c1, 0)
             torch.cuda.synchronize()
             tm = _lib.timing_read()
             if i >= 2:
@@ -319,8 +349,9 @@ def main():
         _lib.timing_enable(False)
         avg_us = {k: v / reps * 1e3 for k, v in acc.items()}
         V, D, WH = V_mean, D_mean, W * H
-        alg = {   # algorithmic bytes per launch (DESIGN.md section "Kernels"; SURVEY.md 8(d) per-unit figures)
-            'preprocess_fwd': 60 * P + 64 * V,
+        sh_bytes = 12 * 16 * P if use_sh else 0
+        alg = {   # algorithmic bytes per launch (SURVEY.md 8(d) per-unit figures)
+            'preprocess_fwd': 60 * P + 64 * V + sh_bytes,
             'cell_scatter': 16 * V + 4 * V + 4 * V,
             'subtile_bin': 16 * V + 8 * D,
             'sort_subtiles': 12 * D,
@@ -330,20 +361,25 @@ def main():
         }
         dom = max((k for k in avg_us if k in alg and alg[k] > 0), key=lambda k: avg_us[k])
         achieved = alg[dom] / (avg_us[dom] * 1e-6) / 1e9
-        total_bytes = 128 * P + 252 * V + 44 * D + 56 * WH
+        fwd_bytes = 60 * P + 88 * V + 40 * D + 28 * WH + sh_bytes
+        total_bytes = (128 * P + 252 * V + 44 * D + 56 * WH) if train else fwd_bytes
         result['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom),
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom) if args.config == 'c3' and train else None,
             'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
             'kernel_avg_us': avg_us,
             'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),
-                     'achieved_GBs_at_measured_step': total_bytes / (ms_per_step * 1e-3) / 1e9,
-                     'frac_at_measured_step': total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     'achieved_GBs_at_measured_step': total_bytes * KV / (ms_per_step * 1e-3) / 1e9,
+                     'frac_at_measured_step': total_bytes * KV / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1) ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(args.config, assets, shape)
+        result['cpu_baseline'] = cpu_baseline(args.config, assets, shape, train)
+
+    # ---- RCCL smoke at world size 1 (the 8-GPU curve is the driver's to measure): init + one all-reduce ----
+    if rank == 0 and world == 1 and single and not args.no_concurrent:
+        result['rccl_world1_smoke'] = rccl_world1_smoke(device)
 
     if rank == 0:
         print(json.dumps(result))
@@ -353,67 +389,122 @@ def main():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r01_final_hbm_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of the same C3 workload); None if not available."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_final_hbm_traffic.json')
-    try:
-        with open(path) as f:
-            return float(json.load(f)['kernels'][kernel]['hbm_bytes'])
-    except Exception:  # noqa: BLE001
-        return None
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>_hbm_traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate rocprofv3 --pmc runs of the same C3 workload); None if not available."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for prefix in (PROFILE_PREFIX,):
+        try:
+            with open(os.path.join(here, 'profiles', prefix + '_hbm_traffic.json')) as f:
+                return float(json.load(f)['kernels'][kernel]['hbm_bytes'])
+        except Exception:  # noqa: BLE001
+            pass
+    return None
 
 
-def concurrent_throughput(S, args, params, P, H, W, bg, vs, cam_tab, make_cam, dL_dimg, rasterize_gaussians,
-                          Settings, device):
-    """Same step, S independent views in flight (one HIP stream + hipGraph each).  Reported next to the headline
-    value, never instead of it: ExAvatar's own loop runs one view at a time (batch size 1, config.py:45)."""
-    ctxs = []
-    for _ in range(S):
-        c = make_cam()
-        c['settings'] = Settings(image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'],
-                                 bg=bg, scale_modifier=1.0, viewmatrix=c['view'], projmatrix=c['proj'], sh_degree=0,
-                                 campos=c['cpos'], prefiltered=False, debug=False)
-        c['mean_2d'] = torch.zeros(P, 3, device=device, requires_grad=True)
-        c['stream'] = torch.cuda.Stream()
-        ctxs.append(c)
-
-    def one(c):
-        m3, sc, rot, op, rgb = params
-        color, _, _, _ = rasterize_gaussians(m3, c['mean_2d'], None, rgb, op, sc, rot, None, c['settings'])
-        torch.autograd.grad([color], list(params) + [c['mean_2d']], grad_outputs=[dL_dimg])
-
+def _timed_replays(ctxs, args, set_view, units_per_step):
     torch.cuda.synchronize()
-    for c in ctxs:
-        with torch.cuda.stream(c['stream']):
-            one(c)
-    torch.cuda.synchronize()
-    for c in ctxs:
-        c['graph'] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(c['graph']):
-            one(c)
-    torch.cuda.synchronize()
-    nv = cam_tab.shape[0]
+    S = len(ctxs)
 
     def run(k0, k1):
         for i in range(k0, k1):
             c = ctxs[i % S]
-            with torch.cuda.stream(c['stream']):
-                c['cam'].copy_(cam_tab[i % nv])
+            if c['stream'] is not None:
+                with torch.cuda.stream(c['stream']):
+                    set_view(i, c)
+                    c['graph'].replay()
+            else:
+                set_view(i, c)
                 c['graph'].replay()
     run(0, 4 * S)
     torch.cuda.synchronize()
+    n = max(args.steps // units_per_step, 8)
     t0 = time.perf_counter()
-    run(0, args.steps)
+    run(0, n)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {'views_in_flight': S, 'value': args.steps / dt, 'unit': 'iters/s', 'ms_per_step': dt / args.steps * 1e3}
+    return n * units_per_step / dt, dt / n * 1e3
 
 
-def cpu_baseline(cfg_name, assets, shape, target_instances=40_000, max_threads=16):
-    """Times oracle/raster_oracle.py (fwd + autograd bwd, float32) on a bounded sample: the full
-    per-Gaussian stage plus the tiles nearest the image centre holding ~``target_instances`` tile
-    instances; the per-tile part is scaled by the instance fraction.  Threads are capped at
-    ``max_threads`` (hundreds of OpenMP threads make the oracle's many small tensor ops far slower)."""
+def batched_throughput(K, args, make_ctx, set_view, raster_step):
+    """K views of this GPU's shard per batched launch (exa_raster_forward_batch / _backward_batch: ONE launch per
+    pipeline stage for the K views, gradients of the shared Gaussians summed in the per-Gaussian kernel).  Reported
+    next to the headline, never instead of it."""
+    c = make_ctx(K)
+    set_view(0, c)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            raster_step(c)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    c['graph'] = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(c['graph']):
+        raster_step(c)
+    val, ms = _timed_replays([c], args, set_view, K)
+    return {'views_per_launch': K, 'value': val, 'unit': 'iters/s', 'ms_per_launch': ms}
+
+
+def concurrent_throughput(S, args, make_ctx, set_view, raster_step):
+    """Same step, S independent views in flight (one HIP stream + hipGraph each)."""
+    ctxs = []
+    for _ in range(S):
+        c = make_ctx(1)
+        c['stream'] = torch.cuda.Stream()
+        ctxs.append(c)
+    torch.cuda.synchronize()
+    for c in ctxs:
+        set_view(0, c)
+        with torch.cuda.stream(c['stream']):
+            raster_step(c)
+    torch.cuda.synchronize()
+    for c in ctxs:
+        c['graph'] = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(c['graph']):
+            raster_step(c)
+    val, ms = _timed_replays(ctxs, args, set_view, 1)
+    return {'views_in_flight': S, 'value': val, 'unit': 'iters/s', 'ms_per_step': ms}
+
+
+_RCCL_SMOKE = r"""
+import os, sys, time, json, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', str(29600 + os.getpid() % 2000))
+dev = torch.device('cuda', 0); torch.cuda.set_device(dev)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+from exavatar_release_amd.dist import FlatGradAllReducer
+x = [torch.ones(1000, 3, device=dev), torch.ones(1000, 4, device=dev)]
+red = FlatGradAllReducer(x, average=True, n_buffers=2)
+t = torch.ones(1 << 20, device=dev)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+dist.all_reduce(t); red.start(x); red.start(x); v = red.finish(); torch.cuda.synchronize()
+ok = float(t.sum()) == float(1 << 20) and float(v[0].sum()) == 3000.0
+print(json.dumps({'ok': bool(ok), 'backend': 'nccl (RCCL)', 'world_size': 1, 'all_reduce_ms': (time.perf_counter() - t0) * 1e3}))
+dist.destroy_process_group()
+"""
+
+
+def rccl_world1_smoke(device):
+    """RCCL initialisation + all-reduces through the product's FlatGradAllReducer in a world of ONE rank on this GPU
+    (all a 1-GPU box can run; the 1/2/4/8-GPU curve is the driver's).  Runs in a child process with a timeout so that a
+    communicator problem can never take the benchmark line down with it."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, '-c', _RCCL_SMOKE, os.path.dirname(os.path.abspath(__file__))],
+                           capture_output=True, text=True, timeout=120)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {'ok': False, 'error': (r.stderr or r.stdout)[-200:]}
+    except Exception as e:  # noqa: BLE001
+        return {'ok': False, 'error': str(e)[:200]}
+
+
+def cpu_baseline(cfg_name, assets, shape, train, target_instances=40_000, max_threads=16):
+    """Times oracle/raster_oracle.py (fwd + autograd bwd, float32; forward only for `--mode forward`) on a bounded
+    sample: the full per-Gaussian stage plus the tiles nearest the image centre holding ~``target_instances`` tile
+    instances; the per-tile part is scaled by the instance fraction.  Threads are capped at ``max_threads``
+    (hundreds of OpenMP threads make the oracle's many small tensor ops far slower)."""
     from exavatar_release_amd import scenes
     from oracle import raster_oracle as ro
     cores = min(os.cpu_count() or 1, max_threads)
@@ -424,15 +515,21 @@ def cpu_baseline(cfg_name, assets, shape, target_instances=40_000, max_threads=1
     g = torch.Generator().manual_seed(1)
     G = torch.randn(3, H, W, generator=g)
     gx, gy = (W + 15) // 16, (H + 15) // 16
+    use_sh = 'sh' in assets
+    so = ro.settings_from_camera(cam, shape, torch.ones(3), 3 if use_sh else 0)
 
     def run(sub):
-        a = {k: v.clone().requires_grad_(True) for k, v in assets.items()}
+        a = {k: v.clone().requires_grad_(train) for k, v in assets.items()}
         t0 = time.perf_counter()
-        out = ro.render(a, shape, cam, torch.ones(3), return_aux=True, tile_subset=sub)
-        if out['img'].requires_grad:
-            (out['img'] * G).sum().backward()
-        return time.perf_counter() - t0, out['aux']
+        with torch.set_grad_enabled(train):
+            res = ro.rasterize(a['mean_3d'], None, a['opacity'], shs=a['sh'] if use_sh else None,
+                               colors_precomp=None if use_sh else a['rgb'], scales=a['scale'], rotations=a['rotation'],
+                               settings=so, return_aux=True, tile_subset=sub)
+            if train and res[0].requires_grad:
+                (res[0] * G).sum().backward()
+        return time.perf_counter() - t0, res[4]
 
+    what = 'fwd+autograd-bwd' if train else 'forward'
     t_pre, aux = run([])                       # per-Gaussian stage + list building only
     ranges = aux['ranges']
     counts = (ranges[:, 1] - ranges[:, 0]).tolist()
@@ -452,14 +549,14 @@ def cpu_baseline(cfg_name, assets, shape, target_instances=40_000, max_threads=1
         # the whole view fits the 10-30 s budget: time it in full instead of extrapolating
         t_meas, _ = run(None)
         return {'value': 1.0 / t_meas, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
-                'sample': 'PyTorch CPU oracle fwd+autograd-bwd of view 0 in full (%d tile instances) on %d of %d '
+                'sample': 'PyTorch CPU oracle %s of view 0 in full (%d tile instances) on %d of %d '
                           'host threads: %.1f s measured (a %.1f%% sample had predicted %.1f s)'
-                          % (D_total, cores, os.cpu_count() or 1, t_meas, 100 * frac, t_full)}
+                          % (what, D_total, cores, os.cpu_count() or 1, t_meas, 100 * frac, t_full)}
     return {'value': 1.0 / t_full, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
-            'sample': 'PyTorch CPU oracle fwd+autograd-bwd of view 0 on %d of %d host threads: full per-Gaussian '
+            'sample': 'PyTorch CPU oracle %s of view 0 on %d of %d host threads: full per-Gaussian '
                       'stage (%.2f s) + the %d central tiles holding %.1f%% of the %d tile instances (%.2f s); '
                       'per-tile part scaled by the instance fraction -> %.1f s per iteration'
-                      % (cores, os.cpu_count() or 1, t_pre, len(subset), 100 * frac, D_total, t_sub, t_full)}
+                      % (what, cores, os.cpu_count() or 1, t_pre, len(subset), 100 * frac, D_total, t_sub, t_full)}
 
 
 if __name__ == '__main__':

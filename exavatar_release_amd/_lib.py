@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libexa_raster.so')
+# EXA_RASTER_LIB: developer override to load an experimental build of the same ABI (tools/gpu_variants.py)
+LIB_PATH = os.environ.get('EXA_RASTER_LIB') or os.path.join(_HERE, 'libexa_raster.so')
 
 c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses
 c_void_p = ctypes.c_void_p
@@ -35,8 +36,37 @@ class ExaRasterWorkspaceSizes(ctypes.Structure):
         ('geom_bytes', ctypes.c_uint64),
         ('tile_bytes', ctypes.c_uint64),
         ('bin_bytes', ctypes.c_uint64),
-        ('img_bytes', ctypes.c_uint64),
         ('grad_bytes', ctypes.c_uint64),
+    ]
+
+
+class ExaRasterForwardJob(ctypes.Structure):
+    """One render of a batched forward call (include/exa_raster.h)."""
+    _fields_ = [
+        ('settings', ctypes.POINTER(ExaRasterSettings)),
+        ('P', ctypes.c_int32), ('sh_M', ctypes.c_int32),
+        ('means3D', c_void_p), ('shs', c_void_p), ('colors_precomp', c_void_p), ('opacities', c_void_p),
+        ('scales', c_void_p), ('rotations', c_void_p), ('cov3D_precomp', c_void_p),
+        ('radii', c_void_p),
+        ('geom_ws', c_void_p), ('tile_ws', c_void_p),
+        ('bin_ws', c_void_p), ('capacity', ctypes.c_uint64),
+        ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
+    ]
+
+
+class ExaRasterBackwardJob(ctypes.Structure):
+    """One render of a batched backward call (include/exa_raster.h)."""
+    _fields_ = [
+        ('settings', ctypes.POINTER(ExaRasterSettings)),
+        ('P', ctypes.c_int32), ('sh_M', ctypes.c_int32),
+        ('means3D', c_void_p), ('shs', c_void_p), ('colors_precomp', c_void_p), ('opacities', c_void_p),
+        ('scales', c_void_p), ('rotations', c_void_p), ('cov3D_precomp', c_void_p),
+        ('radii', c_void_p),
+        ('geom_ws', c_void_p), ('tile_ws', c_void_p), ('bin_ws', c_void_p), ('capacity', ctypes.c_uint64),
+        ('dL_dcolor', c_void_p), ('dL_ddepth', c_void_p), ('dL_dalpha', c_void_p),
+        ('grad_ws', c_void_p),
+        ('dL_dmeans2D', c_void_p), ('dL_dmeans3D', c_void_p), ('dL_dcolors', c_void_p), ('dL_dopacity', c_void_p),
+        ('dL_dscales', c_void_p), ('dL_drotations', c_void_p), ('dL_dsh', c_void_p), ('dL_dcov3D', c_void_p),
     ]
 
 
@@ -49,15 +79,19 @@ SIGNATURES = {
     'exa_raster_last_error': (ctypes.c_char_p, []),
     'exa_raster_workspace_sizes': (ctypes.c_int, [_I32, _I32, _I32, _U64, ctypes.POINTER(ExaRasterWorkspaceSizes)]),
     'exa_raster_forward_bin': (ctypes.c_int, [_SP, _I32, _I32] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p]),
-    'exa_raster_forward_render': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p, _U64, c_void_p,
+    'exa_raster_forward_render': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p, _U64,
                                                  c_void_p, c_void_p, c_void_p, _I32, c_void_p]),
     'exa_raster_forward': (ctypes.c_int, [_SP, _I32, _I32] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p,
                                                                                  _U64, c_void_p, c_void_p, c_void_p,
-                                                                                 c_void_p, _I32, c_void_p]),
+                                                                                 _I32, c_void_p]),
     'exa_raster_backward': (ctypes.c_int, [_SP, _I32, _I32] + [c_void_p] * 7 + [c_void_p, c_void_p, c_void_p, c_void_p,
                                                                                   _U64, c_void_p, c_void_p, c_void_p,
-                                                                                  c_void_p, c_void_p] + [c_void_p] * 8
+                                                                                  c_void_p] + [c_void_p] * 8
                             + [c_void_p]),
+    'exa_raster_forward_bin_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, c_void_p]),
+    'exa_raster_forward_render_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
+    'exa_raster_forward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
+    'exa_raster_backward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterBackwardJob), _I32, _I32, c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),
@@ -87,7 +121,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 100:
+    if lib.exa_raster_version() < 110:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

@@ -100,124 +100,283 @@ int exa_raster_workspace_sizes(int32_t P, int32_t W, int32_t H, uint64_t capacit
     out->geom_bytes = align256(uint64_t(P) * sizeof(Splat));
     out->tile_bytes = tile_ws_bytes(g.cells, num_chunks(P));
     out->bin_bytes = bin_ws_bytes(capacity);
-    out->img_bytes = img_ws_bytes(W, H);
     out->grad_bytes = grad_ws_bytes(capacity);
     return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+int check_forward_job(const ExaRasterForwardJob& j, bool stage1, bool stage2) {
+    int rc = check_settings(j.settings);
+    if (rc) return rc;
+    if (stage1) {
+        rc = check_inputs(j.P, j.sh_M, j.means3D, j.shs, j.colors_precomp, j.opacities, j.scales, j.rotations,
+                          j.cov3D_precomp, j.settings->sh_degree);
+        if (rc) return rc;
+        if (j.P > 0 && !j.radii) return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
+    }
+    if (j.P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
+    if (!j.tile_ws || (j.P > 0 && !j.geom_ws)) return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
+    if (stage2) {
+        if (j.capacity > 0 && !j.bin_ws) return fail(EXA_RASTER_E_WORKSPACE, "workspace is NULL");
+        if (j.capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
+        if (!j.out_color || !j.out_depth || !j.out_alpha) return fail(EXA_RASTER_E_NULLPTR, "output image is NULL");
+    }
+    return 0;
+}
+
+BinArgs bin_args(const ExaRasterForwardJob& j) {
+    BinArgs b;
+    b.P = j.P; b.chunks = num_chunks(j.P);
+    b.grid = make_grid(j.settings->image_width, j.settings->image_height);
+    b.splats = static_cast<Splat*>(j.geom_ws);
+    b.tw = carve_tile_ws(j.tile_ws, b.grid.cells, b.chunks);
+    b.bw = carve_bin_ws(j.bin_ws, j.capacity);
+    b.capacity = j.capacity;
+    return b;
+}
+
+// stage 1 of up to MAX_BATCH jobs: one launch per kernel
+int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st) {
+    PreprocessArgs pa[MAX_BATCH];
+    BinArgs ba[MAX_BATCH];
+    const ExaRasterSettings* s0 = jobs[0].settings;
+    for (int k = 0; k < K; ++k) {
+        const ExaRasterForwardJob& j = jobs[k];
+        const ExaRasterSettings* s = j.settings;
+        PreprocessArgs& a = pa[k];
+        a.P = j.P; a.sh_M = j.sh_M; a.sh_degree = s->sh_degree;
+        a.grid = make_grid(s->image_width, s->image_height);
+        a.tanfovx = s->tanfovx; a.tanfovy = s->tanfovy;
+        a.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
+        a.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
+        a.scale_modifier = s->scale_modifier;
+        a.viewmatrix = s->viewmatrix; a.projmatrix = s->projmatrix; a.campos = s->campos;
+        a.means3D = j.means3D; a.shs = j.shs; a.colors_precomp = j.colors_precomp; a.opacities = j.opacities;
+        a.scales = j.scales; a.rotations = j.rotations; a.cov3D_precomp = j.cov3D_precomp;
+        a.radii = j.radii; a.splats = static_cast<Splat*>(j.geom_ws);
+        a.tw = carve_tile_ws(j.tile_ws, a.grid.cells, num_chunks(j.P));
+        ba[k] = bin_args(j);
+    }
+    int rc;
+    EXA_TIMED(K_PREPROCESS_FWD, launch_preprocess_fwd(pa, K, st), "preprocess_fwd");
+    if ((rc = debug_sync(s0, st, "preprocess_fwd"))) return rc;
+    EXA_TIMED(K_CELL_SCAN, launch_cell_scan(ba, K, st), "cell_scan");
+    if ((rc = debug_sync(s0, st, "cell_scan"))) return rc;
+    return 0;
+}
+
+int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, hipStream_t st) {
+    BinArgs ba[MAX_BATCH];
+    RenderFwdArgs ra[MAX_BATCH];
+    const ExaRasterSettings* s0 = jobs[0].settings;
+    for (int k = 0; k < K; ++k) {
+        const ExaRasterForwardJob& j = jobs[k];
+        ba[k] = bin_args(j);
+        RenderFwdArgs& r = ra[k];
+        r.grid = ba[k].grid; r.splats = ba[k].splats; r.tw = ba[k].tw; r.bw = ba[k].bw; r.capacity = j.capacity;
+        r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
+        r.store_ctx = store_ctx;
+    }
+    int rc;
+    // (cell_scatter_kernel also clears the zero-filled section of the bin workspace: batch owners, blended masks, touched bytes)
+    EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(ba, K, st), "cell_scatter");
+    if ((rc = debug_sync(s0, st, "cell_scatter"))) return rc;
+    EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(ba, K, st), "subtile_bin");
+    if ((rc = debug_sync(s0, st, "subtile_bin"))) return rc;
+    EXA_TIMED(K_SORT, launch_sort_subtiles(ra, K, st), "sort_subtiles");
+    if ((rc = debug_sync(s0, st, "sort_subtiles"))) return rc;
+    EXA_TIMED(K_RENDER_FWD, launch_render_fwd(ra, K, st), "render_fwd");
+    if ((rc = debug_sync(s0, st, "render_fwd"))) return rc;
+    return 0;
+}
+
+int check_backward_job(const ExaRasterBackwardJob& j) {
+    int rc = check_settings(j.settings);
+    if (rc) return rc;
+    rc = check_inputs(j.P, j.sh_M, j.means3D, j.shs, j.colors_precomp, j.opacities, j.scales, j.rotations,
+                      j.cov3D_precomp, j.settings->sh_degree);
+    if (rc) return rc;
+    if (j.P == 0) return 0;
+    if (!j.geom_ws || !j.tile_ws || (j.capacity > 0 && !j.bin_ws) || !j.grad_ws || !j.radii)
+        return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
+    if (j.capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
+    if (!j.dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
+    return 0;
+}
+
+int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipStream_t st) {
+    RenderBwdArgs ra[MAX_BATCH];
+    PreprocessBwdArgs pa[MAX_BATCH];
+    const ExaRasterSettings* s0 = jobs[0].settings;
+    int n = 0;
+    for (int k = 0; k < K; ++k) {
+        const ExaRasterBackwardJob& j = jobs[k];
+        if (j.P == 0) continue;                                   // nothing to differentiate
+        const ExaRasterSettings* s = j.settings;
+        const Grid g = make_grid(s->image_width, s->image_height);
+        RenderBwdArgs& r = ra[n];
+        r.grid = g; r.capacity = j.capacity; r.P = j.P; r.splats = static_cast<const Splat*>(j.geom_ws);
+        r.tw = carve_tile_ws(const_cast<void*>(j.tile_ws), g.cells, num_chunks(j.P));
+        r.bw = carve_bin_ws(const_cast<void*>(j.bin_ws), j.capacity);
+        r.bg = s->bg; r.dL_dcolor = j.dL_dcolor; r.dL_ddepth = j.dL_ddepth; r.dL_dalpha = j.dL_dalpha;
+        r.partials = carve_grad_ws(j.grad_ws, j.capacity);
+        PreprocessBwdArgs& b = pa[n];
+        b.P = j.P; b.sh_M = j.sh_M; b.sh_degree = s->sh_degree; b.grid = g;
+        b.tanfovx = s->tanfovx; b.tanfovy = s->tanfovy;
+        b.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
+        b.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
+        b.scale_modifier = s->scale_modifier;
+        b.viewmatrix = s->viewmatrix; b.projmatrix = s->projmatrix; b.campos = s->campos;
+        b.means3D = j.means3D; b.shs = j.shs; b.opacities = j.opacities; b.scales = j.scales; b.rotations = j.rotations;
+        b.cov3D_precomp = j.cov3D_precomp; b.radii = j.radii; b.splats = r.splats;
+        b.partials = r.partials; b.touched = r.bw.touched; b.header = r.tw.header;
+        b.dL_dmeans2D = j.dL_dmeans2D; b.dL_dmeans3D = j.dL_dmeans3D; b.dL_dcolors = j.dL_dcolors;
+        b.dL_dopacity = j.dL_dopacity; b.dL_dscales = j.dL_dscales; b.dL_drotations = j.dL_drotations;
+        b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;
+        ++n;
+    }
+    if (n == 0) return 0;
+    int rc;
+    EXA_TIMED(K_RENDER_BWD, launch_render_bwd(ra, n, st), "render_bwd");
+    if ((rc = debug_sync(s0, st, "render_bwd"))) return rc;
+    EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(pa, n, sum_shared, st), "preprocess_bwd");
+    if ((rc = debug_sync(s0, st, "preprocess_bwd"))) return rc;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream) {
+    if (K < 0 || (K > 0 && !jobs)) return fail(EXA_RASTER_E_INVALID, "bad job list");
+    for (int k = 0; k < K; ++k) {
+        const int rc = check_forward_job(jobs[k], true, false);
+        if (rc) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
+        const int rc = forward_bin_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int exa_raster_forward_render_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream) {
+    if (K < 0 || (K > 0 && !jobs)) return fail(EXA_RASTER_E_INVALID, "bad job list");
+    for (int k = 0; k < K; ++k) {
+        const int rc = check_forward_job(jobs[k], false, true);
+        if (rc) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
+        const int rc = forward_render_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, store_ctx, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int exa_raster_forward_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream) {
+    if (K < 0 || (K > 0 && !jobs)) return fail(EXA_RASTER_E_INVALID, "bad job list");
+    for (int k = 0; k < K; ++k) {
+        const int rc = check_forward_job(jobs[k], true, true);
+        if (rc) return rc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
+        const int n = K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH;
+        int rc = forward_bin_group(jobs + k0, n, st);
+        if (rc) return rc;
+        rc = forward_render_group(jobs + k0, n, store_ctx, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32_t sum_shared, void* stream) {
+    if (K < 0 || (K > 0 && !jobs)) return fail(EXA_RASTER_E_INVALID, "bad job list");
+    for (int k = 0; k < K; ++k) {
+        const int rc = check_backward_job(jobs[k]);
+        if (rc) return rc;
+        if (sum_shared) {
+            const ExaRasterBackwardJob &a = jobs[0], &b = jobs[k];
+            if (a.P != b.P || a.sh_M != b.sh_M || a.means3D != b.means3D || a.shs != b.shs || a.opacities != b.opacities ||
+                a.colors_precomp != b.colors_precomp || a.scales != b.scales || a.rotations != b.rotations ||
+                a.cov3D_precomp != b.cov3D_precomp || a.settings->sh_degree != b.settings->sh_degree ||
+                a.settings->scale_modifier != b.settings->scale_modifier)
+                return fail(EXA_RASTER_E_INVALID, "sum_shared needs K views of the same Gaussian tensors");
+        }
+    }
+    if (sum_shared && K > MAX_BATCH) return fail(EXA_RASTER_E_INVALID, "sum_shared supports at most 8 views per call");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
+        const int rc = backward_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, sum_shared, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// ---- single-render entry points: a batch of one ------------------------------------------------------------
+static ExaRasterForwardJob one_job(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D,
+                                   const float* shs, const float* colors_precomp, const float* opacities,
+                                   const float* scales, const float* rotations, const float* cov3D_precomp,
+                                   int32_t* radii, void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity,
+                                   float* out_color, float* out_depth, float* out_alpha) {
+    ExaRasterForwardJob j;
+    j.settings = s; j.P = P; j.sh_M = sh_M; j.means3D = means3D; j.shs = shs; j.colors_precomp = colors_precomp;
+    j.opacities = opacities; j.scales = scales; j.rotations = rotations; j.cov3D_precomp = cov3D_precomp;
+    j.radii = radii; j.geom_ws = geom_ws; j.tile_ws = tile_ws; j.bin_ws = bin_ws; j.capacity = capacity;
+    j.out_color = out_color; j.out_depth = out_depth; j.out_alpha = out_alpha;
+    return j;
 }
 
 int exa_raster_forward_bin(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D,
                            const float* shs, const float* colors_precomp, const float* opacities,
                            const float* scales, const float* rotations, const float* cov3D_precomp,
                            int32_t* radii, void* geom_ws, void* tile_ws, void* stream) {
-    int rc = check_settings(s);
-    if (rc) return rc;
-    rc = check_inputs(P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s->sh_degree);
-    if (rc) return rc;
-    if (!tile_ws || (P > 0 && (!geom_ws || !radii))) return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const Grid g = make_grid(s->image_width, s->image_height);
-    TileWs tw = carve_tile_ws(tile_ws, g.cells, num_chunks(P));
-    // header + cell counters + cell cursors are contiguous: one zero-fill
-    PreprocessArgs a;
-    a.P = P; a.sh_M = sh_M; a.sh_degree = s->sh_degree; a.grid = g;
-    a.tanfovx = s->tanfovx; a.tanfovy = s->tanfovy;
-    a.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
-    a.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
-    a.scale_modifier = s->scale_modifier;
-    a.viewmatrix = s->viewmatrix; a.projmatrix = s->projmatrix; a.campos = s->campos;
-    a.means3D = means3D; a.shs = shs; a.colors_precomp = colors_precomp; a.opacities = opacities;
-    a.scales = scales; a.rotations = rotations; a.cov3D_precomp = cov3D_precomp;
-    a.radii = radii; a.splats = static_cast<Splat*>(geom_ws); a.tw = tw;
-    EXA_TIMED(K_PREPROCESS_FWD, launch_preprocess_fwd(a, st), "preprocess_fwd");
-    if ((rc = debug_sync(s, st, "preprocess_fwd"))) return rc;
-    EXA_TIMED(K_CELL_SCAN, launch_cell_scan(tw, g, num_chunks(P), st), "cell_scan");
-    if ((rc = debug_sync(s, st, "cell_scan"))) return rc;
-    return 0;
+    const ExaRasterForwardJob j = one_job(s, P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                          cov3D_precomp, radii, geom_ws, tile_ws, nullptr, 0, nullptr, nullptr, nullptr);
+    return exa_raster_forward_bin_batch(&j, 1, stream);
 }
 
 int exa_raster_forward_render(const ExaRasterSettings* s, int32_t P, const void* geom_ws, void* tile_ws, void* bin_ws,
-                              uint64_t capacity, void* img_ws, float* out_color, float* out_depth, float* out_alpha,
+                              uint64_t capacity, float* out_color, float* out_depth, float* out_alpha,
                               int32_t store_ctx, void* stream) {
-    int rc = check_settings(s);
-    if (rc) return rc;
-    if (P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
-    if (!tile_ws || (P > 0 && !geom_ws) || (capacity > 0 && !bin_ws) || (store_ctx && !img_ws))
-        return fail(EXA_RASTER_E_WORKSPACE, "workspace is NULL");
-    if (!out_color || !out_depth || !out_alpha) return fail(EXA_RASTER_E_NULLPTR, "output image is NULL");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const Grid g = make_grid(s->image_width, s->image_height);
-    TileWs tw = carve_tile_ws(tile_ws, g.cells, num_chunks(P));
-    BinWs bw = carve_bin_ws(bin_ws, capacity);
-    if (capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
-    Splat* splats = static_cast<Splat*>(const_cast<void*>(geom_ws));   // cell_scatter fills Splat::inst_off
-    // the batch-owner array is cleared by cell_scatter_kernel itself (no Gaussians: nobody else would)
-    if (P == 0) EXA_TIMED(K_ZERO, launch_zero(bw.owner, (capacity / BATCH + 1) * 16, st), "zero(batch owners)");
-    EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(P, splats, tw, g, bw, capacity, st), "cell_scatter");
-    if ((rc = debug_sync(s, st, "cell_scatter"))) return rc;
-    EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(splats, tw, g, bw, capacity, st), "subtile_bin");
-    if ((rc = debug_sync(s, st, "subtile_bin"))) return rc;
-    RenderFwdArgs r;
-    r.grid = g; r.splats = static_cast<const Splat*>(geom_ws); r.tw = tw; r.bw = bw; r.capacity = capacity;
-    r.bg = s->bg; r.out_color = out_color; r.out_depth = out_depth; r.out_alpha = out_alpha; r.store_ctx = store_ctx;
-    EXA_TIMED(K_SORT, launch_sort_subtiles(r, st), "sort_subtiles");
-    if ((rc = debug_sync(s, st, "sort_subtiles"))) return rc;
-    EXA_TIMED(K_RENDER_FWD, launch_render_fwd(r, st), "render_fwd");
-    if ((rc = debug_sync(s, st, "render_fwd"))) return rc;
-    return 0;
+    const ExaRasterForwardJob j = one_job(s, P, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                          const_cast<void*>(geom_ws), tile_ws, bin_ws, capacity, out_color, out_depth,
+                                          out_alpha);
+    return exa_raster_forward_render_batch(&j, 1, store_ctx, stream);
 }
 
 int exa_raster_forward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D, const float* shs,
                        const float* colors_precomp, const float* opacities, const float* scales,
                        const float* rotations, const float* cov3D_precomp, int32_t* radii, void* geom_ws,
-                       void* tile_ws, void* bin_ws, uint64_t capacity, void* img_ws, float* out_color,
+                       void* tile_ws, void* bin_ws, uint64_t capacity, float* out_color,
                        float* out_depth, float* out_alpha, int32_t store_ctx, void* stream) {
-    int rc = exa_raster_forward_bin(s, P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                    cov3D_precomp, radii, geom_ws, tile_ws, stream);
-    if (rc) return rc;
-    return exa_raster_forward_render(s, P, geom_ws, tile_ws, bin_ws, capacity, img_ws, out_color, out_depth,
-                                     out_alpha, store_ctx, stream);
+    const ExaRasterForwardJob j = one_job(s, P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                          cov3D_precomp, radii, geom_ws, tile_ws, bin_ws, capacity, out_color, out_depth,
+                                          out_alpha);
+    return exa_raster_forward_batch(&j, 1, store_ctx, stream);
 }
 
 int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, const float* means3D, const float* shs,
                         const float* colors_precomp, const float* opacities, const float* scales,
                         const float* rotations, const float* cov3D_precomp, const int32_t* radii,
                         const void* geom_ws, const void* tile_ws, const void* bin_ws, uint64_t capacity,
-                        const void* img_ws, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
+                        const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                         void* grad_ws, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity,
                         float* dL_dscales, float* dL_drotations, float* dL_dsh, float* dL_dcov3D, void* stream) {
-    int rc = check_settings(s);
-    if (rc) return rc;
-    rc = check_inputs(P, sh_M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, s->sh_degree);
-    if (rc) return rc;
-    if (P == 0) return 0;
-    if (!geom_ws || !tile_ws || (capacity > 0 && !bin_ws) || !img_ws || !grad_ws || !radii)
-        return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
-    if (!dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const Grid g = make_grid(s->image_width, s->image_height);
-    RenderBwdArgs r;
-    r.grid = g; r.capacity = capacity; r.P = P; r.splats = static_cast<const Splat*>(geom_ws);
-    r.tw = carve_tile_ws(const_cast<void*>(tile_ws), g.cells, num_chunks(P));
-    r.bw = carve_bin_ws(const_cast<void*>(bin_ws), capacity);
-    r.bg = s->bg; r.dL_dcolor = dL_dcolor; r.dL_ddepth = dL_ddepth; r.dL_dalpha = dL_dalpha;
-    r.partials = static_cast<Partial*>(grad_ws);
-    EXA_TIMED(K_RENDER_BWD, launch_render_bwd(r, st), "render_bwd");
-    if ((rc = debug_sync(s, st, "render_bwd"))) return rc;
-    PreprocessBwdArgs b;
-    b.P = P; b.sh_M = sh_M; b.sh_degree = s->sh_degree; b.grid = g;
-    b.tanfovx = s->tanfovx; b.tanfovy = s->tanfovy;
-    b.focal_x = (float)s->image_width / (2.0f * s->tanfovx);
-    b.focal_y = (float)s->image_height / (2.0f * s->tanfovy);
-    b.scale_modifier = s->scale_modifier;
-    b.viewmatrix = s->viewmatrix; b.projmatrix = s->projmatrix; b.campos = s->campos;
-    b.means3D = means3D; b.shs = shs; b.opacities = opacities; b.scales = scales; b.rotations = rotations;
-    b.cov3D_precomp = cov3D_precomp; b.radii = radii; b.splats = static_cast<const Splat*>(geom_ws);
-    b.partials = static_cast<const Partial*>(grad_ws);
-    b.dL_dmeans2D = dL_dmeans2D; b.dL_dmeans3D = dL_dmeans3D; b.dL_dcolors = dL_dcolors; b.dL_dopacity = dL_dopacity;
-    b.dL_dscales = dL_dscales; b.dL_drotations = dL_drotations; b.dL_dsh = dL_dsh; b.dL_dcov3D = dL_dcov3D;
-    EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(b, st), "preprocess_bwd");
-    if ((rc = debug_sync(s, st, "preprocess_bwd"))) return rc;
-    return 0;
+    ExaRasterBackwardJob j;
+    j.settings = s; j.P = P; j.sh_M = sh_M; j.means3D = means3D; j.shs = shs; j.colors_precomp = colors_precomp;
+    j.opacities = opacities; j.scales = scales; j.rotations = rotations; j.cov3D_precomp = cov3D_precomp;
+    j.radii = radii; j.geom_ws = geom_ws; j.tile_ws = tile_ws; j.bin_ws = bin_ws; j.capacity = capacity;
+    j.dL_dcolor = dL_dcolor; j.dL_ddepth = dL_ddepth; j.dL_dalpha = dL_dalpha; j.grad_ws = grad_ws;
+    j.dL_dmeans2D = dL_dmeans2D; j.dL_dmeans3D = dL_dmeans3D; j.dL_dcolors = dL_dcolors; j.dL_dopacity = dL_dopacity;
+    j.dL_dscales = dL_dscales; j.dL_drotations = dL_drotations; j.dL_dsh = dL_dsh; j.dL_dcov3D = dL_dcov3D;
+    return exa_raster_backward_batch(&j, 1, 0, stream);
 }
 
 int exa_raster_mark_visible(const ExaRasterSettings* s, int32_t P, const float* means3D, uint8_t* present,

@@ -60,8 +60,12 @@ __global__ __launch_bounds__(BLOCK) void zero_kernel(uint4* __restrict__ p, size
 // entries the EARLIER chunks put into that cell, so that cell_scatter_kernel needs no atomic cursor and places
 // entries deterministically (by chunk, then by LDS rank).
 constexpr int COL_W = 32, COL_RB = SCAN_THREADS / COL_W;
-__global__ __launch_bounds__(SCAN_THREADS) void col_scan_kernel(TileWs w, int cells, int chunks) {
+__global__ __launch_bounds__(SCAN_THREADS) void col_scan_kernel(Batch<BinArgs> batch) {
     __shared__ unsigned long long s_part[COL_RB][COL_W];
+    const BinArgs& a = batch.v[blockIdx.y];
+    const TileWs& w = a.tw;
+    const int cells = a.grid.cells, chunks = a.chunks;
+    if ((int)blockIdx.x * COL_W >= cells) return;
     const int tid = threadIdx.x, col = tid & (COL_W - 1), rb = tid / COL_W;
     const int c = blockIdx.x * COL_W + col;
     const int rows_per = (chunks + COL_RB - 1) / COL_RB;
@@ -117,8 +121,11 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int cells, int chunks) {
+__global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> batch) {
     __shared__ unsigned long long s_tmp[SCAN_THREADS / 64];
+    const BinArgs& a = batch.v[blockIdx.y];
+    const TileWs& w = a.tw;
+    const int cells = a.grid.cells, chunks = a.chunks;
     const int tid = threadIdx.x;
     // every global input of the first trip is requested up front: the kernel is one workgroup of pure latency
     const unsigned long long v0 = tid < cells ? w.cell_cnt[tid] : 0ull;
@@ -188,15 +195,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(TileWs w, int c
 // every cell comes from the scanned count matrix, ranks inside it from LDS atomics, (c) clears this
 // workgroup's slice of the batch-owner array.
 constexpr int SC_BLOCK = CHUNK;        // one Gaussian per thread
-__global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(int P, Splat* __restrict__ splats, TileWs w, Grid g, BinWs b,
-                                                             uint64_t capacity) {
+__global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> batch) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // cnt[cells] | base[cells] | cnt2[cells]
     __shared__ uint32_t s_tmp[SC_BLOCK / 64];
-    {   // this workgroup's slice of the batch-owner array (written by subtile_bin_kernel, the next launch)
-        const size_t n16 = capacity / BATCH + 1, per = (n16 + gridDim.x - 1) / gridDim.x;
+    const BinArgs& a = batch.v[blockIdx.y];
+    const int P = a.P;
+    Splat* __restrict__ splats = a.splats;
+    const TileWs& w = a.tw;
+    const Grid& g = a.grid;
+    const BinWs& b = a.bw;
+    const uint64_t capacity = a.capacity;
+    {   // this workgroup's slice of the zero-filled section of the bin workspace: batch owners (written by
+        // subtile_bin_kernel, the next launch), blended masks (render_fwd), touched bytes (render_bwd)
+        const size_t n16 = bin_zero_bytes(capacity) / 16, per = (n16 + gridDim.x - 1) / gridDim.x;
         const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
         for (size_t i = lo + threadIdx.x; i < hi; i += SC_BLOCK) b.owner[i] = make_uint4(0u, 0u, 0u, 0u);
     }
+    if ((int)blockIdx.x >= a.chunks) return;                    // a job with fewer Gaussians than the largest of the batch
     const uint32_t D = w.header->num_rendered;
     if ((uint64_t)D > capacity) {
         if (blockIdx.x == 0 && threadIdx.x == 0) w.header->overflow = 1u;
@@ -269,7 +284,7 @@ constexpr int BIN_THREADS = 1024;
 //                         its own first slot in every sub-tile) and scatters its quarter of the keys.
 // Plain stores and a kernel boundary instead of any cross-workgroup atomics; part 0 publishes ranges and owners.
 struct CellPart { int cell, part; uint32_t e0, e1, lo, hi; bool overflow; };
-__device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {
+__device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * BIN_PARTS
     CellPart c;
     c.cell = (int)w.cell_order[blockIdx.x / BIN_PARTS];
     c.part = (int)(blockIdx.x % BIN_PARTS);
@@ -283,9 +298,14 @@ __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity
     return c;
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(TileWs w, Grid g, BinWs b, uint64_t capacity) {
+__global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArgs> batch) {
     __shared__ uint32_t s_cnt[SUBS_PER_CELL];
-    const CellPart cp = cell_part(w, capacity);
+    const BinArgs& a = batch.v[blockIdx.y];
+    const TileWs& w = a.tw;
+    const Grid& g = a.grid;
+    const BinWs& b = a.bw;
+    if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
+    const CellPart cp = cell_part(w, a.capacity);
     const int tid = threadIdx.x;
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
@@ -302,10 +322,15 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(TileWs w, Gr
     if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * BIN_PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(TileWs w, Grid g, BinWs b, uint64_t capacity) {
+__global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs> batch) {
     __shared__ uint32_t s_off[SUBS_PER_CELL];
     __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
-    const CellPart cp = cell_part(w, capacity);
+    const BinArgs& a = batch.v[blockIdx.y];
+    const TileWs& w = a.tw;
+    const Grid& g = a.grid;
+    const BinWs& b = a.bw;
+    if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
+    const CellPart cp = cell_part(w, a.capacity);
     const int cell = cp.cell, tid = threadIdx.x;
     if (tid < 64) {
         uint32_t n = 0, before = 0;
@@ -350,25 +375,33 @@ hipError_t launch_zero(void* p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_cell_scan(const TileWs& w, const Grid& g, int chunks, hipStream_t s) {
-    if (g.cells > 0) col_scan_kernel<<<(g.cells + COL_W - 1) / COL_W, SCAN_THREADS, 0, s>>>(w, g.cells, chunks);
-    cell_scan_kernel<<<1, SCAN_THREADS, 0, s>>>(w, g.cells, chunks);
+hipError_t launch_cell_scan(const BinArgs* a, int K, hipStream_t s) {
+    const Batch<BinArgs> b = make_batch(a, K);
+    int cells = 0;
+    for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
+    if (cells > 0) col_scan_kernel<<<dim3((cells + COL_W - 1) / COL_W, K), SCAN_THREADS, 0, s>>>(b);
+    cell_scan_kernel<<<dim3(1, K), SCAN_THREADS, 0, s>>>(b);
     return hipGetLastError();
 }
 
-hipError_t launch_cell_scatter(int P, Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
-                               hipStream_t s) {
-    if (P == 0) return hipSuccess;
-    cell_scatter_kernel<<<num_chunks(P), SC_BLOCK, (size_t)g.cells * 12, s>>>(P, splats, w, g, b, capacity);
+hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s) {
+    const Batch<BinArgs> b = make_batch(a, K);
+    int chunks = 1, cells = 0;                  // at least one workgroup per job: it also clears the zero-filled section
+    for (int k = 0; k < K; ++k) {
+        chunks = max(chunks, a[k].chunks);
+        cells = max(cells, a[k].grid.cells);
+    }
+    cell_scatter_kernel<<<dim3(chunks, K), SC_BLOCK, (size_t)cells * 12, s>>>(b);
     return hipGetLastError();
 }
 
-hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
-                              hipStream_t s) {
-    if (g.cells == 0) return hipSuccess;
-    (void)splats;
-    subtile_count_kernel<<<g.cells * BIN_PARTS, BIN_THREADS, 0, s>>>(w, g, b, capacity);
-    subtile_bin_kernel<<<g.cells * BIN_PARTS, BIN_THREADS, 0, s>>>(w, g, b, capacity);
+hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
+    const Batch<BinArgs> b = make_batch(a, K);
+    int cells = 0;
+    for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
+    if (cells == 0) return hipSuccess;
+    subtile_count_kernel<<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    subtile_bin_kernel<<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
     return hipGetLastError();
 }
 

@@ -25,6 +25,20 @@ constexpr int CHUNK = 1024;                // Gaussians per workgroup in the per
 constexpr int MAX_CELLS = 4096;            // LDS histogram budget (48 KiB of counters) -> images up to 4096x4096
 constexpr int HEADER_BYTES = 512;      // ExaRasterHeader at 0, length-class cursors at 256
 
+// Batched launches: every kernel takes up to MAX_BATCH independent jobs (renders) by value in its kernel arguments and
+// picks its own with blockIdx.y -- K views / K renders of one training iteration cost ONE launch per stage instead
+// of K, and their workgroups fill the chip together (a single 1024x1024 view leaves most of the 256 CUs idle in
+// every stage but the blend).  The job records live in the kernarg segment: indexing them with blockIdx.y compiles
+// to scalar loads with a register offset (no scratch copy).
+constexpr int MAX_BATCH = 8;
+template <typename T> struct Batch { T v[MAX_BATCH]; };
+template <typename T>
+inline Batch<T> make_batch(const T* a, int K) {          // unused slots repeat job 0 (never indexed: gridDim.y = K)
+    Batch<T> b;
+    for (int k = 0; k < MAX_BATCH; ++k) b.v[k] = a[k < K ? k : 0];
+    return b;
+}
+
 constexpr float NEAR_CULL = 0.2f;
 constexpr float LOWPASS = 0.3f;
 constexpr float ALPHA_MAX = 0.99f;
@@ -42,17 +56,14 @@ struct alignas(64) Splat {
 };
 static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 
-// Per-instance partial gradient written (plain stores, no atomics) by render-backward: the ten sums over
-// the 64 pixels of one sub-tile.  Indexed Gaussian-major: inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).
-struct alignas(16) Partial {
-    float mx, my;            // sum s*dx, sum s*dy          (s = dL/dG * G)
-    float mxx, mxy, myy;     // sum s*dx^2, s*dx*dy, s*dy^2
-    float dop;               // sum G * dL/dalpha
-    float dr, dg, db;        // sum alpha*T * dL/dC
-    float dz;                // sum alpha*T * dL/dDepth
-    float pad0, pad1;
-};
-static_assert(sizeof(Partial) == 48, "Partial is three 16-byte rows");
+// Per-instance partial gradients written (plain stores, no atomics) by render-backward: the sums over the 64 pixels
+// of one sub-tile, for every instance the forward pass actually blended somewhere (its `touched` byte is set; the
+// rows of all other instances are never written and never read).  Indexed Gaussian-major:
+// inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).  Three naturally aligned arrays, 40 bytes per instance:
+//   row0 = (sum s dx, sum s dy, sum s dx^2, sum s dx dy)        s = dL/dG * G
+//   row1 = (sum s dy^2, sum G dL/dalpha, sum w dL/dC_r, sum w dL/dC_g)    w = alpha T
+//   row2 = (sum w dL/dC_b, sum w dL/dDepth)
+struct PartialWs { float4* row0; float4* row1; float2* row2; };
 
 struct Grid {
     int W, H;
@@ -132,15 +143,26 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
 // header.num_rendered reports.  A batch slot is the unit of work of the backward pass (one wave each).
 constexpr int BATCH = 64;
 // bin workspace: keys[cap] (u64: depth bits << 32 | gaussian id), sorted ids[cap], cell buckets[cap]
-// (16-byte entries {id, depth bits, sub-tile rect x, y} so the second digit reads them coalesced),
-// batch owner[cap / 64] ({sub-tile + 1, list begin, list length, 0}; all-zero = unused; zeroed by stage 2: the ONE
-// load a backward workgroup needs to find its work), per-pixel forward checkpoints ckpt[cap / 64][5][64] floats
-// (T, Cr, Cg, Cb, depth at the START of every batch slot; the sub-tile's END slot holds the state at the forward's exit).
+// (16-byte entries {id, depth bits, sub-tile rect x, y} so the second digit reads them coalesced), then ONE
+// contiguous section that cell_scatter_kernel zero-fills on every forward:
+//   batch owner[cap / 64 + 1] ({sub-tile + 1, list begin, list length, 0}; all-zero = unused: the ONE load a backward
+//   workgroup needs to find its work), blended mask[cap / 64 + 1] (u64 per batch slot, bit i = entry i of the batch
+//   was blended into at least one pixel by the forward pass: the backward pass replays only those),
+//   touched[cap] (u8 per instance, Gaussian-major: render-backward wrote this instance's partial sums),
+// and per-pixel forward checkpoints ckpt[cap / 64 + 1][5][64] floats (T, Cr, Cg, Cb, depth at the START of every batch
+// slot; the sub-tile's END slot holds the state at the forward's exit).
+__host__ __device__ inline uint64_t bin_zero_bytes(uint64_t cap) {
+    return align256((cap / BATCH + 1) * 16) + align256((cap / BATCH + 1) * 8) + align256(cap);
+}
 __host__ __device__ inline uint64_t bin_ws_bytes(uint64_t cap) {
-    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16) + align256((cap / BATCH + 1) * 16) +
+    return align256(cap * 8) + align256(cap * 4) + align256(cap * 16) + bin_zero_bytes(cap) +
            align256((cap / BATCH + 1) * 5 * 64 * 4);
 }
-struct BinWs { unsigned long long* keys; uint32_t* sorted; uint4* bucket; uint4* owner; float* ckpt; };
+struct BinWs {
+    unsigned long long* keys; uint32_t* sorted; uint4* bucket;
+    uint4* owner; unsigned long long* bmask; uint8_t* touched;      // the zero-filled section starts at `owner`
+    float* ckpt;
+};
 __host__ __device__ inline BinWs carve_bin_ws(void* base, uint64_t cap) {
     BinWs b;
     char* p = static_cast<char*>(base);
@@ -148,6 +170,8 @@ __host__ __device__ inline BinWs carve_bin_ws(void* base, uint64_t cap) {
     b.sorted = reinterpret_cast<uint32_t*>(p); p += align256(cap * 4);
     b.bucket = reinterpret_cast<uint4*>(p); p += align256(cap * 16);
     b.owner = reinterpret_cast<uint4*>(p); p += align256((cap / BATCH + 1) * 16);
+    b.bmask = reinterpret_cast<unsigned long long*>(p); p += align256((cap / BATCH + 1) * 8);
+    b.touched = reinterpret_cast<uint8_t*>(p); p += align256(cap);
     b.ckpt = reinterpret_cast<float*>(p);
     return b;
 }
@@ -156,12 +180,16 @@ __host__ __device__ inline uint32_t cell_slots(uint32_t inst) {
     return inst ? (inst + BATCH - 1) / BATCH + 2 * SUBS_PER_CELL : 0u;
 }
 
-// image workspace: reserved.  The per-pixel context of the backward pass (final T, contributor count) moved into
-// the per-batch checkpoints of the bin workspace; the ABI keeps the argument, 256 bytes are enough.
-__host__ __device__ inline uint64_t img_ws_bytes(int, int) { return 256; }
-
-// backward scratch: one Partial per instance.
-__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * sizeof(Partial)); }
+// backward scratch: the three partial-sum arrays (40 bytes per instance).
+__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return 2 * align256(cap * 16) + align256(cap * 8); }
+__host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t cap) {
+    PartialWs w;
+    char* p = static_cast<char*>(base);
+    w.row0 = reinterpret_cast<float4*>(p); p += align256(cap * 16);
+    w.row1 = reinterpret_cast<float4*>(p); p += align256(cap * 16);
+    w.row2 = reinterpret_cast<float2*>(p);
+    return w;
+}
 
 // Launch order of the forward blend: sub-tiles by DESCENDING list length (64 classes of 16 entries), empty ones
 // last.  All non-empty sub-tiles are resident at once (~3.7 waves per SIMD) and the hardware deals consecutive
@@ -204,7 +232,7 @@ __device__ __forceinline__ void wave_lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
-// Host-side launch helpers implemented one per .hip file.
+// Host-side launch helpers implemented one per .hip file.  Every launcher takes K <= MAX_BATCH jobs.
 struct PreprocessArgs {
     int P, sh_M, sh_degree;
     Grid grid;
@@ -214,31 +242,35 @@ struct PreprocessArgs {
     const float* scales; const float* rotations; const float* cov3D_precomp;
     int32_t* radii; Splat* splats; TileWs tw;
 };
-hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s);
+hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
-hipError_t launch_cell_scan(const TileWs& w, const Grid& g, int chunks, hipStream_t s);
-hipError_t launch_cell_scatter(int P, Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
-                               hipStream_t s);
-hipError_t launch_subtile_bin(const Splat* splats, const TileWs& w, const Grid& g, const BinWs& b, uint64_t capacity,
-                              hipStream_t s);
+
+struct BinArgs {           // one job of the binning stages (binning.hip)
+    int P, chunks;
+    Grid grid;
+    Splat* splats; TileWs tw; BinWs bw; uint64_t capacity;
+};
+hipError_t launch_cell_scan(const BinArgs* a, int K, hipStream_t s);
+hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s);
+hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s);
 
 struct RenderFwdArgs {
     Grid grid;
     const Splat* splats; TileWs tw; BinWs bw; uint64_t capacity;
     const float* bg; float* out_color; float* out_depth; float* out_alpha; int store_ctx;
 };
-hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s);
-hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s);
+hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s);
+hipError_t launch_render_fwd(const RenderFwdArgs* a, int K, hipStream_t s);
 
 struct RenderBwdArgs {
     Grid grid; uint64_t capacity; int P;
     const Splat* splats; TileWs tw; BinWs bw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
-    Partial* partials;
+    PartialWs partials;
 };
-hipError_t launch_render_bwd(const RenderBwdArgs& a, hipStream_t s);
+hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s);
 
 struct PreprocessBwdArgs {
     int P, sh_M, sh_degree;
@@ -247,11 +279,14 @@ struct PreprocessBwdArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* means3D; const float* shs; const float* opacities;
     const float* scales; const float* rotations; const float* cov3D_precomp;
-    const int32_t* radii; const Splat* splats; const Partial* partials;
+    const int32_t* radii; const Splat* splats; PartialWs partials; const uint8_t* touched;
+    const ExaRasterHeader* header;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
 };
-hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s);
+// sum_shared != 0: the K jobs are K views of the SAME Gaussians (identical input pointers and P): one thread
+// per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, hipStream_t s);
 hipError_t launch_ssim_fwd(int N, int H, int W, const float* img1, const float* img2, float* map, float* dm_dmu1,
                            float* dm_dE11, float* dm_dE12, hipStream_t s);
 hipError_t launch_ssim_bwd(int N, int H, int W, const float* img1, const float* img2, const float* dL_dmap,

@@ -10,97 +10,135 @@
 // (pixel gradient * (W/2, H/2), z = 0), which is what the reference's densification reads
 // (avatar/main/train.py:51).
 //
-// HBM traffic per Gaussian: reads 48 B per instance + 32 B of the splat record + 44 B inputs,
-// writes 68 B of gradients (SH: + 12 * M B).
+// HBM traffic per Gaussian: reads 1 B per instance + 40 B per BLENDED instance + 32 B of the splat record + 44 B
+// inputs, writes 68 B of gradients (SH: + 12 * M B).
 #include "common.h"
 
 namespace exa {
 
-__global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs a) {
+// One thread per Gaussian.  SUM = false: gridDim.y jobs, each thread handles (job blockIdx.y, Gaussian idx).
+// SUM = true: the K jobs are K views of the SAME Gaussians; the thread walks the views and writes the summed
+// gradient to job 0's outputs (dL_dmeans2D stays per view: the densification statistics need per-view norms,
+// reference avatar/common/nets/module.py:155-157).
+template <bool SUM>
+__global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K) {
+    const PreprocessBwdArgs& out = batch.v[SUM ? 0 : blockIdx.y];
+    if ((int)(blockIdx.x * BLOCK) >= out.P) return;             // workgroup-uniform
     const int idx = blockIdx.x * BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
-    // r3 first: the partial gather depends on it; every other input load is independent and issued before it
-    // is needed (one round trip for the inputs, one for the partials)
-    const uint4 r3 = reinterpret_cast<const uint4*>(a.splats + idx)[3];
-    const bool vis = a.radii[idx] > 0;
+    // NO per-lane early exit: the wave-cooperative gather below needs all 64 lanes, also in the last, partly filled
+    // wave (Gaussians appended by densification sit exactly there)
+    const bool valid = idx < out.P;
+    const int idc = valid ? idx : out.P - 1;                    // clamped index for loads
+    const int lane = threadIdx.x & 63;
     float in_s[3] = {0.f, 0.f, 0.f};
     float4 in_q = make_float4(1.f, 0.f, 0.f, 0.f);
     float in_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (a.cov3D_precomp) {
+    if (out.cov3D_precomp) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) in_cov[i] = a.cov3D_precomp[idx * 6 + i];
+        for (int i = 0; i < 6; ++i) in_cov[i] = out.cov3D_precomp[idc * 6 + i];
     } else {
-        in_s[0] = a.scales[idx * 3 + 0]; in_s[1] = a.scales[idx * 3 + 1]; in_s[2] = a.scales[idx * 3 + 2];
-        in_q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        in_s[0] = out.scales[idc * 3 + 0]; in_s[1] = out.scales[idc * 3 + 1]; in_s[2] = out.scales[idc * 3 + 2];
+        in_q = reinterpret_cast<const float4*>(out.rotations)[idc];
     }
+    const float x = out.means3D[idc * 3 + 0], y = out.means3D[idc * 3 + 1], z = out.means3D[idc * 3 + 2];
 
-    float dmean[3] = {0.f, 0.f, 0.f}, dm2[2] = {0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
+    float dmean[3] = {0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
+    bool sh_init = false;                                       // dL_dsh of this Gaussian already holds an earlier view's values
 
-    const float* __restrict__ v = a.viewmatrix;
-    const float* __restrict__ p = a.projmatrix;
-    const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
+    const int n_views = SUM ? K : 1;
+    for (int view = 0; view < n_views; ++view) {
+        const PreprocessBwdArgs& a = batch.v[SUM ? view : blockIdx.y];
+        const float* __restrict__ v = a.viewmatrix;
+        const float* __restrict__ p = a.projmatrix;
+        // r3 first: the partial gather depends on it
+        const uint4 r3 = reinterpret_cast<const uint4*>(a.splats + idc)[3];
+        // an overflowed forward left no lists behind: every gradient of that view is zero (the overflow itself is
+        // reported to the host through the header, include/exa_raster.h)
+        const bool vis = valid && a.header->overflow == 0u && a.radii[idc] > 0;
+        const uint8_t* __restrict__ touched = a.touched;
+        const float4* __restrict__ row0 = a.partials.row0;
+        const float4* __restrict__ row1 = a.partials.row1;
+        const float2* __restrict__ row2 = a.partials.row2;
 
-    // Large splats (scene Gaussians: hundreds to > 1000 sub-tiles) would turn the per-lane gather below into a
-    // serial tail of hundreds of trips in ONE lane: from COOP_MIN instances on, the whole wave fetches that
-    // Gaussian's partials together -- lane l takes instances l, l + 64, ... (contiguous 48-byte records: coalesced)
-    // -- and the ten sums are reduced across the wave (c5: 286 -> 148 us; no such splat exists in C3).
-    constexpr uint32_t COOP_MIN = 64;
-    float co[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {
-        unsigned long long heavy = __ballot(vis && r3.z >= COOP_MIN);
-        if (__builtin_expect(heavy != 0ull, 0)) {
-            const int lane = threadIdx.x & 63;
-            while (heavy) {                                         // wave-uniform loop
-                const int L = __ffsll((long long)heavy) - 1;
-                heavy &= heavy - 1ull;
-                const uint32_t off = (uint32_t)__shfl((int)r3.w, L, 64), nn = (uint32_t)__shfl((int)r3.z, L, 64);
-                const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)off * 3;
-                float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
-                    const float4 q0 = pp[(size_t)j * 3], q1 = pp[(size_t)j * 3 + 1], q2 = pp[(size_t)j * 3 + 2];
-                    acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
-                    acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
-                    acc[8] += q2.x; acc[9] += q2.y;
-                }
-#pragma unroll
-                for (int k = 0; k < 10; ++k) {
-#pragma unroll
-                    for (int d = 32; d > 0; d >>= 1) acc[k] += __shfl_xor(acc[k], d, 64);
-                    if (lane == L) co[k] = acc[k];
-                }
-            }
-        }
-    }
-
-    if (vis) {
-        // ---- gather this Gaussian's instances (contiguous, written exactly once each) -----------------
-        float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
+        // Large splats (scene Gaussians: hundreds to > 1000 sub-tiles) would turn the per-lane gather below into a
+        // serial tail of hundreds of trips in ONE lane: from COOP_MIN instances on, the whole wave fetches that
+        // Gaussian's partials together -- lane l takes instances l, l + 64, ... -- and the ten sums are reduced
+        // across the wave (c5: 286 -> 148 us; no such splat exists in C3).
+        constexpr uint32_t COOP_MIN = 64;
+        float co[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         {
-            const float4* pp = reinterpret_cast<const float4*>(a.partials) + (size_t)r3.w * 3;
-            // four instances per trip: 12 independent 16-byte loads in flight (a typical avatar splat has ~6)
-            const uint32_t n_own = r3.z < COOP_MIN ? r3.z : 0u;     // larger ones were fetched by the whole wave above
-            for (uint32_t i = 0; i < n_own; i += 4) {
-                float4 q[4][3];
+            unsigned long long heavy = __ballot(vis && r3.z >= COOP_MIN);
+            if (__builtin_expect(heavy != 0ull, 0)) {
+                while (heavy) {                                         // wave-uniform loop, all 64 lanes take part
+                    const int L = __ffsll((long long)heavy) - 1;
+                    heavy &= heavy - 1ull;
+                    const uint32_t off = (uint32_t)__shfl((int)r3.w, L, 64), nn = (uint32_t)__shfl((int)r3.z, L, 64);
+                    float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
+                        if (touched[off + j]) {
+                            const float4 q0 = row0[off + j], q1 = row1[off + j];
+                            const float2 q2 = row2[off + j];
+                            acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
+                            acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
+                            acc[8] += q2.x; acc[9] += q2.y;
+                        }
+                    }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool ok = i + u < n_own;
-                    const float4* src = pp + (size_t)(ok ? i + u : i) * 3;
-                    q[u][0] = src[0]; q[u][1] = src[1]; q[u][2] = src[2];
-                    if (!ok) { q[u][0] = make_float4(0.f, 0.f, 0.f, 0.f); q[u][1] = q[u][0]; q[u][2] = q[u][0]; }
-                }
+                    for (int k = 0; k < 10; ++k) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    mx += q[u][0].x; my += q[u][0].y; mxx += q[u][0].z; mxy += q[u][0].w;
-                    myy += q[u][1].x; dop += q[u][1].y; dcol[0] += q[u][1].z; dcol[1] += q[u][1].w;
-                    dcol[2] += q[u][2].x; dz_view += q[u][2].y;
+                        for (int d = 32; d > 0; d >>= 1) acc[k] += __shfl_xor(acc[k], d, 64);
+                        if (lane == L) co[k] = acc[k];
+                    }
                 }
             }
         }
 
-        mx += co[0]; my += co[1]; mxx += co[2]; mxy += co[3]; myy += co[4];
-        dop += co[5]; dcol[0] += co[6]; dcol[1] += co[7]; dcol[2] += co[8]; dz_view += co[9];
+        float vmean[3] = {0.f, 0.f, 0.f}, vm2[2] = {0.f, 0.f}, vscale[3] = {0.f, 0.f, 0.f};
+        float vq[4] = {0.f, 0.f, 0.f, 0.f}, vcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float vop = 0.f, vcol[3] = {0.f, 0.f, 0.f};
+        if (vis) {
+            // ---- gather this Gaussian's blended instances (contiguous slots, each written at most once) ----------
+            float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
+            {
+                const uint32_t n_own = r3.z < COOP_MIN ? r3.z : 0u;     // larger ones were fetched by the whole wave above
+                const uint32_t off = r3.w;
+                for (uint32_t i = 0; i < n_own; i += 8) {
+                    // the `touched` bytes of eight instances in one round trip (a typical avatar splat has ~6) ...
+                    uint32_t fl = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const bool in = i + u < n_own;
+                        const uint32_t t = touched[off + (in ? i + u : i)];
+                        fl |= (in && t) ? (1u << u) : 0u;
+                    }
+                    // ... then only the flagged records, four at a time: 12 independent loads in flight (an unflagged
+                    // slot re-reads the trip's first record -- a cache hit -- and is masked out)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        if (((fl >> (4 * half)) & 15u) == 0u) continue;
+                        float4 q0[4], q1[4];
+                        float2 q2[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool ok = (fl >> (4 * half + u)) & 1u;
+                            const uint32_t src = off + (ok ? i + 4 * half + u : i);
+                            q0[u] = row0[src]; q1[u] = row1[src]; q2[u] = row2[src];
+                            if (!ok) { q0[u] = make_float4(0.f, 0.f, 0.f, 0.f); q1[u] = q0[u]; q2[u] = make_float2(0.f, 0.f); }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            mx += q0[u].x; my += q0[u].y; mxx += q0[u].z; mxy += q0[u].w;
+                            myy += q1[u].x; vop += q1[u].y; vcol[0] += q1[u].z; vcol[1] += q1[u].w;
+                            vcol[2] += q2[u].x; dz_view += q2[u].y;
+                        }
+                    }
+                }
+            }
+
+            mx += co[0]; my += co[1]; mxx += co[2]; mxy += co[3]; myy += co[4];
+            vop += co[5]; vcol[0] += co[6]; vcol[1] += co[7]; vcol[2] += co[8]; dz_view += co[9];
 
         // ---- recompute the forward quantities ---------------------------------------------------
         const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
@@ -158,7 +196,8 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
         const float cb2 = T0[0] * ST1[0] + T0[1] * ST1[1] + T0[2] * ST1[2];
         const float cc2 = (T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2]) + LOWPASS;
         const float det = ca2 * cc2 - cb2 * cb2;
-        const float idet = 1.0f / det, idet2 = idet * idet;
+        // upstream computeCov2DCUDA (backward): "denom2inv" = 1 / (det^2 + 1e-7), not the exact 1 / det^2
+        const float idet = 1.0f / det, idet2 = 1.0f / (det * det + 1e-7f);
         // moments of s = dL/dG * G  ->  d/d(pixel centre) and d/d(conic) with the raw conic (A, B, C)
         const float cA = cc2 * idet, cB = -cb2 * idet, cC = ca2 * idet;
         const float dpx = -cA * mx - cB * my, dpy = -cC * my - cB * mx;
@@ -183,8 +222,8 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
             dT1[j] = 2.0f * dc * ST1[j] + db * ST0[j];
         }
         if (a.cov3D_precomp) {
-            dcov[0] = G[0]; dcov[1] = G[1] + G[3]; dcov[2] = G[2] + G[6];
-            dcov[3] = G[4]; dcov[4] = G[5] + G[7]; dcov[5] = G[8];
+            vcov[0] = G[0]; vcov[1] = G[1] + G[3]; vcov[2] = G[2] + G[6];
+            vcov[3] = G[4]; vcov[4] = G[5] + G[7]; vcov[5] = G[8];
         } else {
             // Sigma = M M^T, M = R diag(s):  dL/dM = (G + G^T) M
             float M[9], dM[9];
@@ -204,14 +243,14 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
             float dR[9];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                dscale[j] = a.scale_modifier * (dM[0 * 3 + j] * R[0 * 3 + j] + dM[1 * 3 + j] * R[1 * 3 + j] + dM[2 * 3 + j] * R[2 * 3 + j]);
+                vscale[j] = a.scale_modifier * (dM[0 * 3 + j] * R[0 * 3 + j] + dM[1 * 3 + j] * R[1 * 3 + j] + dM[2 * 3 + j] * R[2 * 3 + j]);
 #pragma unroll
                 for (int i = 0; i < 3; ++i) dR[i * 3 + j] = dM[i * 3 + j] * sc[j];
             }
-            dq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
-            dq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - qr * dR[5] + qz * dR[6] + qr * dR[7] - 2.0f * qx * dR[8]);
-            dq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + qr * dR[2] + qx * dR[3] + qz * dR[5] - qr * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
-            dq[3] = 2.0f * (-2.0f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
+            vq[0] = 2.0f * (-qz * dR[1] + qy * dR[2] + qz * dR[3] - qx * dR[5] - qy * dR[6] + qx * dR[7]);
+            vq[1] = 2.0f * (qy * dR[1] + qz * dR[2] + qy * dR[3] - 2.0f * qx * dR[4] - qr * dR[5] + qz * dR[6] + qr * dR[7] - 2.0f * qx * dR[8]);
+            vq[2] = 2.0f * (-2.0f * qy * dR[0] + qx * dR[1] + qr * dR[2] + qx * dR[3] + qz * dR[5] - qr * dR[6] + qz * dR[7] - 2.0f * qy * dR[8]);
+            vq[3] = 2.0f * (-2.0f * qz * dR[0] - qr * dR[1] + qx * dR[2] + qr * dR[3] - 2.0f * qz * dR[4] + qy * dR[5] + qx * dR[6] + qy * dR[7]);
         }
 
         // ---- T = J Rv -> J -> view-space t ---------------------------------------------------------
@@ -225,23 +264,23 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
         const float dtz = -a.focal_x * itz2 * dJ00 - a.focal_y * itz2 * dJ11 +
                           2.0f * a.focal_x * tx * itz3 * dJ02 + 2.0f * a.focal_y * ty * itz3 * dJ12 + dz_view;
         // t = [mu, 1] @ viewmatrix[:, :3]
-        dmean[0] = dtx * v[0] + dty * v[1] + dtz * v[2];
-        dmean[1] = dtx * v[4] + dty * v[5] + dtz * v[6];
-        dmean[2] = dtx * v[8] + dty * v[9] + dtz * v[10];
+        vmean[0] = dtx * v[0] + dty * v[1] + dtz * v[2];
+        vmean[1] = dtx * v[4] + dty * v[5] + dtz * v[6];
+        vmean[2] = dtx * v[8] + dty * v[9] + dtz * v[10];
 
         // ---- pixel centre -> NDC -> clip -> mean ---------------------------------------------------
-        dm2[0] = dpx * 0.5f * a.grid.W;
-        dm2[1] = dpy * 0.5f * a.grid.H;
-        const float dhx = dm2[0] * pw, dhy = dm2[1] * pw;
-        const float dhw = -(dm2[0] * hx + dm2[1] * hy) * pw * pw;
-        dmean[0] += dhx * p[0] + dhy * p[1] + dhw * p[3];
-        dmean[1] += dhx * p[4] + dhy * p[5] + dhw * p[7];
-        dmean[2] += dhx * p[8] + dhy * p[9] + dhw * p[11];
+        vm2[0] = dpx * 0.5f * a.grid.W;
+        vm2[1] = dpy * 0.5f * a.grid.H;
+        const float dhx = vm2[0] * pw, dhy = vm2[1] * pw;
+        const float dhw = -(vm2[0] * hx + vm2[1] * hy) * pw * pw;
+        vmean[0] += dhx * p[0] + dhy * p[1] + dhw * p[3];
+        vmean[1] += dhx * p[4] + dhy * p[5] + dhw * p[7];
+        vmean[2] += dhx * p[8] + dhy * p[9] + dhw * p[11];
 
         // ---- SH colour ---------------------------------------------------------------------------
         if (a.shs) {
-            const uint32_t flags = reinterpret_cast<const uint4*>(a.splats + idx)[2].w;
-            const float g[3] = {(flags & 1u) ? 0.f : dcol[0], (flags & 2u) ? 0.f : dcol[1], (flags & 4u) ? 0.f : dcol[2]};
+            const uint32_t flags = reinterpret_cast<const uint4*>(a.splats + idc)[2].w;
+            const float g[3] = {(flags & 1u) ? 0.f : vcol[0], (flags & 2u) ? 0.f : vcol[1], (flags & 4u) ? 0.f : vcol[2]};
             const float* cp = a.campos;
             const float ux = x - cp[0], uy = y - cp[1], uz = z - cp[2];
             const float inv = 1.0f / sqrtf(ux * ux + uy * uy + uz * uz);
@@ -280,14 +319,17 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
                 }
             }
             const int ncoef = (deg + 1) * (deg + 1);
-            const float* sh = a.shs + (size_t)idx * a.sh_M * 3;
-            float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)idx * a.sh_M * 3 : nullptr;
+            const float* sh = a.shs + (size_t)idc * a.sh_M * 3;
+            float* dsh = out.dL_dsh ? out.dL_dsh + (size_t)idc * a.sh_M * 3 : nullptr;
             float ddirx = 0.f, ddiry = 0.f, ddirz = 0.f;
             for (int k = 0; k < a.sh_M; ++k) {
                 const bool on = k < ncoef && k < 16;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    if (dsh) dsh[k * 3 + c] = on ? basis[k] * g[c] : 0.f;
+                    if (dsh && valid) {
+                        const float val = on ? basis[k] * g[c] : 0.f;
+                        dsh[k * 3 + c] = sh_init ? dsh[k * 3 + c] + val : val;
+                    }
                     if (on) {
                         const float w = sh[k * 3 + c] * g[c];
                         ddirx += bdx[k] * w; ddiry += bdy[k] * w; ddirz += bdz[k] * w;
@@ -296,24 +338,37 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(PreprocessBwdArgs
             }
             // dir = u / |u|
             const float dot = X * ddirx + Y * ddiry + Z * ddirz;
-            dmean[0] += (ddirx - X * dot) * inv;
-            dmean[1] += (ddiry - Y * dot) * inv;
-            dmean[2] += (ddirz - Z * dot) * inv;
+            vmean[0] += (ddirx - X * dot) * inv;
+            vmean[1] += (ddiry - Y * dot) * inv;
+            vmean[2] += (ddirz - Z * dot) * inv;
+            sh_init = true;
         }
-    } else if (a.shs && a.dL_dsh) {
-        float* dsh = a.dL_dsh + (size_t)idx * a.sh_M * 3;
-        for (int k = 0; k < a.sh_M * 3; ++k) dsh[k] = 0.f;
+        }
+        if (valid && a.dL_dmeans2D) {
+            a.dL_dmeans2D[idx * 3 + 0] = vm2[0]; a.dL_dmeans2D[idx * 3 + 1] = vm2[1]; a.dL_dmeans2D[idx * 3 + 2] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dmean[i] += vmean[i]; dscale[i] += vscale[i]; dcol[i] += vcol[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[i] += vq[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dcov[i] += vcov[i];
+        dop += vop;
+    }
+    if (!valid) return;
+    if (!sh_init && out.shs && out.dL_dsh) {                    // never visible: the SH block above did not run
+        float* dsh = out.dL_dsh + (size_t)idx * out.sh_M * 3;
+        for (int k = 0; k < out.sh_M * 3; ++k) dsh[k] = 0.f;
     }
 
-    if (a.dL_dmeans3D) { a.dL_dmeans3D[idx * 3 + 0] = dmean[0]; a.dL_dmeans3D[idx * 3 + 1] = dmean[1]; a.dL_dmeans3D[idx * 3 + 2] = dmean[2]; }
-    if (a.dL_dmeans2D) { a.dL_dmeans2D[idx * 3 + 0] = dm2[0]; a.dL_dmeans2D[idx * 3 + 1] = dm2[1]; a.dL_dmeans2D[idx * 3 + 2] = 0.f; }
-    if (a.dL_dopacity) a.dL_dopacity[idx] = dop;
-    if (a.dL_dcolors) { a.dL_dcolors[idx * 3 + 0] = dcol[0]; a.dL_dcolors[idx * 3 + 1] = dcol[1]; a.dL_dcolors[idx * 3 + 2] = dcol[2]; }
-    if (a.dL_dscales) { a.dL_dscales[idx * 3 + 0] = dscale[0]; a.dL_dscales[idx * 3 + 1] = dscale[1]; a.dL_dscales[idx * 3 + 2] = dscale[2]; }
-    if (a.dL_drotations) reinterpret_cast<float4*>(a.dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-    if (a.dL_dcov3D) {
+    if (out.dL_dmeans3D) { out.dL_dmeans3D[idx * 3 + 0] = dmean[0]; out.dL_dmeans3D[idx * 3 + 1] = dmean[1]; out.dL_dmeans3D[idx * 3 + 2] = dmean[2]; }
+    if (out.dL_dopacity) out.dL_dopacity[idx] = dop;
+    if (out.dL_dcolors) { out.dL_dcolors[idx * 3 + 0] = dcol[0]; out.dL_dcolors[idx * 3 + 1] = dcol[1]; out.dL_dcolors[idx * 3 + 2] = dcol[2]; }
+    if (out.dL_dscales) { out.dL_dscales[idx * 3 + 0] = dscale[0]; out.dL_dscales[idx * 3 + 1] = dscale[1]; out.dL_dscales[idx * 3 + 2] = dscale[2]; }
+    if (out.dL_drotations) reinterpret_cast<float4*>(out.dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    if (out.dL_dcov3D) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) a.dL_dcov3D[idx * 6 + i] = dcov[i];
+        for (int i = 0; i < 6; ++i) out.dL_dcov3D[idx * 6 + i] = dcov[i];
     }
 }
 
@@ -341,9 +396,14 @@ hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, f
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t s) {
-    if (a.P == 0) return hipSuccess;
-    preprocess_bwd_kernel<<<(a.P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(a);
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, hipStream_t s) {
+    int P = 0;
+    for (int k = 0; k < K; ++k) P = max(P, a[k].P);
+    if (P == 0) return hipSuccess;
+    if (sum_shared)
+        preprocess_bwd_kernel<true><<<dim3((P + BLOCK - 1) / BLOCK, 1), BLOCK, 0, s>>>(make_batch(a, K), K);
+    else
+        preprocess_bwd_kernel<false><<<dim3((P + BLOCK - 1) / BLOCK, K), BLOCK, 0, s>>>(make_batch(a, K), K);
     return hipGetLastError();
 }
 

@@ -216,9 +216,11 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
 // MI355X and ~150 chunks adding into the same few dozen cell counters serialise at the memory side
 // (that tail was ~8 us of this kernel).  cell_scan_kernel sums the columns.
 constexpr int PBLOCK = 1024;           // threads per chunk: one Gaussian each (no atomics left to contend on)
-__global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(PreprocessArgs a) {
+__global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<PreprocessArgs> batch) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_cell[];   // [cells]
     __shared__ uint32_t s_red[PBLOCK / 64];
+    const PreprocessArgs& a = batch.v[blockIdx.y];              // this workgroup's job (kernarg segment: scalar loads)
+    if ((int)blockIdx.x >= num_chunks(a.P)) return;             // a job with fewer Gaussians than the largest of the batch
     const int tid = threadIdx.x;
     for (int c = tid; c < a.grid.cells; c += PBLOCK) s_cell[c] = 0ull;
     __syncthreads();
@@ -274,9 +276,17 @@ __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float*
     present[idx] = pvz > NEAR_CULL ? 1 : 0;
 }
 
-hipError_t launch_preprocess_fwd(const PreprocessArgs& a, hipStream_t s) {
-    if (a.P == 0) return hipSuccess;
-    preprocess_fwd_kernel<<<num_chunks(a.P), PBLOCK, (size_t)a.grid.cells * 8, s>>>(a);
+hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s) {
+    Batch<PreprocessArgs> b;
+    int chunks = 0, cells = 0;
+    for (int k = 0; k < K; ++k) {
+        b.v[k] = a[k];
+        chunks = max(chunks, num_chunks(a[k].P));
+        cells = max(cells, a[k].grid.cells);
+    }
+    for (int k = K; k < MAX_BATCH; ++k) b.v[k] = a[0];
+    if (chunks == 0) return hipSuccess;
+    preprocess_fwd_kernel<<<dim3(chunks, K), PBLOCK, (size_t)cells * 8, s>>>(b);
     return hipGetLastError();
 }
 

@@ -1,32 +1,40 @@
-// Per-batch backward of the alpha compositing for gfx950 -- atomic-free, one wave per 64-splat batch.
+// Per-batch backward of the alpha compositing for gfx950 -- atomic-free, one wave per 64-entry batch.
 //
 // Unit of work = a BATCH SLOT: 64 consecutive entries of one sub-tile's sorted list x the 64 pixels of that
 // sub-tile.  The forward pass checkpoints the per-pixel state (T, C_rgb, depth; stopped pixels as -T) at the
 // start of every batch and at its exit, so every batch of every sub-tile runs concurrently and the longest
 // dependent chain is 64 splats (a kernel that walks whole lists with one wave is bound by its longest list).
 //
-// The kernel is bound by VALU issue and per-wave latency (profiles/: VALU-active ~29 % of the wave cycles at ~3
-// waves per SIMD; HBM < 10 % of peak), so the design minimises instructions per (pixel, splat) pair.  Two phases
-// per chunk of GC = 16 splats (8 and 32 measured slower):
+// COMPACTION.  The forward pass also leaves one 64-bit mask per batch: which entries it blended into at least one
+// pixel.  An entry that touched no live pixel is the identity of the recurrence (alpha_eff = 0 everywhere) and gets
+// no gradient, so the backward pass drops it before doing anything else: the flagged entries are staged densely in
+// LDS (rank = mbcnt of the mask) and everything below runs on that shorter list.  On avatar-like scenes (opaque,
+// small splats) only ~60 % of the entries of the batches the forward enters survive, ~46 % of all instances
+// (C3, ring view 0: 893 k instances, 690 k in entered batches, 409 k blended).  Skip decisions depend on alpha only and
+// stay bit-identical to the forward's; the transmittance is re-multiplied in a different grouping of four, i.e. may
+// differ from the forward's by an ulp, which can move a `T < 1e-4` stop only when T (1 - alpha) lies within ~1e-7
+// (relative) of the threshold, with an effect of <= 1e-4 on that pixel's weights -- far inside the 1e-3 bar.
+//
+// The kernel is bound by VALU issue (profiles/: ~80 % of the issue slots with ~3 waves per SIMD; HBM < 10 % of
+// peak), so the design minimises instructions per (pixel, splat) pair.  Two phases per chunk of GC = 16 splats:
 //
 //  Phase A  (lane = pixel, splats in list order): REPLAY the forward recurrence from the checkpoint with the
 //           forward's own code (blend.h) -- no 1/(1-alpha) reconstruction of T, no `n_contrib` array -- and
 //           get dL/d(alpha_i) from a running scalar instead of per-channel suffix colours:
 //               R_i = (C_fin - C_i) . g - tail,      tail = T_fin (g_alpha - bg . g)
 //               dL/d(alpha_i) = T_i (c_i . g) - R_{i+1} / (1 - alpha_i)
-//           ("." also runs over the depth channel).  Two numbers per pair go to LDS: aG = G dL/dalpha and the
-//           blend weight w = alpha T.
-//  Phase B  (lane = splat, loop over pixels): the transposed read of those numbers turns the ten per-splat
-//           sums over the 64 pixels (five screen-space moments of aG, sum aG, and w-weighted pixel gradients)
-//           into plain per-lane accumulation: ~14 VALU per pixel step for GC splats at once, versus a
-//           ~58-instruction cross-lane butterfly PER SPLAT in the previous version of this kernel
-//           (120 -> 90 us).  64 / GC pixel groups run side by side and are combined with log2(64 / GC) shuffle
-//           steps.  (The same phase as a GEMM on v_mfma_f32_16x16x4_f32 was tried: fp32 MFMA runs at the vector
-//           rate, 32 cycles per instruction, and the wave waits for it -- 20 % slower.)
+//           ("." also runs over the depth channel).  Two numbers per pair go to LDS as one 8-byte store:
+//           aG = G dL/dalpha and the blend weight w = alpha T.
+//  Phase B  (lane = splat g, pixel group h of 16 pixels): the transposed read (ds_read_b128, row stride 36 floats:
+//           conflict-free) turns the per-splat sums over the 64 pixels into per-lane accumulation.  The screen-space
+//           moments are accumulated against COMPILE-TIME pixel coordinates (x - 4 in -4..3, row 0 / 1 of the group):
+//           sum aG, sum aG x, sum aG x^2, sum aG y, sum aG x y -- 3.7 VALU per pixel instead of 8 with per-lane
+//           dx, dy -- and shifted to the splat centre once per chunk; + 3 (4) FMAs for the colour (depth) sums.
+//           The four pixel groups are combined with two shuffle steps.
 //
-// Every instance gets its 48-byte Gaussian-major `Partial` written exactly once (zeros when nothing
-// contributed): no memset, NO atomic in the whole backward pass (device-scope fp32 atomics run at ~12 G/s on
-// MI355X), bit-deterministic.
+// Only blended instances get their 40-byte Gaussian-major partial record written (exactly once: no memset, NO atomic
+// in the whole backward pass -- device-scope fp32 atomics run at ~12 G/s on MI355X -- bit-deterministic) and their
+// `touched` byte set; preprocess_bwd.hip reads the bytes and fetches only those records.
 //
 // Replaces upstream BACKWARD::renderCUDA of the rasterizer behind reference
 // avatar/common/nets/module.py:632-640 (backward reached from avatar/main/train.py:46).
@@ -34,50 +42,69 @@
 // min(0.99, .).  The screen-space gradients are emitted as five moments of s = dL/dG * G
 // (sum s dx, s dy, s dx^2, s dx dy, s dy^2); preprocess_bwd.hip turns them into d/d(mean2D, conic).
 //
-// Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered splat, 12 (+8) B/pixel of
-// incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 48 B per instance.
+// Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered (blended) splat, 12 (+8) B/pixel of
+// incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 41 B per blended instance.
 #include "blend.h"
 
 namespace exa {
 
 constexpr int RBLOCK = 64;            // ONE wave per workgroup
-constexpr int XS = 65;                // row stride (floats) of the transposition buffers: odd, so that the
-                                      // column reads of phase B hit 32 different banks
+constexpr int GC = 16;                // splats per chunk
+constexpr int XROW = 36;              // floats per (pixel group, splat) row of the transposition buffer: 16 pixels x
+                                      // {aG, w} + 4 pad -> the 16 rows read together by ds_read_b128 start 9 quads
+                                      // apart: all 64 banks, no conflict
+constexpr int XGROUP = GC * XROW;     // floats per pixel group
 
-template <int GC>
-__global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
-    static_assert(GC == 16 || GC == 32, "chunk = 16 or 32 splats");
+__device__ __forceinline__ int mask_rank(uint32_t lo, uint32_t hi) {          // set bits of (hi:lo) below this lane
+    return (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+}
+
+template <bool HAS_DEPTH>
+__global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
     __shared__ BatchLds s_b;
-    __shared__ float4 s_pg[64];                 // incoming gradient of each pixel: r, g, b, depth
+    __shared__ float4 s_pg[4 * 17];             // incoming gradient of each pixel (r, g, b, depth), 16 per pixel group;
+                                                // group stride 17: the two groups one ds_read_b128 quarter-wave sees
+                                                // sit on different banks
     __shared__ uint32_t s_pslot[64];            // Partial slot of each staged splat
-    __shared__ float s_xa[GC * XS];             // aG[splat][pixel]
-    __shared__ float s_xw[GC * XS];             // w[splat][pixel]
+    __shared__ __attribute__((aligned(16))) float s_x[4 * XGROUP];   // {aG, w}[pixel group][splat][pixel of the group]
 
+    const RenderBwdArgs& a = batch.v[blockIdx.y];
+    const uint32_t slot = blockIdx.x;
+    if ((uint64_t)slot >= a.capacity / BATCH) return;           // a job with a smaller instance space than the largest
     const int lane = threadIdx.x;
-    // Round trip 1: the owner record and -- speculatively, the instance space being 64-aligned per sub-tile --
-    // this slot's 64 sorted ids (garbage past the end of the list; clamped before use).
-    const uint4 own = a.bw.owner[blockIdx.x];
-    const uint32_t id_raw = a.bw.sorted[(size_t)blockIdx.x * BATCH + lane];
-    if (own.x == 0) return;                                     // unused batch slot
+    // Round trip 1: the owner record, the batch's blended mask and -- speculatively, the instance space being
+    // 64-aligned per sub-tile -- this slot's 64 sorted ids (garbage past the end of the list; only flagged lanes use theirs).
+    const uint4 own = a.bw.owner[slot];
+    const unsigned long long bm_v = a.bw.bmask[slot];
+    const uint32_t id_raw = a.bw.sorted[(size_t)slot * BATCH + lane];
+    const uint32_t bm_lo = __builtin_amdgcn_readfirstlane((uint32_t)bm_v);
+    const uint32_t bm_hi = __builtin_amdgcn_readfirstlane((uint32_t)(bm_v >> 32));
+    if (own.x == 0 || (bm_lo | bm_hi) == 0u) return;            // unused / end slot, or nothing of this batch was blended
     const int st = (int)own.x - 1;
     const int n = (int)own.z;
     const int b0 = (int)(own.y / BATCH);                        // first slot of the sub-tile
-    const int bq = (int)blockIdx.x - b0;                        // batch index inside the sub-tile
-    const int bstart = bq * BATCH;
-    const int cnt = min(BATCH, n - bstart);
-    // Round trip 2: everything else (records, batches entered, checkpoints, pixel gradients) is issued together.
-    const int entered = (int)a.tw.fwd_exit[st].y;               // batches the forward pass walked into
+    const int bq = (int)slot - b0;                              // batch index inside the sub-tile
+    const int cnt = __popc(bm_lo) + __popc(bm_hi);              // blended entries of this batch
+    const bool flagged = (((lane < 32 ? bm_lo : bm_hi) >> (lane & 31)) & 1u) != 0u;
+    const int below = mask_rank(bm_lo, bm_hi);
+    const int dst = flagged ? below : cnt + (lane - below);     // a permutation of 0..63: blended entries first, in order
+
+    // Round trip 2: everything else (records, checkpoints, pixel gradients) is issued together.
     const SubTile sub = decode_subtile(st, a.grid);
-    float4* __restrict__ partials = reinterpret_cast<float4*>(a.partials);
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* rec = reinterpret_cast<const float4*>(a.splats + min(id_raw, (uint32_t)(a.P - 1)));
-    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-    const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
+    float4 r0 = zero4, r1 = zero4, r2 = zero4;
+    uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
+    if (flagged) {
+        const float4* rec = reinterpret_cast<const float4*>(a.splats + min(id_raw, (uint32_t)(a.P - 1)));
+        r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+        r3 = reinterpret_cast<const uint4*>(rec)[3];
+    }
     // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
     const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;
-    const float* cs = a.bw.ckpt + (size_t)blockIdx.x * (5 * 64) + lane;
-    const float cs0 = cs[0], cs1 = cs[64], cs2 = cs[128], cs3 = cs[192], cs4 = cs[256];    // unused for batch 0
-    const float cf0 = cf[0], cf1 = cf[64], cf2 = cf[128], cf3 = cf[192], cf4 = cf[256];
+    const float* cs = a.bw.ckpt + (size_t)slot * (5 * 64) + lane;
+    float cs0 = 1.0f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cs4 = 0.f;
+    if (bq > 0) { cs0 = cs[0]; cs1 = cs[64]; cs2 = cs[128]; cs3 = cs[192]; cs4 = HAS_DEPTH ? cs[256] : 0.f; }
+    const float cf0 = cf[0], cf1 = cf[64], cf2 = cf[128], cf3 = cf[192], cf4 = HAS_DEPTH ? cf[256] : 0.f;
 
     // ---- per-pixel set-up --------------------------------------------------------------------------
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
@@ -90,30 +117,19 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
         gr = a.dL_dcolor[pix];
         gg = a.dL_dcolor[HW + pix];
         gb = a.dL_dcolor[2 * HW + pix];
-        if (a.dL_ddepth) gd = a.dL_ddepth[pix];
+        if (HAS_DEPTH && a.dL_ddepth) gd = a.dL_ddepth[pix];
         if (a.dL_dalpha) ga = a.dL_dalpha[pix];
     }
 
     uint32_t pslot = 0;
-    if (lane < cnt) {
+    if (flagged) {
         const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
         pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
     }
-    if (bq >= entered) {                                        // every pixel had stopped before this batch
-        if (lane < cnt) {
-            float4* dst = partials + (size_t)pslot * 3;
-            dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
-        }
-        return;
-    }
-    if (lane < cnt) {
-        stage_splat(s_b, lane, r0, r1, r2);
-        s_pslot[lane] = pslot;
-    } else {                                                    // past the end of the list: all-zero record (alpha 0)
-        stage_splat(s_b, lane, zero4, zero4, zero4);
-    }
+    stage_splat(s_b, dst, r0, r1, r2);                          // unflagged lanes stage all-zero records (alpha 0) behind the list
+    s_pslot[dst] = pslot;
+    s_pg[(lane >> 4) * 17 + (lane & 15)] = make_float4(gr, gg, gb, gd);
 
-    s_pg[lane] = make_float4(gr, gg, gb, gd);
     float T = 1.0f, live = inside ? 1.0f : 0.0f;
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
     if (bq > 0) {
@@ -125,96 +141,110 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(RenderBwdArgs a) {
     const float* __restrict__ bg = a.bg;
     // d/d(alpha_i) of [T_final * bg . g] and of [ga * (1 - T_final)]:  (T_final / (1 - alpha_i)) * (ga - bg.g)
     const float tail = T_final * (ga - (bg[0] * gr + bg[1] * gg + bg[2] * gb));
-    float R = (cf1 - sr) * gr + (cf2 - sg) * gg + (cf3 - sb) * gb + (cf4 - sd) * gd - tail;
+    float R = (cf1 - sr) * gr + (cf2 - sg) * gg + (cf3 - sb) * gb - tail;
+    if (HAS_DEPTH) R = fmaf(cf4 - sd, gd, R);
     wave_lds_fence();
 
-    const int g = lane % GC, h = lane / GC;
+    const int g = lane & (GC - 1), h = lane >> 4;               // phase B role: splat g of the chunk, pixel group h
+    float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane >> 4) * XGROUP + 2 * (lane & 15));   // phase A: my column
+    const float4* const xr_row = reinterpret_cast<const float4*>(s_x + h * XGROUP + g * XROW);          // phase B: my row
+    float4* __restrict__ prow0 = a.partials.row0;
+    float4* __restrict__ prow1 = a.partials.row1;
+    float2* __restrict__ prow2 = a.partials.row2;
+    uint8_t* __restrict__ touched = a.bw.touched;
+
     for (int c0 = 0; c0 < cnt; c0 += GC) {
+        if (__all(live == 0.0f)) break;                         // (only after a 1e-7-probability stop flip, see header)
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
-        bool any_contrib = false;
-        if (!__all(live == 0.0f)) {
+        {
             Ops4 cur = load_ops4(s_b, c0);
             for (int k = c0; k < cend; k += 4) {
                 const Ops4 nxt = load_ops4(s_b, (k + 4) & 63);   // next group's operands: in flight during this one
                 const float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
                 const Alpha4 e = splat_alpha4(cur, fx, fy);
                 cur = nxt;
-                const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
-                float* xa = s_xa + (k - c0) * XS + lane;
-                float* xw = s_xw + (k - c0) * XS + lane;
-                if (__any(amax > 0.0f)) {
-                    any_contrib = true;
-                    float aeff[4], Tb[4], w[4];
-                    blend_group4(T, live, e.alpha, aeff, Tb, w);
+                float aeff[4], Tb[4], w[4];
+                blend_group4(T, live, e.alpha, aeff, Tb, w);
+                float2* x = xw_row + (k - c0) * (XROW / 2);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 c = col[u];
-                        const float cg = fmaf(c.w, gd, fmaf(c.z, gb, fmaf(c.y, gg, c.x * gr)));
-                        R = fmaf(-cg, w[u], R);                                  // R_{i+1}
-                        const float inv = __builtin_amdgcn_rcpf(1.0f - aeff[u]);
-                        const float dLda = fmaf(Tb[u], cg, -(R * inv));
-                        xa[u * XS] = w[u] > 0.0f ? e.G[u] * dLda : 0.0f;
-                        xw[u * XS] = w[u];
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { xa[u * XS] = 0.0f; xw[u * XS] = 0.0f; }
+                for (int u = 0; u < 4; ++u) {
+                    const float4 c = col[u];
+                    float cg = fmaf(c.z, gb, fmaf(c.y, gg, c.x * gr));
+                    if (HAS_DEPTH) cg = fmaf(c.w, gd, cg);
+                    R = fmaf(-cg, w[u], R);                                  // R_{i+1}
+                    const float inv = __builtin_amdgcn_rcpf(1.0f - aeff[u]);
+                    const float dLda = fmaf(Tb[u], cg, -(R * inv));
+                    x[u * (XROW / 2)] = make_float2(w[u] > 0.0f ? e.G[u] * dLda : 0.0f, w[u]);
                 }
             }
         }
-        if (!any_contrib) {                                     // uniform: nothing of this chunk was blended
-            if (lane < cend - c0) {
-                float4* dst = partials + (size_t)s_pslot[c0 + lane] * 3;
-                dst[0] = zero4; dst[1] = zero4; dst[2] = zero4;
-            }
-            continue;
-        }
         wave_lds_fence();
-        // ---- phase B: lane = (splat g of the chunk, pixel group h) ------------------------------------
+        // ---- phase B: lane = (splat g of the chunk, pixel group h = pixel rows 2h, 2h + 1) -------------------
         {
             const int kk = c0 + g;                              // rows >= cend hold stale data: never stored
-            const float gx = s_b.px[kk], gy = s_b.py[kk];
-            const float fx0 = (float)sub.ox, fy0 = (float)(sub.oy + h * (GC / 8));
-            const float* xa = s_xa + g * XS + h * GC;
-            const float* xw = s_xw + g * XS + h * GC;
-            float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dop = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dz = 0.f;
+            float S0 = 0.f, Sx = 0.f, Sxx = 0.f, Sy = 0.f, Sxy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dz = 0.f;
 #pragma unroll
-            for (int q = 0; q < GC; ++q) {
-                const float aG = xa[q], w = xw[q];
-                const float4 pg = s_pg[h * GC + q];
-                const float dx = gx - (fx0 + (float)(q & 7));
-                const float dy = gy - (fy0 + (float)(q >> 3));
-                const float sdx = aG * dx, sdy = aG * dy;
-                mx += sdx; my += sdy;
-                mxx = fmaf(sdx, dx, mxx); mxy = fmaf(sdx, dy, mxy); myy = fmaf(sdy, dy, myy);
-                dop += aG;
-                dr = fmaf(w, pg.x, dr); dg = fmaf(w, pg.y, dg); db = fmaf(w, pg.z, db); dz = fmaf(w, pg.w, dz);
+            for (int j = 0; j < 8; ++j) {
+                const float4 v = xr_row[j];                     // {aG, w} of pixels q = 2j, 2j + 1 of the group
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int q = 2 * j + t;
+                    const float aG = t ? v.z : v.x, wq = t ? v.w : v.y;
+                    const float4 pg = s_pg[h * 17 + q];
+                    const float X = (float)((q & 7) - 4);       // compile-time pixel coordinates (about column 4, row 2h)
+                    S0 += aG;
+                    if ((q & 7) != 4) { Sx = fmaf(aG, X, Sx); Sxx = fmaf(aG, X * X, Sxx); }
+                    if (q >> 3) {
+                        Sy += aG;
+                        if ((q & 7) != 4) Sxy = fmaf(aG, X, Sxy);
+                    }
+                    dr = fmaf(wq, pg.x, dr); dg = fmaf(wq, pg.y, dg); db = fmaf(wq, pg.z, db);
+                    if (HAS_DEPTH) dz = fmaf(wq, pg.w, dz);
+                }
             }
+            // moments about the splat centre: d = (gx, gy) - pixel;  with u = gx - (ox + 4), v = gy - (oy + 2h):
+            //   sum aG dx = u S0 - Sx, sum aG dy = v S0 - Sy, sum aG dx^2 = u (u S0 - 2 Sx) + Sxx, ...  (Syy = Sy)
+            const float u0 = s_b.px[kk] - (float)(sub.ox + 4), v0 = s_b.py[kk] - (float)(sub.oy + 2 * h);
+            float mx = fmaf(u0, S0, -Sx), my = fmaf(v0, S0, -Sy);
+            float mxx = fmaf(u0, mx - Sx, Sxx);
+            float mxy = fmaf(v0, mx, fmaf(-u0, Sy, Sxy));
+            float myy = fmaf(v0, my - Sy, Sy);
+            float dop = S0;
 #pragma unroll
             for (int d = GC; d < 64; d <<= 1) {
                 mx += __shfl_xor(mx, d, 64); my += __shfl_xor(my, d, 64);
                 mxx += __shfl_xor(mxx, d, 64); mxy += __shfl_xor(mxy, d, 64); myy += __shfl_xor(myy, d, 64);
                 dop += __shfl_xor(dop, d, 64);
                 dr += __shfl_xor(dr, d, 64); dg += __shfl_xor(dg, d, 64);
-                db += __shfl_xor(db, d, 64); dz += __shfl_xor(dz, d, 64);
+                db += __shfl_xor(db, d, 64);
+                if (HAS_DEPTH) dz += __shfl_xor(dz, d, 64);
             }
             if (h == 0 && kk < cend) {
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
-                float4* dst = partials + (size_t)s_pslot[kk] * 3;
-                dst[0] = make_float4(o * mx, o * my, o * mxx, o * mxy);
-                dst[1] = make_float4(o * myy, dop, dr, dg);
-                dst[2] = make_float4(db, dz, 0.f, 0.f);
+                const uint32_t ps = s_pslot[kk];
+                prow0[ps] = make_float4(o * mx, o * my, o * mxx, o * mxy);
+                prow1[ps] = make_float4(o * myy, dop, dr, dg);
+                prow2[ps] = make_float2(db, dz);
+                touched[ps] = (uint8_t)1;
             }
         }
-        wave_lds_fence();                                       // the next chunk overwrites s_xa / s_xw
+        wave_lds_fence();                                       // the next chunk overwrites s_x
     }
 }
 
-hipError_t launch_render_bwd(const RenderBwdArgs& a, hipStream_t s) {
-    const uint64_t slots = a.capacity / BATCH;
+hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
+    uint64_t slots = 0;
+    bool depth = false;
+    for (int k = 0; k < K; ++k) {
+        slots = a[k].capacity / BATCH > slots ? a[k].capacity / BATCH : slots;
+        depth = depth || a[k].dL_ddepth != nullptr;
+    }
     if (slots == 0) return hipSuccess;
-    render_bwd_kernel<16><<<(unsigned)slots, RBLOCK, 0, s>>>(a);
+    if (depth)
+        render_bwd_kernel<true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(make_batch(a, K));
+    else
+        render_bwd_kernel<false><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(make_batch(a, K));
     return hipGetLastError();
 }
 

@@ -20,6 +20,7 @@
 // Algorithmic HBM bytes: sort reads 8 B/instance, writes 4 B/instance; blend reads 4 B/instance + 48 B per
 // gathered splat per sub-tile it touches (L2-resident after the first touch), writes 20 B/pixel
 // (rgb, depth, alpha) + 20 B/pixel of checkpoint per batch entered (training only).
+#include <stdlib.h>
 #include "blend.h"
 
 namespace exa {
@@ -255,8 +256,10 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
     }
 }
 
-__global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) {
+__global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
+    const RenderFwdArgs& a = batch.v[blockIdx.y];
+    if ((int)blockIdx.x >= a.grid.subtiles + ORDER_WGS) return;   // a job with a smaller image than the largest of the batch
     const int tid = threadIdx.x;
     if (blockIdx.x < ORDER_WGS) {
         order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid);
@@ -292,9 +295,11 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(RenderFwdArgs a) 
 
 // ---- blend ---------------------------------------------------------------------------------------------
 template <bool STORE>
-__global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
+__global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ BatchLds s_b;
 
+    const RenderFwdArgs& a = batch.v[blockIdx.y];
+    if ((int)blockIdx.x >= a.grid.subtiles) return;
     const int lane = threadIdx.x;
 #ifdef EXA_PROBE_FWD
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -354,6 +359,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
         }
         wave_lds_fence();
         const int cnt = min(64, n - base);
+        // training: which entries of this batch were blended into at least one pixel (alpha > 0 at a live pixel; the
+        // entry that stops a pixel counts).  The backward pass replays exactly those: on avatar-like scenes only
+        // ~60 % of the entries of the batches the forward enters (tools/cpu_blend_stats.py).
+        unsigned long long blended = 0ull;
         Ops4 cur = load_ops4(s_b, 0);
         for (int k = 0; k < cnt; k += 4) {
             const Ops4 nxt = load_ops4(s_b, (k + 4) & 63);       // operands of the next group: in flight during this one
@@ -364,6 +373,11 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
             if (__any(amax > 0.0f)) {
                 float aeff[4], Tb[4], w[4];
                 blend_group4(T, live, e.alpha, aeff, Tb, w);
+                if (STORE) {                                     // wave-uniform bits: v_cmp into an SGPR pair + scalar ops
+                    const uint32_t nib = (__ballot(aeff[0] > 0.0f) ? 1u : 0u) | (__ballot(aeff[1] > 0.0f) ? 2u : 0u) |
+                                         (__ballot(aeff[2] > 0.0f) ? 4u : 0u) | (__ballot(aeff[3] > 0.0f) ? 8u : 0u);
+                    blended |= (unsigned long long)nib << k;
+                }
                 Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
                 Cbd = __builtin_elementwise_fma(v2f{c0.z, c0.w}, v2f{w[0], w[0]}, Cbd);
                 Crg = __builtin_elementwise_fma(v2f{c1.x, c1.y}, v2f{w[1], w[1]}, Crg);
@@ -375,6 +389,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
                 if (__all(live == 0.0f)) break;
             }
         }
+        if (STORE && lane == 0) a.bw.bmask[range.x / BATCH + (uint32_t)(entered - 1)] = blended;
         wave_lds_fence();
     }
 
@@ -407,18 +422,30 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(RenderFwdArgs a) {
     }
 }
 
-hipError_t launch_sort_subtiles(const RenderFwdArgs& a, hipStream_t s) {
-    if (a.grid.subtiles == 0) return hipSuccess;
-    sort_subtiles_kernel<<<a.grid.subtiles + ORDER_WGS, SBLOCK, 0, s>>>(a);
+static int max_subtiles(const RenderFwdArgs* a, int K) {
+    int n = 0;
+    for (int k = 0; k < K; ++k) n = max(n, a[k].grid.subtiles);
+    return n;
+}
+
+hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
+    const int subtiles = max_subtiles(a, K);
+    if (subtiles == 0) return hipSuccess;
+    sort_subtiles_kernel<<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
     return hipGetLastError();
 }
 
-hipError_t launch_render_fwd(const RenderFwdArgs& a, hipStream_t s) {
-    if (a.grid.subtiles == 0) return hipSuccess;
-    if (a.store_ctx)
-        render_fwd_kernel<true><<<a.grid.subtiles, RBLOCK, 0, s>>>(a);
+// All jobs of a batch share store_ctx (checked by the C ABI).  EXA_FWD_LDS_PAD (bytes, developer knob) adds unused
+// dynamic LDS per workgroup: fewer resident waves per CU, so that the tail of the length-sorted launch is dealt out
+// dynamically as earlier waves retire instead of all sub-tiles being placed at once.
+hipError_t launch_render_fwd(const RenderFwdArgs* a, int K, hipStream_t s) {
+    const int subtiles = max_subtiles(a, K);
+    if (subtiles == 0) return hipSuccess;
+    static const int pad = [] { const char* e = getenv("EXA_FWD_LDS_PAD"); return e ? atoi(e) : 0; }();
+    if (a[0].store_ctx)
+        render_fwd_kernel<true><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
     else
-        render_fwd_kernel<false><<<a.grid.subtiles, RBLOCK, 0, s>>>(a);
+        render_fwd_kernel<false><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
     return hipGetLastError();
 }
 

@@ -8,16 +8,25 @@ and the same ``(color, radii, depth, alpha)`` return order (module.py:632-640), 
 ``torch.autograd.Function`` over the C ABI of ``libexa_raster.so`` (hand-written HIP for gfx950).
 Tensors stay PyTorch-ROCm tensors; only raw device pointers cross the boundary.
 
-Instance-buffer sizing.  The number of (Gaussian, tile) instances D is only known on the device
-after the binning stage.  Two policies (``config.mode``):
+One autograd node serves K >= 1 renders ("jobs"): ``rasterize_gaussians`` is a batch of one,
+``rasterize_gaussians_batch`` puts K renders -- K training views of the same Gaussians, or the five
+same-camera renders of an ExAvatar iteration (``avatar/main/model.py:119-167``) -- into ONE launch per
+pipeline stage (``exa_raster_*_batch``, include/exa_raster.h).
 
-* ``'exact'`` (default, what upstream does): stage 1, read D back (16-byte D2H copy, one stream
-  sync), allocate exactly, stage 2.
+Instance-buffer sizing.  The number of (Gaussian, tile) instances D is only known on the device
+after the binning stage.  Policies (``config.mode``):
+
+* ``'exact'`` (what upstream does): stage 1, read D back (16-byte D2H copy, one stream sync),
+  allocate exactly, stage 2.
 * ``'capacity'``: one fused call with a buffer sized from the D of earlier calls of the same shape
   (x ``config.capacity_growth``; the first call of a shape runs in exact mode to measure D), or from
   ``config.fixed_capacity``; no host sync and hipGraph-capturable.  An overflow is latched on
-  the device, surfaced by :func:`check_overflow` (also called at the start of every later call
-  once the asynchronous read-back has landed) and raises ``RuntimeError``.
+  the device: the forward outputs of that call are invalid and its backward writes zero gradients.  It
+  is surfaced (``RuntimeError``) by the render's own ``backward`` before any gradient is returned, by
+  :func:`check_overflow`, and at the start of every later call once the asynchronous read-back has landed.
+* ``'auto'`` (default): ``'capacity'`` for renders that will be differentiated (the training loop: the
+  overflow check sits in ``backward``, so an optimizer step never sees gradients of an overflowed render)
+  and under stream capture, ``'exact'`` for ``torch.no_grad()`` renders.
 """
 import ctypes
 from typing import NamedTuple
@@ -44,22 +53,26 @@ class GaussianRasterizationSettings(NamedTuple):
 
 
 class _Config:
-    mode = 'exact'            # 'exact' | 'capacity'
+    mode = 'auto'             # 'auto' | 'exact' | 'capacity'
     capacity_growth = 1.5     # capacity mode: head-room over the largest D seen so far
     min_capacity = 1 << 16
     fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up)
+    keep_debug = False        # developer probes: keep the workspaces of the most recent forward reachable
 
 
 config = _Config()
 
-# capacity-mode state, per (device index, P, H, W): largest D observed, pending async read-backs
-_debug_last = {}   # tile workspace / capacity of the most recent forward (developer introspection only)
-_seen_D = {}
-_pending = []     # list of (event, pinned header tensor, key, capacity)
+_debug_last = {}  # only filled when config.keep_debug (tools/): workspaces of the most recent forward
+_seen_D = {}      # (device index, P, H, W) -> largest instance capacity a call of that shape needed
+_pending = []     # capacity-mode calls without a backward: (event, pinned header rows, [(key, capacity)])
 
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _addr(t):
+    return t.data_ptr() if t is not None else None
 
 
 def _f32c(t, name, device):
@@ -71,7 +84,7 @@ def _f32c(t, name, device):
         raise ValueError('%s is on %s, expected %s' % (name, t.device, device))
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    return t if t.is_contiguous() else t.contiguous()
 
 
 def _stream_ptr(device):
@@ -91,32 +104,36 @@ def _make_settings(rs, device, keep):
     s.debug = int(bool(rs.debug))
     for name in ('bg', 'viewmatrix', 'projmatrix', 'campos'):
         t = getattr(rs, name)
-        if not isinstance(t, torch.Tensor):
-            t = torch.as_tensor(t, dtype=torch.float32)
-        t = t.to(device=device, dtype=torch.float32).contiguous()
+        if not (isinstance(t, torch.Tensor) and t.device == device and t.dtype == torch.float32 and t.is_contiguous()):
+            if not isinstance(t, torch.Tensor):
+                t = torch.as_tensor(t, dtype=torch.float32)
+            t = t.to(device=device, dtype=torch.float32).contiguous()
         keep.append(t)
         setattr(s, name, t.data_ptr())
     return s
 
 
+def _note_header(key, cap, D, overflow):
+    _seen_D[key] = max(_seen_D.get(key, 0), D)
+    if overflow:
+        raise RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); the outputs '
+                           'of that render are invalid and its gradients are zero. Use config.mode="exact" or raise '
+                           'config.capacity_growth.' % (D, cap))
+
+
 def _drain_pending(block=False):
     """Process finished asynchronous header read-backs of capacity-mode calls."""
     global _pending
-    rest = []
-    for ev, host, key, cap in _pending:
+    rest, todo = [], []
+    for item in _pending:
+        ev = item[0]
         if block:
             ev.synchronize()
-        if ev.query():
-            D, overflow = int(host[0]), int(host[1])
-            _seen_D[key] = max(_seen_D.get(key, 0), D)
-            if overflow:
-                _pending = [p for p in _pending if p[0] is not ev]
-                raise RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); '
-                                   'the outputs of that call are invalid. Use config.mode="exact" or raise '
-                                   'config.capacity_growth.' % (D, cap))
-        else:
-            rest.append((ev, host, key, cap))
+        (todo if ev.query() else rest).append(item)
     _pending = rest
+    for _, host, jobs in todo:
+        for k, (key, cap) in enumerate(jobs):
+            _note_header(key, cap, int(host[k, 0]), int(host[k, 1]))
 
 
 def check_overflow():
@@ -124,9 +141,14 @@ def check_overflow():
     _drain_pending(block=True)
 
 
+def read_header(tile_ws):
+    """(num_rendered, overflow, entries, num_visible, num_instances) of a tile workspace tensor (synchronises)."""
+    return tuple(int(v) for v in tile_ws[:20].view(torch.int32).cpu())
+
+
 def last_header():
-    """(num_rendered, overflow, entries, num_visible, num_instances) of the most recent forward (synchronises)."""
-    return tuple(int(v) for v in _debug_last['tile'][:20].view(torch.int32).cpu())
+    """Header of the most recent forward; needs ``config.keep_debug = True`` (developer probes only)."""
+    return read_header(_debug_last['tile'])
 
 
 _size_cache = {}
@@ -143,159 +165,270 @@ def _sizes(P, W, H, capacity):
     return sz
 
 
-class _RasterizeGaussians(torch.autograd.Function):
+class _Job:
+    """Host-side record of one render of a batch."""
+    __slots__ = ('rs', 'P', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
+                 'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
+                 'gb', 'tb')
+
+
+N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D
+
+
+class _Rasterize(torch.autograd.Function):
+    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, *tensors[8 K])."""
+
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+    def forward(ctx, K, settings, grad_enabled, shared, *tensors):
         lib = _lib.load()
-        device = means3D.device
+        device = tensors[0].device
         if device.type != 'cuda':
             raise RuntimeError('exavatar_release_amd: the rasterizer runs on a ROCm device only '
                                '(got %s); there is no CPU path' % device)
-        rs = raster_settings
-        H, W = int(rs.image_height), int(rs.image_width)
-        P = int(means3D.shape[0])
-        means3D = _f32c(means3D, 'means3D', device)
-        sh = _f32c(sh, 'shs', device)
-        colors_precomp = _f32c(colors_precomp, 'colors_precomp', device)
-        opacities = _f32c(opacities, 'opacities', device)
-        scales = _f32c(scales, 'scales', device)
-        rotations = _f32c(rotations, 'rotations', device)
-        cov3Ds_precomp = _f32c(cov3Ds_precomp, 'cov3D_precomp', device)
-        sh_M = int(sh.shape[1]) if sh is not None else 0
-        need_ctx = any(ctx.needs_input_grad)
+        # autograd is off inside forward(): the caller samples torch.is_grad_enabled() (a render under no_grad must
+        # not pay for the backward context although GaussianRenderer's mean_2d probe requires grad)
+        need_ctx = bool(grad_enabled) and any(ctx.needs_input_grad)
+        jobs = []
+        for k in range(K):
+            m3, _m2, sh, col, op, sc, rot, cov = tensors[N_IN * k: N_IN * (k + 1)]
+            j = _Job()
+            j.rs = settings[k]
+            j.H, j.W = int(j.rs.image_height), int(j.rs.image_width)
+            j.P = int(m3.shape[0])
+            j.means3D = _f32c(m3, 'means3D', device)
+            j.sh = _f32c(sh, 'shs', device)
+            j.colors = _f32c(col, 'colors_precomp', device)
+            j.opac = _f32c(op, 'opacities', device)
+            j.scales = _f32c(sc, 'scales', device)
+            j.rot = _f32c(rot, 'rotations', device)
+            j.cov = _f32c(cov, 'cov3D_precomp', device)
+            j.sh_M = int(j.sh.shape[1]) if j.sh is not None else 0
+            j.key = (device.index, j.P, j.H, j.W)
+            jobs.append(j)
 
-        keep = []
+        mode = config.mode
+        capturing = torch.cuda.is_current_stream_capturing()
+        if mode == 'auto':
+            mode = 'capacity' if (need_ctx or capturing) else 'exact'
+        elif mode not in ('exact', 'capacity'):
+            raise ValueError('config.mode must be "auto", "exact" or "capacity"')
+        if mode == 'capacity' and config.fixed_capacity is None and any(j.key not in _seen_D for j in jobs):
+            if capturing:
+                raise RuntimeError('exavatar_release_amd: capacity mode needs config.fixed_capacity (or one '
+                                   'earlier un-captured call of the same shape) before stream capture')
+            mode = 'exact'            # first call of this shape: measure D once, like upstream does
+
         with torch.cuda.device(device):
-            st = _make_settings(rs, device, keep)
             stream = _stream_ptr(device)
-            u8 = dict(dtype=torch.uint8, device=device)
-            planes = torch.empty((5, H, W), dtype=torch.float32, device=device)      # one allocation, three views
-            color, depth, alpha = planes[0:3], planes[3:4], planes[4:5]
-            radii = torch.empty((P,), dtype=torch.int32, device=device)
-            sz = _sizes(P, W, H, 0)
-            geom = torch.empty(int(sz.geom_bytes), **u8)
-            tile = torch.empty(int(sz.tile_bytes), **u8)
-            img = torch.empty(int(sz.img_bytes) if need_ctx else 0, **u8)
-            inputs = (_ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales), _ptr(rotations),
-                      _ptr(cov3Ds_precomp))
-            mode = config.mode
-            if mode not in ('exact', 'capacity'):
-                raise ValueError('config.mode must be "exact" or "capacity"')
-            key = (device.index, P, H, W)
-            capturing = torch.cuda.is_current_stream_capturing()
-            if mode == 'capacity' and config.fixed_capacity is None and key not in _seen_D:
-                if capturing:
-                    raise RuntimeError('exavatar_release_amd: capacity mode needs config.fixed_capacity (or one '
-                                       'earlier un-captured call of the same shape) before stream capture')
-                mode = 'exact'            # first call of this shape: measure D once, like upstream does
-            if mode == 'exact':
-                _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
-                                                      _ptr(tile), stream))
-                hdr = tile[:16].view(torch.int32).cpu()          # D2H + sync, as upstream does
-                capacity = max(int(hdr[0]), 64)          # header reports whole 64-instance batch slots
-                _seen_D[key] = max(_seen_D.get(key, 0), int(hdr[0]))
-                bins = torch.empty(int(_sizes(P, W, H, capacity).bin_bytes), **u8)
-                _lib.check(lib.exa_raster_forward_render(ctypes.byref(st), P, _ptr(geom), _ptr(tile), _ptr(bins),
-                                                         capacity, _ptr(img), _ptr(color), _ptr(depth), _ptr(alpha),
-                                                         int(need_ctx), stream))
-            else:
-                if not capturing:
-                    _drain_pending()          # event queries are illegal during stream capture
-                if config.fixed_capacity is not None:
-                    capacity = int(config.fixed_capacity)
+            if mode == 'capacity' and not capturing:
+                _drain_pending()          # event queries are illegal during stream capture
+            arr = (_lib.ExaRasterForwardJob * K)()
+            for k, j in enumerate(jobs):
+                j.keep = []
+                j.settings = _make_settings(j.rs, device, j.keep)
+                j.planes = torch.empty((5, j.H, j.W), dtype=torch.float32, device=device)   # colour | depth | alpha
+                j.radii = torch.empty((j.P,), dtype=torch.int32, device=device)
+                sz = _sizes(j.P, j.W, j.H, 0)
+                j.gb, j.tb = int(sz.geom_bytes), int(sz.tile_bytes)
+                j.bins = None
+                if mode == 'capacity':
+                    if config.fixed_capacity is not None:
+                        cap = int(config.fixed_capacity)
+                    else:
+                        cap = max(int(_seen_D[j.key] * config.capacity_growth), config.min_capacity)
+                    j.capacity = (cap + 63) // 64 * 64
+                    # ONE arena per render: splat records | tile workspace | bin workspace
+                    j.ws = torch.empty(j.gb + j.tb + int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes),
+                                       dtype=torch.uint8, device=device)
+                    j.bin_ptr = j.ws.data_ptr() + j.gb + j.tb
                 else:
-                    capacity = max(int(_seen_D[key] * config.capacity_growth), config.min_capacity)
-                capacity = (capacity + 63) // 64 * 64
-                bins = torch.empty(int(_sizes(P, W, H, capacity).bin_bytes), **u8)
-                _lib.check(lib.exa_raster_forward(ctypes.byref(st), P, sh_M, *inputs, _ptr(radii), _ptr(geom),
-                                                  _ptr(tile), _ptr(bins), capacity, _ptr(img), _ptr(color),
-                                                  _ptr(depth), _ptr(alpha), int(need_ctx), stream))
+                    j.capacity = 0
+                    j.ws = torch.empty(j.gb + j.tb, dtype=torch.uint8, device=device)
+                    j.bin_ptr = None
+                j.geom_ptr = j.ws.data_ptr()
+                j.tile_ptr = j.geom_ptr + j.gb
+                a = arr[k]
+                a.settings = ctypes.pointer(j.settings)
+                a.P, a.sh_M = j.P, j.sh_M
+                a.means3D, a.shs, a.colors_precomp = _addr(j.means3D), _addr(j.sh), _addr(j.colors)
+                a.opacities, a.scales, a.rotations = _addr(j.opac), _addr(j.scales), _addr(j.rot)
+                a.cov3D_precomp = _addr(j.cov)
+                a.radii = j.radii.data_ptr()
+                a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = j.geom_ptr, j.tile_ptr, j.bin_ptr, j.capacity
+                base = j.planes.data_ptr()
+                a.out_color, a.out_depth, a.out_alpha = base, base + 12 * j.H * j.W, base + 16 * j.H * j.W
+
+            hdr_check = None
+            if mode == 'exact':
+                _lib.check(lib.exa_raster_forward_bin_batch(arr, K, stream))
+                rows = [j.ws[j.gb:j.gb + 16].view(torch.int32) for j in jobs]
+                hdr = (rows[0] if K == 1 else torch.stack(rows)).cpu().view(K, 4)        # D2H + sync, as upstream does
+                for k, j in enumerate(jobs):
+                    j.capacity = max(int(hdr[k, 0]), 64)          # header reports whole 64-instance batch slots
+                    _seen_D[j.key] = max(_seen_D.get(j.key, 0), int(hdr[k, 0]))
+                    j.bins = torch.empty(int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes), dtype=torch.uint8, device=device)
+                    arr[k].bin_ws, arr[k].capacity = j.bins.data_ptr(), j.capacity
+                _lib.check(lib.exa_raster_forward_render_batch(arr, K, int(need_ctx), stream))
+            else:
+                _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
                 if not capturing:
-                    host = torch.empty(4, dtype=torch.int32, pin_memory=True)
-                    host.copy_(tile[:16].view(torch.int32), non_blocking=True)
+                    host = torch.empty((K, 4), dtype=torch.int32, pin_memory=True)
+                    rows = [j.ws[j.gb:j.gb + 16].view(torch.int32) for j in jobs]
+                    host.copy_(rows[0].view(1, 4) if K == 1 else torch.stack(rows), non_blocking=True)
                     ev = torch.cuda.Event()
                     ev.record(torch.cuda.current_stream(device))
-                    _pending.append((ev, host, key, capacity))
+                    hdr_check = (ev, host, [(j.key, j.capacity) for j in jobs])
+                    if not need_ctx:
+                        _pending.append(hdr_check)
 
-        _debug_last['tile'] = tile
-        _debug_last['geom'] = geom
-        _debug_last['capacity'] = capacity
-        ctx.raster_settings = rs
+        if config.keep_debug:
+            j = jobs[-1]
+            _debug_last['tile'] = j.ws[j.gb:j.gb + j.tb]
+            _debug_last['geom'] = j.ws[:j.gb]
+            _debug_last['capacity'] = j.capacity
         ctx.need_ctx = need_ctx
+        outs = []
+        for j in jobs:
+            outs += [j.planes[0:3], j.radii, j.planes[3:4], j.planes[4:5]]
         if need_ctx:
-            ctx.sh_M = sh_M
-            ctx.capacity = capacity
-            ctx.keep = keep
-            ctx.settings_struct = st
-            ctx.has = tuple(t is not None for t in (sh, colors_precomp, scales, rotations, cov3Ds_precomp))
-            empty = torch.empty(0, device=device)
-            ctx.save_for_backward(means3D, sh if sh is not None else empty,
-                                  colors_precomp if colors_precomp is not None else empty, opacities,
-                                  scales if scales is not None else empty,
-                                  rotations if rotations is not None else empty,
-                                  cov3Ds_precomp if cov3Ds_precomp is not None else empty,
-                                  radii, geom, tile, bins, img)
-        ctx.mark_non_differentiable(radii)
+            ctx.K = K
+            ctx.shared = bool(shared) and K > 1
+            ctx.hdr_check = hdr_check
+            ctx.meta = [(j.rs, j.P, j.H, j.W, j.sh_M, j.capacity, j.gb, j.tb, j.settings, j.keep, j.ws, j.bins,
+                         tuple(t is not None for t in (j.sh, j.colors, j.scales, j.rot, j.cov))) for j in jobs]
+            saved = []
+            empty = None
+            for j in jobs:
+                for t in (j.means3D, j.sh, j.colors, j.opac, j.scales, j.rot, j.cov):
+                    if t is None:
+                        if empty is None:
+                            empty = torch.empty(0, device=device)
+                        t = empty
+                    saved.append(t)
+                saved.append(j.radii)
+            ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(*[outs[4 * k + 1] for k in range(K)])
         # outputs nobody differentiates (radii, and depth / alpha when the loss ignores them) reach backward as None
         # instead of freshly zero-filled 4 MB tensors: the kernels take a null pointer for "no gradient"
         ctx.set_materialize_grads(False)
-        return color, radii, depth, alpha
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+    def backward(ctx, *grads):
         if not ctx.need_ctx:
             raise RuntimeError('exavatar_release_amd: backward called on a forward that stored no context')
         lib = _lib.load()
-        rs = ctx.raster_settings
-        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, tile, bins,
-         img) = ctx.saved_tensors
-        has_sh, has_col, has_sc, has_rot, has_cov = ctx.has
-        device = means3D.device
-        P = int(means3D.shape[0])
-        H, W = int(rs.image_height), int(rs.image_width)
+        K = ctx.K
+        saved = ctx.saved_tensors
+        device = saved[0].device
         f32 = dict(dtype=torch.float32, device=device)
-
-        def grad_in(g, shape):
-            if g is None:
-                return None
-            g = g.to(**f32).expand(shape).contiguous()
-            return g
-        g_color = grad_in(grad_color, (3, H, W))
-        if g_color is None:
-            g_color = torch.zeros((3, H, W), **f32)
-        g_depth = grad_in(grad_depth, (1, H, W))
-        g_alpha = grad_in(grad_alpha, (1, H, W))
-
+        need = ctx.needs_input_grad[4:]
+        arr = (_lib.ExaRasterBackwardJob * K)()
+        keep, ret = [], [None, None, None, None]
         with torch.cuda.device(device):
-            st = ctx.settings_struct          # built in forward; the tensors it points to are kept alive by ctx.keep
-            # separate tensors on purpose: AccumulateGrad adopts a whole tensor as `.grad` without a copy, a view of a
-            # shared buffer would be cloned
-            d_means3D = torch.empty((P, 3), **f32)
-            d_means2D = torch.empty((P, 3), **f32)
-            d_opac = torch.empty((P, 1), **f32)
-            d_colors = torch.empty((P, 3), **f32)
-            d_scales = torch.empty((P, 3), **f32) if has_sc else None
-            d_rot = torch.empty((P, 4), **f32) if has_rot else None
-            d_sh = torch.empty((P, ctx.sh_M, 3), **f32) if has_sh else None
-            d_cov = torch.empty((P, 6), **f32) if has_cov else None
-            sz = _sizes(P, W, H, ctx.capacity)
-            grad_ws = torch.empty(int(sz.grad_bytes), dtype=torch.uint8, device=device)
-            _lib.check(lib.exa_raster_backward(
-                ctypes.byref(st), P, ctx.sh_M,
-                _ptr(means3D), _ptr(sh if has_sh else None), _ptr(colors_precomp if has_col else None),
-                _ptr(opacities), _ptr(scales if has_sc else None), _ptr(rotations if has_rot else None),
-                _ptr(cov3Ds_precomp if has_cov else None), _ptr(radii), _ptr(geom), _ptr(tile), _ptr(bins),
-                ctx.capacity, _ptr(img), _ptr(g_color), _ptr(g_depth), _ptr(g_alpha), _ptr(grad_ws),
-                _ptr(d_means2D), _ptr(d_means3D), _ptr(d_colors), _ptr(d_opac), _ptr(d_scales), _ptr(d_rot),
-                _ptr(d_sh), _ptr(d_cov), _stream_ptr(device)))
-        return (d_means3D, d_means2D, d_sh, d_colors if has_col else None, d_opac, d_scales, d_rot, d_cov, None)
+            for k in range(K):
+                rs, P, H, W, sh_M, cap, gb, tb, st, _skeep, ws, bins, has = ctx.meta[k]
+                has_sh, has_col, has_sc, has_rot, has_cov = has
+                means3D, sh, col, opac, scales, rot, cov, radii = saved[8 * k: 8 * k + 8]
+                g_color, g_depth, g_alpha = grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]
+
+                def grad_in(g, shape):
+                    if g is None:
+                        return None
+                    g = g.to(**f32).expand(shape)
+                    return g if g.is_contiguous() else g.contiguous()
+                g_color = grad_in(g_color, (3, H, W))
+                if g_color is None:
+                    g_color = torch.zeros((3, H, W), **f32)
+                g_depth = grad_in(g_depth, (1, H, W))
+                g_alpha = grad_in(g_alpha, (1, H, W))
+                nd = need[N_IN * k: N_IN * (k + 1)]
+                own = (not ctx.shared) or k == 0          # shared: job 0's outputs receive the sum over the K views
+                # separate tensors on purpose: AccumulateGrad adopts a whole tensor as `.grad` without a copy, a view
+                # of a shared buffer would be cloned
+                d_means3D = torch.empty((P, 3), **f32) if own and nd[0] else None
+                d_means2D = torch.empty((P, 3), **f32) if nd[1] else None
+                d_sh = torch.empty((P, sh_M, 3), **f32) if own and has_sh and nd[2] else None
+                d_colors = torch.empty((P, 3), **f32) if own and has_col and nd[3] else None
+                d_opac = torch.empty((P, 1), **f32) if own and nd[4] else None
+                d_scales = torch.empty((P, 3), **f32) if own and has_sc and nd[5] else None
+                d_rot = torch.empty((P, 4), **f32) if own and has_rot and nd[6] else None
+                d_cov = torch.empty((P, 6), **f32) if own and has_cov and nd[7] else None
+                grad_ws = torch.empty(int(_sizes(P, W, H, cap).grad_bytes), dtype=torch.uint8, device=device)
+                keep += [g_color, g_depth, g_alpha, grad_ws]
+                a = arr[k]
+                a.settings = ctypes.pointer(st)           # built in forward; its tensors are kept alive by ctx.meta
+                a.P, a.sh_M = P, sh_M
+                a.means3D = means3D.data_ptr()
+                a.shs = sh.data_ptr() if has_sh else None
+                a.colors_precomp = col.data_ptr() if has_col else None
+                a.opacities = opac.data_ptr()
+                a.scales = scales.data_ptr() if has_sc else None
+                a.rotations = rot.data_ptr() if has_rot else None
+                a.cov3D_precomp = cov.data_ptr() if has_cov else None
+                a.radii = radii.data_ptr()
+                a.geom_ws = ws.data_ptr()
+                a.tile_ws = ws.data_ptr() + gb
+                a.bin_ws = bins.data_ptr() if bins is not None else ws.data_ptr() + gb + tb
+                a.capacity = cap
+                a.dL_dcolor, a.dL_ddepth, a.dL_dalpha = g_color.data_ptr(), _addr(g_depth), _addr(g_alpha)
+                a.grad_ws = grad_ws.data_ptr()
+                a.dL_dmeans2D, a.dL_dmeans3D, a.dL_dcolors = _addr(d_means2D), _addr(d_means3D), _addr(d_colors)
+                a.dL_dopacity, a.dL_dscales, a.dL_drotations = _addr(d_opac), _addr(d_scales), _addr(d_rot)
+                a.dL_dsh, a.dL_dcov3D = _addr(d_sh), _addr(d_cov)
+                ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
+            _lib.check(lib.exa_raster_backward_batch(arr, K, int(ctx.shared), _stream_ptr(device)))
+        if ctx.hdr_check is not None:
+            # capacity mode: make sure this render's forward did not overflow BEFORE handing gradients to the optimizer
+            # (an overflowed forward gets zero gradients from the kernels above).  The backward kernels are already
+            # queued, so waiting for the forward's 16-byte header read-back does not idle the GPU.
+            ev, host, jobs = ctx.hdr_check
+            ctx.hdr_check = None
+            ev.synchronize()
+            for k, (key, cap) in enumerate(jobs):
+                _note_header(key, cap, int(host[k, 0]), int(host[k, 1]))
+        return tuple(ret)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, means3D, means2D, sh, colors_precomp,
+                            opacities, scales, rotations, cov3Ds_precomp)
+
+
+_IN_NAMES = ('means3D', 'means2D', 'shs', 'colors_precomp', 'opacities', 'scales', 'rotations', 'cov3D_precomp')
+
+
+def rasterize_gaussians_batch(jobs):
+    """K renders in one launch per pipeline stage.
+
+    ``jobs``: sequence of dicts with the keyword arguments of ``GaussianRasterizer.forward`` plus
+    ``raster_settings``.  Returns a list of ``(color, radii, depth, alpha)`` tuples, bit-identical to K single
+    calls.  When every job passes the SAME tensor objects for the Gaussians (K views of one model), the backward
+    sums the K views' gradients inside the per-Gaussian kernel (one thread walks the K views) instead of letting
+    autograd add K gradient tensors.
+    """
+    jobs = list(jobs)
+    K = len(jobs)
+    if K == 0:
+        return []
+    flat = []
+    for j in jobs:
+        _check_combo(j.get('shs'), j.get('colors_precomp'), j.get('scales'), j.get('rotations'), j.get('cov3D_precomp'))
+        flat += [j.get(n) for n in _IN_NAMES]
+    shared = K > 1 and all(all(jobs[k].get(n) is jobs[0].get(n) for n in _IN_NAMES if n != 'means2D') for k in range(1, K))
+    if shared and K > 8:
+        shared = False
+    outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, *flat)
+    return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
+
+
+def _check_combo(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+            ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
 
 class GaussianRasterizer(nn.Module):
@@ -323,10 +456,6 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
-        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
-            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
-        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
-                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
-            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        _check_combo(shs, colors_precomp, scales, rotations, cov3D_precomp)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, self.raster_settings)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 100          /* 0.1.0 */
+#define EXA_RASTER_VERSION 110          /* 0.1.1: batched entry points, img workspace removed */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
 #define EXA_RASTER_E_INVALID (-1)
@@ -61,9 +61,8 @@ typedef struct ExaRasterSettings {
 typedef struct ExaRasterWorkspaceSizes {
     uint64_t geom_bytes;   /* per-Gaussian splat records, 64 B * P                         */
     uint64_t tile_bytes;   /* header, (chunk, cell) count matrix, prefixes, per-sub-tile ranges   */
-    uint64_t bin_bytes;    /* keys, sorted ids, cell buckets, batch owners, checkpoints: ~48 B * capacity */
-    uint64_t img_bytes;    /* reserved (256): the per-pixel context lives in the batch checkpoints */
-    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
+    uint64_t bin_bytes;    /* keys, sorted ids, cell buckets, batch owners / masks, checkpoints: ~50 B * capacity */
+    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 40 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
 /* Device-side header at the start of the tile workspace (readable with a 20-byte D2H copy). */
@@ -109,7 +108,6 @@ int exa_raster_forward_bin(const ExaRasterSettings* settings, int32_t P, int32_t
  */
 int exa_raster_forward_render(const ExaRasterSettings* settings, int32_t P,
                               const void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity,
-                              void* img_ws,
                               float* out_color,   /* [dev] float[3,H,W] */
                               float* out_depth,   /* [dev] float[1,H,W] */
                               float* out_alpha,   /* [dev] float[1,H,W] */
@@ -120,7 +118,7 @@ int exa_raster_forward(const ExaRasterSettings* settings, int32_t P, int32_t sh_
                        const float* means3D, const float* shs, const float* colors_precomp,
                        const float* opacities, const float* scales, const float* rotations,
                        const float* cov3D_precomp, int32_t* radii,
-                       void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity, void* img_ws,
+                       void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity,
                        float* out_color, float* out_depth, float* out_alpha,
                        int32_t store_ctx, void* stream);
 
@@ -129,7 +127,8 @@ int exa_raster_forward(const ExaRasterSettings* settings, int32_t P, int32_t sh_
  * a forward call with store_ctx != 0 filled.  dL_ddepth / dL_dalpha may be NULL (= zeros; the
  * ExAvatar training case).  Gradient outputs that do not apply
  * (dL_dsh without shs, dL_dcov3D without cov3D_precomp, ...) may be NULL.  All non-NULL outputs
- * are fully written (zeros for culled Gaussians).
+ * are fully written (zeros for culled Gaussians).  If the forward call overflowed its instance capacity
+ * (header.overflow != 0) every gradient of that render is written as zero.
  * dL_dmeans2D[P,3]: (x, y) = dL/dpix * (W/2, H/2), z = 0 -- the densification signal the reference
  * reads at avatar/main/train.py:51.
  */
@@ -139,7 +138,6 @@ int exa_raster_backward(const ExaRasterSettings* settings, int32_t P, int32_t sh
                         const float* cov3D_precomp, const int32_t* radii,
                         const void* geom_ws, const void* tile_ws, const void* bin_ws,
                         uint64_t capacity,        /* the capacity bin_ws was carved with in forward */
-                        const void* img_ws,
                         const float* dL_dcolor,   /* [dev] float[3,H,W] */
                         const float* dL_ddepth,   /* [dev] float[1,H,W] or NULL */
                         const float* dL_dalpha,   /* [dev] float[1,H,W] or NULL */
@@ -147,6 +145,48 @@ int exa_raster_backward(const ExaRasterSettings* settings, int32_t P, int32_t sh
                         float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity,
                         float* dL_dscales, float* dL_drotations, float* dL_dsh, float* dL_dcov3D,
                         void* stream);
+
+/*
+ * Batched entry points: K independent renders ("jobs") per call, ONE kernel launch per pipeline stage for up to
+ * eight jobs (larger K is processed in groups of eight).  Two uses on ExAvatar's path:
+ *   - the K training views one GPU holds of a view-sharded step (same Gaussian tensors, K cameras; the reference's
+ *     per-sample loop avatar/main/model.py:81): exa_raster_backward_batch(..., sum_shared = 1) then returns the SUM
+ *     of the K views' gradients in job 0's outputs (dL_dmeans2D stays per view);
+ *   - the five same-camera renders of one iteration (scene, human, scene+human, human refined, scene+human refined;
+ *     avatar/main/model.py:119-167): five jobs with their own Gaussian tensors, sum_shared = 0.
+ * A single 1024x1024 render leaves most of the chip idle in every stage but the blend, so a batch costs far less
+ * than K calls.  Results are bit-identical to K single calls (sum_shared: up to the order of the K-term sum).
+ * All jobs of one call share `store_ctx`.  Same workspace / ownership / error rules as the single-render calls,
+ * which are implemented as a batch of one.
+ */
+typedef struct ExaRasterForwardJob {
+    const ExaRasterSettings* settings;
+    int32_t P, sh_M;
+    const float* means3D; const float* shs; const float* colors_precomp; const float* opacities;
+    const float* scales; const float* rotations; const float* cov3D_precomp;
+    int32_t* radii;                 /* [dev] out int32[P]                                              */
+    void* geom_ws; void* tile_ws;   /* sized by exa_raster_workspace_sizes(P, W, H, capacity)          */
+    void* bin_ws; uint64_t capacity;                     /* ignored by exa_raster_forward_bin_batch    */
+    float* out_color; float* out_depth; float* out_alpha; /* ignored by exa_raster_forward_bin_batch   */
+} ExaRasterForwardJob;
+
+typedef struct ExaRasterBackwardJob {
+    const ExaRasterSettings* settings;
+    int32_t P, sh_M;
+    const float* means3D; const float* shs; const float* colors_precomp; const float* opacities;
+    const float* scales; const float* rotations; const float* cov3D_precomp;
+    const int32_t* radii;
+    const void* geom_ws; const void* tile_ws; const void* bin_ws; uint64_t capacity;
+    const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
+    void* grad_ws;
+    float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
+    float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
+} ExaRasterBackwardJob;
+
+int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream);
+int exa_raster_forward_render_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);
+int exa_raster_forward_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);
+int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32_t sum_shared, void* stream);
 
 /* upstream markVisible: present[i] = (view-space z of means3D[i] > 0.2). */
 int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const float* means3D,

@@ -30,6 +30,7 @@ alpha = 1 - T, radii.
 
 Backward = torch.autograd of the forward with the rules of SURVEY.md 8(c): discrete decisions are
 constants, ``min(0.99, .)`` is straight-through, the fov clamp zeroes its gradient when active,
+the conic's backward carries upstream's ``1 / (det^2 + 1e-7)`` (``_ConicFromCov2D``),
 ``means2D`` is added to the NDC position so its gradient is d L / d pix * (W/2, H/2).
 """
 from typing import NamedTuple, Optional
@@ -116,6 +117,35 @@ def cov3d_from_packed(c6):
     """Upper-triangular packing [xx, xy, xz, yy, yz, zz] -> 3x3 (upstream cov3D_precomp layout)."""
     xx, xy, xz, yy, yz, zz = [c6[:, i] for i in range(6)]
     return torch.stack((xx, xy, xz, xy, yy, yz, xz, yz, zz), 1).view(-1, 3, 3)
+
+
+class _ConicFromCov2D(torch.autograd.Function):
+    """conic = Sigma2^-1 = (c, -b, a) / det with upstream's backward.
+
+    The forward is the exact inverse.  The backward follows upstream ``computeCov2DCUDA`` (backward): the
+    exact partial derivatives, but with the common factor ``1 / det^2`` evaluated as
+    ``1 / (det^2 + 1e-7)`` ("denom2inv") -- a guard upstream carries and that the replacement must
+    reproduce (det >= 0.09 because of the +0.3 low-pass, so the deviation from the exact derivative is
+    <= 1.2e-5 relative).  SURVEY.md 8(c); the HIP kernel uses the same form (preprocess_bwd.hip).
+    """
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        det = a * c - b * b
+        det_safe = torch.where(det == 0, torch.ones_like(det), det)
+        det_inv = 1.0 / det_safe
+        ctx.save_for_backward(a, b, c, det)
+        return torch.stack((c * det_inv, -b * det_inv, a * det_inv), 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, c, det = ctx.saved_tensors
+        gA, gB, gC = g[:, 0], g[:, 1], g[:, 2]
+        d2i = 1.0 / (det * det + 1e-7)
+        da = d2i * (-c * c * gA + b * c * gB + (det - a * c) * gC)
+        dc = d2i * ((det - a * c) * gA + a * b * gB - a * a * gC)
+        db = d2i * (2.0 * b * c * gA - (det + 2.0 * b * b) * gB + 2.0 * a * b * gC)
+        return da, db, dc
 
 
 def preprocess(means3D, means2D, opacities, scales, rotations, cov3D_precomp, s: OracleSettings, dtype):
@@ -206,9 +236,7 @@ def preprocess(means3D, means2D, opacities, scales, rotations, cov3D_precomp, s:
     b = (U00 * T10 + U01 * T11) + U02 * T12
     c = ((U10 * T10 + U11 * T11) + U12 * T12) + LOWPASS
     det = a * c - b * b
-    det_safe = torch.where(det == 0, torch.ones_like(det), det)
-    det_inv = 1.0 / det_safe
-    conic = torch.stack((c * det_inv, -b * det_inv, a * det_inv), 1)
+    conic = _ConicFromCov2D.apply(a, b, c)      # exact forward, upstream's 1 / (det^2 + 1e-7) backward
     # 5. radius
     with torch.no_grad():
         mid = 0.5 * (a + c)

@@ -1,10 +1,20 @@
 """Shared helpers of the parity tests: tolerances are BASELINE.json's (image L-inf 1e-4, grads 1e-3 rel)."""
+import json
+import os
+
 import torch
 
 IMG_TOL = 1e-4        # per-pixel L-infinity on colour / depth / alpha (north_star)
 GRAD_REL_TOL = 1e-3   # relative gradient error (north_star)
-AMBIGUOUS_MAX_FRACTION = 5e-3   # pixels whose discrete decisions sit within 1e-4 (relative) of a threshold
+# Pixels whose discrete decisions (alpha >= 1/255, T < 1e-4, power > 0) sit within 1e-4 (relative) of their
+# threshold may flip one decision between two fp32 implementations.  The budget is data driven: the small synthetic
+# scenes measure <= 2e-4 of their pixels, the full-size BASELINE workloads assert their own measured counts
+# (tests/test_gpu_fullsize.py).
+AMBIGUOUS_MAX_FRACTION = 1e-3
 AMBIGUOUS_TOL = 2e-2            # such a pixel may flip one alpha >= 1/255 / T < 1e-4 decision
+# per-Gaussian gradient check: |g_i - r_i|_inf <= 1e-3 |r_i|_inf + GAUSS_FLOOR * mean_j |r_j|_inf  (an absolute floor
+# for Gaussians whose net gradient is a small difference of large per-pixel contributions)
+GAUSS_FLOOR = 1e-3
 
 
 def grad_rel_err(got, ref):
@@ -15,20 +25,60 @@ def grad_rel_err(got, ref):
     return float((got - ref).abs().max() / scale), float((got - ref).norm() / ref.norm().clamp_min(1e-30))
 
 
-def assert_image_close(got, ref, ambiguous, name='img'):
+def per_gaussian_excess(got, ref):
+    """max over Gaussians of (|g_i - r_i|_inf - 1e-3 |r_i|_inf) / mean_j |r_j|_inf: the absolute floor (in units of the
+    mean per-Gaussian gradient magnitude) a per-Gaussian 1e-3-relative check needs.  <= GAUSS_FLOOR passes."""
+    ref = ref.double().reshape(ref.shape[0], -1)
+    got = got.double().reshape(got.shape[0], -1)
+    if ref.shape[0] == 0:
+        return 0.0
+    rn = ref.abs().amax(1)
+    en = (got - ref).abs().amax(1)
+    scale = rn.mean().clamp_min(1e-30)
+    return float(((en - GRAD_REL_TOL * rn) / scale).max())
+
+
+def image_stats(got, ref, ambiguous):
     got = got.detach().cpu().float()
     ref = ref.detach().cpu().float()
     d = (got - ref).abs()
+    if d.dim() == 3:
+        d = d.amax(0)
     amb = ambiguous.bool()
-    frac = float(amb.float().mean())
-    assert frac <= AMBIGUOUS_MAX_FRACTION, '%s: %.2e of the pixels are ambiguous' % (name, frac)
     strict = d.clone()
-    strict[..., amb] = 0
-    assert float(strict.max()) <= IMG_TOL, '%s: L-inf %.3e on unambiguous pixels' % (name, float(strict.max()))
-    if amb.any():
-        assert float(d[..., amb].max()) <= AMBIGUOUS_TOL, '%s: ambiguous pixel off by %.3e' % (name, float(d[..., amb].max()))
+    strict[amb] = 0
+    return {'n_ambiguous': int(amb.sum()), 'linf_unambiguous': float(strict.max()) if strict.numel() else 0.0,
+            'linf_ambiguous': float(d[amb].max()) if amb.any() else 0.0,
+            'n_ambiguous_off': int((d[amb] > IMG_TOL).sum()) if amb.any() else 0}
 
 
-def assert_grads_close(got, ref, name):
-    mx, l2 = grad_rel_err(got.detach().cpu(), ref.detach().cpu())
+def assert_image_close(got, ref, ambiguous, name='img', max_ambiguous=None, stats=None):
+    st = stats if stats is not None else image_stats(got, ref, ambiguous)
+    budget = max_ambiguous if max_ambiguous is not None else AMBIGUOUS_MAX_FRACTION * ambiguous.numel()
+    assert st['n_ambiguous'] <= budget, '%s: %d ambiguous pixels (budget %g)' % (name, st['n_ambiguous'], budget)
+    assert st['linf_unambiguous'] <= IMG_TOL, '%s: L-inf %.3e on unambiguous pixels' % (name, st['linf_unambiguous'])
+    assert st['linf_ambiguous'] <= AMBIGUOUS_TOL, '%s: ambiguous pixel off by %.3e' % (name, st['linf_ambiguous'])
+    return st
+
+
+def grad_stats(got, ref):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    mx, l2 = grad_rel_err(got, ref)
+    return {'max_rel': mx, 'l2_rel': l2, 'per_gaussian_floor_needed': per_gaussian_excess(got, ref)}
+
+
+def assert_grads_close(got, ref, name, per_gaussian=True):
+    got, ref = got.detach().cpu(), ref.detach().cpu()
+    mx, l2 = grad_rel_err(got, ref)
     assert mx <= GRAD_REL_TOL and l2 <= GRAD_REL_TOL, 'grad %s: max-rel %.3e, L2-rel %.3e' % (name, mx, l2)
+    ex = per_gaussian_excess(got, ref) if per_gaussian else 0.0
+    assert ex <= GAUSS_FLOOR, 'grad %s: per-Gaussian error exceeds 1e-3 relative + floor (needs floor %.3e)' % (name, ex)
+    return {'max_rel': mx, 'l2_rel': l2, 'per_gaussian_floor_needed': ex}
+
+
+def record_stats(tag, stats):
+    """Append measured parity statistics to gpurun_out/parity_stats.jsonl (when that directory exists: GPU box runs)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(d):
+        with open(os.path.join(d, 'parity_stats.jsonl'), 'a') as f:
+            f.write(json.dumps({'tag': tag, **stats}) + '\n')

@@ -12,12 +12,17 @@ from exavatar_release_amd.dist import FlatGradAllReducer, reduce_densify_stats, 
 def test_shard_views_partition_and_reshuffle():
     for world in (1, 2, 3, 8):
         for epoch in (0, 1):
-            shards = [shard_views(200, r, world, epoch=epoch) for r in range(world)]
+            shards = [shard_views(200, r, world, epoch=epoch, pad=False) for r in range(world)]
             allv = sorted(v for s in shards for v in s)
             assert allv == list(range(200))
             assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+            # default: padded to equal length (every rank issues the same number of all-reduces per epoch)
+            padded = [shard_views(200, r, world, epoch=epoch) for r in range(world)]
+            assert len({len(s) for s in padded}) == 1 and len(padded[0]) == -(-200 // world)
+            assert set(v for s in padded for v in s) == set(range(200))
     assert shard_views(200, 0, 8, epoch=0) != shard_views(200, 0, 8, epoch=1)
     assert shard_views(10, 1, 2, shuffle=False) == [1, 3, 5, 7, 9]
+    assert shard_views(10, 2, 3, shuffle=False) == [2, 5, 8, 1] and shard_views(10, 2, 3, shuffle=False, pad=False) == [2, 5, 8]
 
 
 def _worker(rank, world, port, q):
@@ -29,10 +34,14 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(100 + rank)
         shapes = [(P, 3), (P, 3), (P, 4), (P, 1), (P, 3)]
         grads = [torch.randn(*s, generator=g) for s in shapes]
-        red = FlatGradAllReducer(grads, average=True)
+        red = FlatGradAllReducer(grads, average=True, n_buffers=2)
         assert red.nbytes == P * 14 * 4
         red.start(grads)
-        out = [v.clone() for v in red.finish()]
+        # double buffering: a second step may pack while the first collective is in flight; both results survive
+        red.start([2.0 * g_ for g_ in grads])
+        red.finish()
+        assert torch.allclose(red.buffer_views(1)[0], 2.0 * red.buffer_views(0)[0], atol=1e-6)
+        out = [v.clone() for v in red.buffer_views(0)]
         # second step: rank 1 did not touch the opacity parameter (None grad = zeros)
         grads2 = [torch.full(s, float(rank + 1)) for s in shapes]
         if rank == 1:

@@ -261,8 +261,8 @@ def _c3_step(dev, assets, shape, view, G, mode='exact'):
 
 
 def test_c3_full_size_properties(dev):
-    """BASELINE config C3 (150 k avatar-like, 1024x1024), too big for the oracle in seconds:
-    size-independent properties instead -- determinism (the backward is atomic-free), background
+    """BASELINE config C3 (150 k avatar-like, 1024x1024); oracle parity at this size lives in test_gpu_fullsize.py,
+    here the size-independent properties -- determinism (the backward is atomic-free), background
     linearity, alpha == 1 - T, invariance to a permutation of the Gaussians, capacity mode == exact mode."""
     shape = (1024, 1024)
     assets = scenes.dist_b_avatar(150_000, seed=0)
@@ -407,7 +407,7 @@ def test_fused_densify_stats_match_reference_bookkeeping(dev):
 
 def test_render_many_is_bit_identical_to_sequential_renders(dev):
     """the five same-camera renders of one ExAvatar iteration (model.py:129-167: scene, human,
-    scene+human, human refined, scene+human refined) issued concurrently on five streams -- images and every
+    scene+human, human refined, scene+human refined) as five jobs of ONE batched call (one launch per pipeline stage) -- images and every
     gradient equal the sequential result bit for bit."""
     H, W = 128, 160
     f = 170.0
@@ -435,6 +435,122 @@ def test_render_many_is_bit_identical_to_sequential_renders(dev):
     imgs_b, grads_b = run(True)
     for x, y in zip(imgs_a + grads_a, imgs_b + grads_b):
         assert torch.equal(x, y)
+
+
+def test_last_partial_wave_with_large_gaussian(dev):
+    """P % 64 != 0 with a splat of >= 64 sub-tiles at index P - 1 (where densification appends): the per-Gaussian
+    backward fetches such a splat's partial sums with the WHOLE wave, so the lanes past P must take part."""
+    H, W = 128, 160
+    f = 170.0
+    P = 1000 + 37
+    a = scenes.dist_a_random(P, H, W, seed=77, focal=f)
+    for i in (P - 1, P - 2, P - 40):
+        a['scale'][i] = torch.tensor([0.45, 0.40, 0.35])       # ~ 60 px radius at z = 3: well over 64 sub-tiles
+        a['mean_3d'][i] = torch.tensor([0.02 * (P - i), -0.03, 3.0])
+        a['opacity'][i] = 0.35
+    cam = scenes.neutral_camera(H, W, focal=f)
+    g = torch.Generator().manual_seed(78)
+    out, ref = _cmp_render(a, (H, W), cam, torch.rand(3, generator=g), dev, torch.randn(3, H, W, generator=g))
+    pre = ref['aux']['pre']
+    assert int(pre['tiles_touched'][P - 1]) >= 16              # >= 16 tiles of 16x16 = >= 64 sub-tiles
+
+
+def test_batched_views_equal_single_renders_and_sum_gradients(dev):
+    """exa_raster_*_batch (the view shard of one GPU in one launch per stage): K views of the same Gaussians
+    give bit-identical images to K single renders, the shared tensors receive the SUM of the per-view gradients, every
+    view keeps its own mean_2d probe -- checked against sequential HIP renders bitwise / to rounding AND against the
+    oracle's summed autograd gradients."""
+    H, W = 160, 192
+    f = 260.0
+    K = 3
+    assets = scenes.dist_b_avatar(6000, seed=11)
+    cams = [scenes.ring_camera(H, W, v, 24, focal=f) for v in (0, 5, 17)]
+    g = torch.Generator().manual_seed(12)
+    Gs = [torch.randn(3, H, W, generator=g) for _ in range(K)]
+    bg = torch.rand(3, generator=g)
+    rend = exa.GaussianRenderer()
+    to_dev = lambda c: {k: v.to(dev) for k, v in c.items()}
+    # sequential single renders
+    a_seq = _to(assets, dev)
+    outs_seq = [rend(a_seq, (H, W), to_dev(c), bg.to(dev)) for c in cams]
+    sum((o['img'] * G.to(dev)).sum() for o, G in zip(outs_seq, Gs)).backward()
+    # one batched call
+    a_bat = _to(assets, dev)
+    outs_bat = exa.render_views(rend, a_bat, (H, W), [to_dev(c) for c in cams], bg.to(dev))
+    sum((o['img'] * G.to(dev)).sum() for o, G in zip(outs_bat, Gs)).backward()
+    for ob, os_ in zip(outs_bat, outs_seq):
+        for k in ('img', 'depthmap', 'mask', 'radius'):
+            assert torch.equal(ob[k], os_[k]), k
+        assert torch.equal(ob['mean_2d'].grad, os_['mean_2d'].grad)       # per view, not summed
+    for k in KEYS:
+        gb, gs = a_bat[k].grad, a_seq[k].grad
+        assert float((gb - gs).abs().max()) <= 2e-6 * float(gs.abs().max()), k    # same terms, different summation order
+    # oracle: sum of the K views' autograd gradients
+    a_cpu = {k: v.clone().requires_grad_(True) for k, v in assets.items()}
+    loss = 0
+    for c, G in zip(cams, Gs):
+        loss = loss + (ro.render(a_cpu, (H, W), c, bg)['img'] * G).sum()
+    loss.backward()
+    for k in KEYS:
+        assert_grads_close(a_bat[k].grad, a_cpu[k].grad, k)
+
+
+def test_batch_of_heterogeneous_jobs_and_more_than_eight(dev):
+    """Jobs with different Gaussian counts AND different image sizes in one batched call, and more jobs than one launch
+    holds (groups of eight): every job equals its single render bit for bit, gradients included."""
+    specs = [(900, 64, 96), (2500, 120, 80), (64, 40, 40), (1500, 75, 100), (0, 32, 48), (700, 96, 64), (1200, 130, 70),
+             (300, 48, 160), (2000, 100, 100), (1100, 88, 56)]
+    rend = exa.GaussianRenderer()
+    jobs, singles = [], []
+    g = torch.Generator().manual_seed(5)
+    for i, (P, H, W) in enumerate(specs):
+        f = 1.3 * max(H, W)
+        a = scenes.dist_a_random(P, H, W, seed=100 + i, focal=f)
+        cam = {k: v.to(dev) for k, v in scenes.neutral_camera(H, W, focal=f).items()}
+        bg = torch.rand(3, generator=g).to(dev)
+        G = torch.randn(3, H, W, generator=g).to(dev)
+        jobs.append((_to(a, dev), (H, W), cam, bg, G))
+        singles.append((_to(a, dev), (H, W), cam, bg, G))
+    outs_s = [rend(*j[:4]) for j in singles]
+    sum((o['img'] * j[4]).sum() + o['mask'].sum() for o, j in zip(outs_s, singles)).backward()
+    outs_b = exa.render_many(rend, [j[:4] for j in jobs])
+    sum((o['img'] * j[4]).sum() + o['mask'].sum() for o, j in zip(outs_b, jobs)).backward()
+    for ob, os_, jb, js in zip(outs_b, outs_s, jobs, singles):
+        for k in ('img', 'depthmap', 'mask', 'radius'):
+            assert torch.equal(ob[k], os_[k]), k
+        assert torch.equal(ob['mean_2d'].grad, os_['mean_2d'].grad)
+        for k in KEYS:
+            assert torch.equal(jb[0][k].grad, js[0][k].grad), k
+
+
+def test_overflowed_render_raises_in_backward_and_writes_zero_gradients(dev):
+    """Capacity mode with a buffer that is too small: the forward latches the overflow on the device; the render's own
+    backward surfaces it (RuntimeError) before any gradient reaches an optimizer, and the kernels it launched wrote
+    zeros (checked through the C ABI output buffers of a second, direct call)."""
+    assets, shape, cam = scenes.make_config('c1')
+    exa.config.mode = 'capacity'
+    exa.config.fixed_capacity = 1024            # far too small
+    try:
+        a = _to(assets, dev)
+        out = exa.GaussianRenderer()(a, shape, {k: v.to(dev) for k, v in cam.items()}, torch.ones(3, device=dev))
+        with pytest.raises(RuntimeError, match='overflow'):
+            out['img'].sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        exa.config.mode = 'exact'
+        exa.config.fixed_capacity = None
+
+
+def test_no_grad_render_matches_training_render(dev):
+    """torch.no_grad() renders take the inference variant of the blend kernel (no checkpoints, no masks) although the
+    renderer's mean_2d probe requires grad: same image bit for bit."""
+    assets, shape, cam = scenes.make_config('c1')
+    camd = {k: v.to(dev) for k, v in cam.items()}
+    a = _to(assets, dev)
+    out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+    with torch.no_grad():
+        out2 = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+    assert torch.equal(out['img'].detach(), out2['img']) and not out2['img'].requires_grad
 
 
 def test_bench_multi_rank_code_path_on_one_gpu():

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 100
+    assert lib.exa_raster_version() == 110
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
@@ -40,8 +40,7 @@ def test_settings_struct_layout_matches_c():
 def test_workspace_sizes():
     s = _lib.workspace_sizes(150_000, 1024, 1024, 1_000_000)
     assert s.geom_bytes == 150_000 * 64
-    assert s.bin_bytes >= 16 * 1_000_000 and s.grad_bytes >= 48 * 1_000_000
-    assert s.img_bytes >= 256          # reserved section
+    assert s.bin_bytes >= 29 * 1_000_000 and s.grad_bytes >= 40 * 1_000_000
     s2 = _lib.workspace_sizes(0, 0, 0, 0)
     assert s2.geom_bytes == 0
     with pytest.raises(RuntimeError):
@@ -80,6 +79,22 @@ def test_argument_validation_returns_negative_status_without_touching_the_gpu():
     assert rc == -1 and b'too large' in lib.exa_raster_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc)
+
+
+def test_batch_job_structs_match_c_layout():
+    # LP64: pointer, 2 x int32, then 8-byte fields only
+    assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8
+    assert _lib.ExaRasterForwardJob.capacity.offset == 104 and _lib.ExaRasterForwardJob.out_color.offset == 112
+    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8
+    assert _lib.ExaRasterBackwardJob.grad_ws.offset == 136
+    lib = _lib.load()
+    # argument validation of the batched entry points, no GPU touched
+    jobs = (_lib.ExaRasterForwardJob * 2)()
+    assert lib.exa_raster_forward_batch(jobs, 2, 0, None) == -2 and b'settings' in lib.exa_raster_last_error()
+    assert lib.exa_raster_forward_batch(None, 2, 0, None) == -1
+    assert lib.exa_raster_forward_batch(None, 0, 0, None) == 0
+    bj = (_lib.ExaRasterBackwardJob * 1)()
+    assert lib.exa_raster_backward_batch(bj, 1, 0, None) == -2
 
 
 def test_python_surface_matches_the_reference_plugin():

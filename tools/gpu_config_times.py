@@ -9,6 +9,7 @@ from exavatar_release_amd.camera import make_raster_matrices
 
 dev = torch.device('cuda:0')
 exa.config.mode = 'exact'
+exa.config.keep_debug = True
 for name in (sys.argv[1:] or ['c2', 'c3s', 'c5']):
     assets, (H, W), cam = scenes.make_config(name)
     P = assets['mean_3d'].shape[0]

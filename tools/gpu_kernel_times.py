@@ -16,6 +16,7 @@ mean_2d = torch.zeros(P, 3, device=dev, requires_grad=True)
 G = torch.randn(3, H, W, device=dev)
 views = [int(v) for v in (sys.argv[1:] or [0, 25, 50, 75, 100])]
 exa.config.mode = 'exact'
+exa.config.keep_debug = True
 for k in views:
     tanx, tany, view, proj, cpos = make_raster_matrices(scenes.ring_camera(H, W, k, 200), (H, W))
     st = GaussianRasterizationSettings(H, W, tanx, tany, torch.ones(3, device=dev), 1.0, view.to(dev), proj.to(dev), 0, cpos.to(dev), False, False)
