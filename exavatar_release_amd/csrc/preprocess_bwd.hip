@@ -16,20 +16,27 @@
 
 namespace exa {
 
-// One thread per Gaussian.  SUM = false: gridDim.y jobs, each thread handles (job blockIdx.y, Gaussian idx).
-// SUM = true: the K jobs are K views of the SAME Gaussians; the thread walks the views and writes the summed
-// gradient to job 0's outputs (dL_dmeans2D stays per view: the densification statistics need per-view norms,
-// reference avatar/common/nets/module.py:155-157).
-template <bool SUM>
+// One thread per (job, Gaussian).  SUM = false: gridDim.y jobs, thread = (job blockIdx.y, Gaussian idx).
+// SUM = true: the K jobs are K views of the SAME Gaussians and job 0's outputs receive the summed gradient
+// (dL_dmeans2D stays per view: the densification statistics need per-view norms, reference
+// avatar/common/nets/module.py:155-157).  VW = 4: the four waves of a workgroup share 64 Gaussians and split the
+// views (wave w takes views w, w + 4), then add their sums through LDS -- a thread that walked all K views alone
+// paid 3 K dependent memory round trips.  VW = 1 (the SH path, whose 48-float dL_dsh rows are accumulated in
+// global memory by their single owner): one thread walks all views.  SH = false compiles the SH backward out (the
+// colours-precomp path of ExAvatar's renderer, module.py:632-640): fewer registers, more waves per SIMD.
+template <bool SUM, int VW, bool SH>
 __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K) {
+    static_assert(VW == 1 || (SUM && VW == BLOCK / 64), "views are split over the waves of a workgroup in SUM mode only");
+    __shared__ float s_red[VW > 1 ? 20 * BLOCK : 1];
     const PreprocessBwdArgs& out = batch.v[SUM ? 0 : blockIdx.y];
-    if ((int)(blockIdx.x * BLOCK) >= out.P) return;             // workgroup-uniform
-    const int idx = blockIdx.x * BLOCK + threadIdx.x;
+    constexpr int GPB = BLOCK / VW;                             // Gaussians per workgroup
+    if ((int)(blockIdx.x * GPB) >= out.P) return;               // workgroup-uniform
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int idx = VW == 1 ? blockIdx.x * BLOCK + threadIdx.x : blockIdx.x * 64 + lane;
     // NO per-lane early exit: the wave-cooperative gather below needs all 64 lanes, also in the last, partly filled
     // wave (Gaussians appended by densification sit exactly there)
     const bool valid = idx < out.P;
     const int idc = valid ? idx : out.P - 1;                    // clamped index for loads
-    const int lane = threadIdx.x & 63;
     float in_s[3] = {0.f, 0.f, 0.f};
     float4 in_q = make_float4(1.f, 0.f, 0.f, 0.f);
     float in_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -48,7 +55,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
     bool sh_init = false;                                       // dL_dsh of this Gaussian already holds an earlier view's values
 
     const int n_views = SUM ? K : 1;
-    for (int view = 0; view < n_views; ++view) {
+    for (int view = VW == 1 ? 0 : wave; view < n_views; view += VW) {
         const PreprocessBwdArgs& a = batch.v[SUM ? view : blockIdx.y];
         const float* __restrict__ v = a.viewmatrix;
         const float* __restrict__ p = a.projmatrix;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         vmean[2] += dhx * p[8] + dhy * p[9] + dhw * p[11];
 
         // ---- SH colour ---------------------------------------------------------------------------
-        if (a.shs) {
+        if (SH && a.shs) {
             const uint32_t flags = reinterpret_cast<const uint4*>(a.splats + idc)[2].w;
             const float g[3] = {(flags & 1u) ? 0.f : vcol[0], (flags & 2u) ? 0.f : vcol[1], (flags & 4u) ? 0.f : vcol[2]};
             const float* cp = a.campos;
@@ -355,8 +362,31 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         for (int i = 0; i < 6; ++i) dcov[i] += vcov[i];
         dop += vop;
     }
+    if (VW > 1) {                                               // add the view subsets of the four waves
+        float* r = s_red + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { r[i * BLOCK] = dmean[i]; r[(3 + i) * BLOCK] = dscale[i]; r[(17 + i) * BLOCK] = dcol[i]; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[(6 + i) * BLOCK] = dq[i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[(10 + i) * BLOCK] = dcov[i];
+        r[16 * BLOCK] = dop;
+        __syncthreads();
+        if (wave != 0) return;
+        auto total = [&](int f) {
+            const float* q = s_red + f * BLOCK + lane;
+            return (q[0] + q[64]) + (q[128] + q[192]);
+        };
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { dmean[i] = total(i); dscale[i] = total(3 + i); dcol[i] = total(17 + i); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[i] = total(6 + i);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dcov[i] = total(10 + i);
+        dop = total(16);
+    }
     if (!valid) return;
-    if (!sh_init && out.shs && out.dL_dsh) {                    // never visible: the SH block above did not run
+    if (SH && !sh_init && out.shs && out.dL_dsh) {                    // never visible: the SH block above did not run
         float* dsh = out.dL_dsh + (size_t)idx * out.sh_M * 3;
         for (int k = 0; k < out.sh_M * 3; ++k) dsh[k] = 0.f;
     }
@@ -400,10 +430,17 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shar
     int P = 0;
     for (int k = 0; k < K; ++k) P = max(P, a[k].P);
     if (P == 0) return hipSuccess;
-    if (sum_shared)
-        preprocess_bwd_kernel<true><<<dim3((P + BLOCK - 1) / BLOCK, 1), BLOCK, 0, s>>>(make_batch(a, K), K);
+    bool sh = false;
+    for (int k = 0; k < K; ++k) sh = sh || a[k].shs != nullptr;
+    const dim3 grid256((P + BLOCK - 1) / BLOCK, sum_shared ? 1 : K);
+    if (sum_shared && !sh)
+        preprocess_bwd_kernel<true, BLOCK / 64, false><<<dim3((P + 63) / 64, 1), BLOCK, 0, s>>>(make_batch(a, K), K);
+    else if (sum_shared)
+        preprocess_bwd_kernel<true, 1, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+    else if (sh)
+        preprocess_bwd_kernel<false, 1, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
     else
-        preprocess_bwd_kernel<false><<<dim3((P + BLOCK - 1) / BLOCK, K), BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
     return hipGetLastError();
 }
 

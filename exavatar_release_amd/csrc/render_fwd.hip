@@ -363,31 +363,39 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         // entry that stops a pixel counts).  The backward pass replays exactly those: on avatar-like scenes only
         // ~60 % of the entries of the batches the forward enters (tools/cpu_blend_stats.py).
         unsigned long long blended = 0ull;
-        Ops4 cur = load_ops4(s_b, 0);
-        for (int k = 0; k < cnt; k += 4) {
-            const Ops4 nxt = load_ops4(s_b, (k + 4) & 63);       // operands of the next group: in flight during this one
+        // One group of four splats; returns true when every pixel of the sub-tile has stopped.
+        auto group4 = [&](const Ops4& ops, int k) -> bool {
             const float4 c0 = s_b.col[k], c1 = s_b.col[k + 1], c2 = s_b.col[k + 2], c3 = s_b.col[k + 3];
-            const Alpha4 e = splat_alpha4(cur, fx, fy);
-            cur = nxt;
+            const Alpha4 e = splat_alpha4(ops, fx, fy);
             const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
-            if (__any(amax > 0.0f)) {
-                float aeff[4], Tb[4], w[4];
-                blend_group4(T, live, e.alpha, aeff, Tb, w);
-                if (STORE) {                                     // wave-uniform bits: v_cmp into an SGPR pair + scalar ops
-                    const uint32_t nib = (__ballot(aeff[0] > 0.0f) ? 1u : 0u) | (__ballot(aeff[1] > 0.0f) ? 2u : 0u) |
-                                         (__ballot(aeff[2] > 0.0f) ? 4u : 0u) | (__ballot(aeff[3] > 0.0f) ? 8u : 0u);
-                    blended |= (unsigned long long)nib << k;
-                }
-                Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
-                Cbd = __builtin_elementwise_fma(v2f{c0.z, c0.w}, v2f{w[0], w[0]}, Cbd);
-                Crg = __builtin_elementwise_fma(v2f{c1.x, c1.y}, v2f{w[1], w[1]}, Crg);
-                Cbd = __builtin_elementwise_fma(v2f{c1.z, c1.w}, v2f{w[1], w[1]}, Cbd);
-                Crg = __builtin_elementwise_fma(v2f{c2.x, c2.y}, v2f{w[2], w[2]}, Crg);
-                Cbd = __builtin_elementwise_fma(v2f{c2.z, c2.w}, v2f{w[2], w[2]}, Cbd);
-                Crg = __builtin_elementwise_fma(v2f{c3.x, c3.y}, v2f{w[3], w[3]}, Crg);
-                Cbd = __builtin_elementwise_fma(v2f{c3.z, c3.w}, v2f{w[3], w[3]}, Cbd);
-                if (__all(live == 0.0f)) break;
+            if (!__any(amax > 0.0f)) return false;
+            float aeff[4], Tb[4], w[4];
+            blend_group4(T, live, e.alpha, aeff, Tb, w);
+            if (STORE) {                                         // wave-uniform bits: v_cmp into an SGPR pair + scalar ops
+                uint32_t nib = (__ballot(aeff[0] > 0.0f) ? 1u : 0u) | (__ballot(aeff[1] > 0.0f) ? 2u : 0u) |
+                               (__ballot(aeff[2] > 0.0f) ? 4u : 0u) | (__ballot(aeff[3] > 0.0f) ? 8u : 0u);
+                nib = __builtin_amdgcn_readfirstlane(nib);       // keep the mask in SGPRs
+                blended |= (unsigned long long)nib << k;
             }
+            Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
+            Cbd = __builtin_elementwise_fma(v2f{c0.z, c0.w}, v2f{w[0], w[0]}, Cbd);
+            Crg = __builtin_elementwise_fma(v2f{c1.x, c1.y}, v2f{w[1], w[1]}, Crg);
+            Cbd = __builtin_elementwise_fma(v2f{c1.z, c1.w}, v2f{w[1], w[1]}, Cbd);
+            Crg = __builtin_elementwise_fma(v2f{c2.x, c2.y}, v2f{w[2], w[2]}, Crg);
+            Cbd = __builtin_elementwise_fma(v2f{c2.z, c2.w}, v2f{w[2], w[2]}, Cbd);
+            Crg = __builtin_elementwise_fma(v2f{c3.x, c3.y}, v2f{w[3], w[3]}, Crg);
+            Cbd = __builtin_elementwise_fma(v2f{c3.z, c3.w}, v2f{w[3], w[3]}, Cbd);
+            return __all(live == 0.0f);
+        };
+        // two groups per trip with ping-pong operand registers: the operands of the next group are in flight during the
+        // current one, and no register-to-register rotation is needed (a `cur = nxt` copy cost 12 v_mov_b64 per group)
+        Ops4 opsA = load_ops4(s_b, 0);
+        for (int k = 0; k < cnt; k += 8) {
+            const Ops4 opsB = load_ops4(s_b, (k + 4) & 63);
+            if (group4(opsA, k)) break;
+            if (k + 4 >= cnt) break;
+            opsA = load_ops4(s_b, (k + 8) & 63);
+            if (group4(opsB, k + 4)) break;
         }
         if (STORE && lane == 0) a.bw.bmask[range.x / BATCH + (uint32_t)(entered - 1)] = blended;
         wave_lds_fence();
