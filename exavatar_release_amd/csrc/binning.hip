@@ -182,6 +182,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
     if (tid == 0) {
         uint32_t run = 0;
         for (int b = 32; b >= 0; --b) { const uint32_t n = s_bucket[b]; s_bucket[b] = run; run += n; }
+        // the empty cells sit at the end of cell_order: the per-cell kernels that follow stop at this count instead of
+        // sending a workgroup through three dependent loads for every empty cell (~75 % of the cells of an avatar view)
+        w.header->active_cells = s_bucket[0];
     }
     __syncthreads();
     for (int c = tid; c < cells; c += SCAN_THREADS) {
@@ -305,6 +308,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
+    if (blockIdx.x / BIN_PARTS >= w.header->active_cells) return;      // empty cell: nothing to count
     const CellPart cp = cell_part(w, a.capacity);
     const int tid = threadIdx.x;
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
@@ -330,6 +334,11 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
+    if (blockIdx.x / BIN_PARTS >= w.header->active_cells) {             // empty cell: part 0 publishes 64 empty ranges
+        if (blockIdx.x % BIN_PARTS == 0 && threadIdx.x < SUBS_PER_CELL)
+            w.ranges[w.cell_order[blockIdx.x / BIN_PARTS] * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+        return;
+    }
     const CellPart cp = cell_part(w, a.capacity);
     const int cell = cp.cell, tid = threadIdx.x;
     if (tid < 64) {

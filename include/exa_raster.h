@@ -65,7 +65,7 @@ typedef struct ExaRasterWorkspaceSizes {
     uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 40 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
-/* Device-side header at the start of the tile workspace (readable with a 20-byte D2H copy). */
+/* Device-side header at the start of the tile workspace (readable with a 24-byte D2H copy). */
 typedef struct ExaRasterHeader {
     uint32_t num_rendered;   /* instance capacity this call needs: 64 * batch slots (role of upstream's
                                 num_rendered: what the caller sizes the bin workspace with)   */
@@ -73,6 +73,7 @@ typedef struct ExaRasterHeader {
     uint32_t max_tile_list;  /* number of (Gaussian, 64x64 cell) entries                     */
     uint32_t num_visible;    /* V = Gaussians with radius > 0                                */
     uint32_t num_instances;  /* D = (Gaussian, 8x8 sub-tile) instances actually emitted      */
+    uint32_t active_cells;   /* 64x64-pixel cells that hold at least one instance            */
 } ExaRasterHeader;
 
 int exa_raster_version(void);

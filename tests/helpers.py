@@ -23,15 +23,18 @@ GAUSS_FLOOR = 1e-3
 GAUSS_FLOOR_AMBIGUOUS = 1e-1
 
 
-def grad_rel_err(got, ref):
-    """max-norm and L2 relative errors of a gradient tensor."""
+def grad_rel_err(got, ref, abs_scale=0.0):
+    """max-norm and L2 relative errors of a gradient tensor.  ``abs_scale``: the natural magnitude of this gradient
+    when the reference itself is (near) zero -- e.g. dL/d(rotation) of isotropic Gaussians is EXACTLY zero in the
+    oracle while any other evaluation order leaves rounding noise of a few ulp of |dL/d(scale)| * |scale|."""
     ref = ref.double()
     got = got.double()
-    scale = ref.abs().max().clamp_min(1e-30)
-    return float((got - ref).abs().max() / scale), float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+    scale = ref.abs().max().clamp_min(max(abs_scale, 1e-30))
+    l2s = ref.norm().clamp_min(max(abs_scale * ref.numel() ** 0.5, 1e-30))
+    return float((got - ref).abs().max() / scale), float((got - ref).norm() / l2s)
 
 
-def per_gaussian_excess(got, ref, near_ambiguous=None):
+def per_gaussian_excess(got, ref, near_ambiguous=None, abs_scale=0.0):
     """max over Gaussians of (|g_i - r_i|_inf - 1e-3 |r_i|_inf) / mean_j |r_j|_inf: the absolute floor (in units of the
     mean per-Gaussian gradient magnitude) a per-Gaussian 1e-3-relative check needs.  Returns (clean, ambiguous): the
     maximum over the Gaussians away from / near ambiguous pixels (``near_ambiguous``: bool [P] or None)."""
@@ -41,7 +44,7 @@ def per_gaussian_excess(got, ref, near_ambiguous=None):
         return 0.0, 0.0
     rn = ref.abs().amax(1)
     en = (got - ref).abs().amax(1)
-    scale = rn.mean().clamp_min(1e-30)
+    scale = rn.mean().clamp_min(max(abs_scale, 1e-30))
     ex = (en - GRAD_REL_TOL * rn) / scale
     if near_ambiguous is None or not bool(near_ambiguous.any()):
         return float(ex.max()), 0.0
@@ -91,16 +94,21 @@ def assert_image_close(got, ref, ambiguous, name='img', max_ambiguous=None, stat
     return st
 
 
-def grad_stats(got, ref, near_ambiguous=None):
+def grad_stats(got, ref, near_ambiguous=None, abs_scale=0.0):
     got, ref = got.detach().cpu(), ref.detach().cpu()
-    mx, l2 = grad_rel_err(got, ref)
-    clean, amb = per_gaussian_excess(got, ref, near_ambiguous)
+    mx, l2 = grad_rel_err(got, ref, abs_scale)
+    clean, amb = per_gaussian_excess(got, ref, near_ambiguous, abs_scale)
     return {'max_rel': mx, 'l2_rel': l2, 'per_gaussian_floor_needed': clean, 'per_gaussian_floor_needed_near_ambiguous': amb}
 
 
-def assert_grads_close(got, ref, name, near_ambiguous=None, per_gaussian=True):
+def rotation_grad_scale(scale, scale_grad_ref):
+    """Natural magnitude of dL/d(rotation): |dL/d(scale)| * |scale| (both enter Sigma = R S S^T R^T the same way)."""
+    return float(scale_grad_ref.detach().abs().max() * scale.detach().abs().max())
+
+
+def assert_grads_close(got, ref, name, near_ambiguous=None, per_gaussian=True, abs_scale=0.0):
     """Global 1e-3 relative (max-norm and L2) and -- for [P, ...] tensors -- per Gaussian."""
-    st = grad_stats(got, ref, near_ambiguous)
+    st = grad_stats(got, ref, near_ambiguous, abs_scale)
     assert st['max_rel'] <= GRAD_REL_TOL and st['l2_rel'] <= GRAD_REL_TOL, \
         'grad %s: max-rel %.3e, L2-rel %.3e' % (name, st['max_rel'], st['l2_rel'])
     if per_gaussian:

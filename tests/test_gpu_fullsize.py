@@ -12,7 +12,7 @@ import exavatar_release_amd as exa
 from exavatar_release_amd import scenes
 from exavatar_release_amd.camera import make_raster_matrices
 from oracle import raster_oracle as ro
-from tests.helpers import (assert_grads_close, assert_image_close, gaussians_near_pixels, grad_stats, image_stats,
+from tests.helpers import (assert_grads_close, assert_image_close, gaussians_near_pixels, rotation_grad_scale, grad_stats, image_stats,
                            record_stats)
 
 pytestmark = pytest.mark.gpu
@@ -52,7 +52,8 @@ def _full_parity(tag, assets, shape, cam, dev, max_ambiguous):
     near = gaussians_near_pixels(ref['aux']['pre'], amb)
     stats['gaussians_near_ambiguous_pixels'] = int(near.sum())
     for k in KEYS:
-        stats['grad_' + k] = grad_stats(a_gpu[k].grad, a_cpu[k].grad, near)
+        stats['grad_' + k] = grad_stats(a_gpu[k].grad, a_cpu[k].grad, near,
+                                        rotation_grad_scale(a_cpu['scale'], a_cpu['scale'].grad) if k == 'rotation' else 0.0)
     stats['grad_mean_2d'] = grad_stats(out['mean_2d'].grad, ref['mean_2d'].grad, near)
     record_stats(tag, stats)
     for name in ('img', 'depth', 'alpha'):
@@ -60,7 +61,8 @@ def _full_parity(tag, assets, shape, cam, dev, max_ambiguous):
     assert stats['radii_equal'], 'radii differ'
     assert torch.equal(out['is_vis'].cpu(), ref['is_vis'])
     for k in KEYS:
-        assert_grads_close(a_gpu[k].grad, a_cpu[k].grad, k, near)
+        assert_grads_close(a_gpu[k].grad, a_cpu[k].grad, k, near,
+                           abs_scale=rotation_grad_scale(a_cpu['scale'], a_cpu['scale'].grad) if k == 'rotation' else 0.0)
     assert_grads_close(out['mean_2d'].grad, ref['mean_2d'].grad, 'mean_2d', near)
     return stats
 
