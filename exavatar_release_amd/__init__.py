@@ -8,9 +8,9 @@ Public surface (drop-in for ``diff_gaussian_rasterization_depth`` as used at ref
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, check_overflow, config,
                          rasterize_gaussians, rasterize_gaussians_batch)
 from .densify import track_densify_stats
-from .losses import SSIM, RGBLoss
+from .losses import SSIM, PhotometricLoss, RGBLoss
 from .renderer import GaussianRenderer, render_many, render_views
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
            'rasterize_gaussians_batch', 'config', 'check_overflow', 'track_densify_stats', 'render_many', 'render_views',
-           'SSIM', 'RGBLoss']
+           'SSIM', 'RGBLoss', 'PhotometricLoss']

@@ -96,6 +96,12 @@ SIGNATURES = {
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),
     'exa_ssim_backward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 8),
+    'exa_photo_loss_blocks': (ctypes.c_int64, [_I32, _I32, _I32, _I32]),
+    'exa_photo_loss_forward': (ctypes.c_int, [_I32] * 4 + [ctypes.POINTER(ctypes.c_int32)] + [c_void_p] * 7),
+    'exa_photo_loss_grad': (ctypes.c_int, [_I32] * 4 + [ctypes.POINTER(ctypes.c_int32)] + [c_void_p] * 4 +
+                            [ctypes.c_float, ctypes.c_float] + [c_void_p] * 3),
+    'exa_l1_forward': (ctypes.c_int, [_I32] * 4 + [ctypes.POINTER(ctypes.c_int32)] + [c_void_p] * 6),
+    'exa_l1_backward': (ctypes.c_int, [_I32] * 4 + [ctypes.POINTER(ctypes.c_int32)] + [c_void_p] * 7),
     'exa_raster_timing_enable': (ctypes.c_int, [_I32]),
     'exa_raster_timing_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_float), _I32]),
     'exa_raster_timing_name': (ctypes.c_char_p, [_I32]),

@@ -422,6 +422,66 @@ int exa_ssim_backward(int32_t N, int32_t H, int32_t W, const float* img1, const 
     return 0;
 }
 
+static int check_crop(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop) {
+    if (B < 0 || C < 0 || H < 0 || W < 0) return fail(EXA_RASTER_E_INVALID, "negative size");
+    if (!crop) return fail(EXA_RASTER_E_NULLPTR, "crop is NULL");
+    if (crop[0] < 0 || crop[1] < 0 || crop[2] < 0 || crop[3] < 0 || crop[0] + crop[2] > W || crop[1] + crop[3] > H)
+        return fail(EXA_RASTER_E_INVALID, "crop window outside the image");
+    return 0;
+}
+
+int64_t exa_photo_loss_blocks(int32_t B, int32_t C, int32_t crop_w, int32_t crop_h) {
+    if (B < 0 || C < 0 || crop_w < 0 || crop_h < 0) return 0;
+    return (int64_t)B * C * ((crop_w + 31) / 32) * ((crop_h + 31) / 32);
+}
+
+int exa_photo_loss_forward(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                           const float* img_target, const float* l1_weight, const float* ssim_mask, float* maps_ws,
+                           float* partials, void* stream) {
+    int rc = check_crop(B, C, H, W, crop);
+    if (rc) return rc;
+    if ((int64_t)B * C * crop[2] * crop[3] > 0 && (!img_out || !img_target || !maps_ws || !partials))
+        return fail(EXA_RASTER_E_NULLPTR, "photo loss: NULL argument");
+    EXA_HIP(launch_photo_loss(B, C, H, W, crop, img_out, img_target, l1_weight, ssim_mask, 0.f, 0.f, maps_ws, partials,
+                              nullptr, 0, static_cast<hipStream_t>(stream)), "photo_stats");
+    return 0;
+}
+
+int exa_photo_loss_grad(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                        const float* img_target, const float* l1_weight, const float* ssim_mask, float w_l1, float w_ssim,
+                        const float* maps_ws, float* dL_dimg, void* stream) {
+    int rc = check_crop(B, C, H, W, crop);
+    if (rc) return rc;
+    if ((int64_t)B * C * crop[2] * crop[3] > 0 && (!img_out || !img_target || !maps_ws || !dL_dimg))
+        return fail(EXA_RASTER_E_NULLPTR, "photo loss: NULL argument");
+    EXA_HIP(launch_photo_loss(B, C, H, W, crop, img_out, img_target, l1_weight, ssim_mask, w_l1, w_ssim,
+                              const_cast<float*>(maps_ws), nullptr, dL_dimg, 1, static_cast<hipStream_t>(stream)), "photo_grad");
+    return 0;
+}
+
+int exa_l1_forward(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                   const float* img_target, const float* mask, const float* bg, float* l1_map, void* stream) {
+    int rc = check_crop(B, C, H, W, crop);
+    if (rc) return rc;
+    if ((int64_t)B * C * crop[2] * crop[3] > 0 && (!img_out || !img_target || !l1_map))
+        return fail(EXA_RASTER_E_NULLPTR, "l1: NULL argument");
+    EXA_HIP(launch_l1(B, C, H, W, crop, img_out, img_target, mask, bg, nullptr, l1_map, 0, static_cast<hipStream_t>(stream)),
+            "l1_fwd");
+    return 0;
+}
+
+int exa_l1_backward(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                    const float* img_target, const float* mask, const float* bg, const float* dL_dmap, float* dL_dimg,
+                    void* stream) {
+    int rc = check_crop(B, C, H, W, crop);
+    if (rc) return rc;
+    if ((int64_t)B * C * crop[2] * crop[3] > 0 && (!img_out || !img_target || !dL_dmap || !dL_dimg))
+        return fail(EXA_RASTER_E_NULLPTR, "l1: NULL argument");
+    EXA_HIP(launch_l1(B, C, H, W, crop, img_out, img_target, mask, bg, dL_dmap, dL_dimg, 1, static_cast<hipStream_t>(stream)),
+            "l1_bwd");
+    return 0;
+}
+
 int exa_raster_timing_enable(int32_t on) {
     if (on && !g_t.created) {
         for (int i = 0; i < K_COUNT; ++i)

@@ -292,6 +292,11 @@ hipError_t launch_ssim_fwd(int N, int H, int W, const float* img1, const float* 
 hipError_t launch_ssim_bwd(int N, int H, int W, const float* img1, const float* img2, const float* dL_dmap,
                            const float* dm_dmu1, const float* dm_dE11, const float* dm_dE12, float* dL_dimg1,
                            hipStream_t s);
+hipError_t launch_photo_loss(int B, int C, int H, int W, const int* crop, const float* x, const float* y, const float* l1w,
+                             const float* smask, float w_l1, float w_ssim, float* maps, float* partials, float* dL_dx,
+                             int stage, hipStream_t s);
+hipError_t launch_l1(int B, int C, int H, int W, const int* crop, const float* x, const float* y, const float* mask,
+                     const float* bg, const float* g, float* out, int backward, hipStream_t s);
 hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, float* accum, float* cnt, float* rmax,
                                 hipStream_t s);
 

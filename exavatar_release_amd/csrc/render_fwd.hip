@@ -269,35 +269,30 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
     if (blockIdx.x == ORDER_WGS && tid == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
-    // Grid-stride loop over the sub-tiles of the ACTIVE cells only (cell_order lists them first, heaviest first;
-    // header.active_cells counts them): an avatar view has ~3 800 non-empty lists in 16 384 sub-tiles, and a workgroup
-    // per sub-tile spent half of this launch walking empty ones through two dependent loads each.
-    const int n_work = (int)a.tw.header->active_cells * SUBS_PER_CELL;
-    const int stride = (int)gridDim.x - ORDER_WGS;
-    bool first = true;
-    for (int wg = (int)blockIdx.x - ORDER_WGS; wg < n_work; wg += stride) {
-        if (!first) __syncthreads();                            // the previous list is done with s_buf
-        first = false;
-        const int st = (int)a.tw.cell_order[wg >> 6] * SUBS_PER_CELL + (wg & 63);
-        const uint2 range = a.tw.ranges[st];
-        const int n = (int)(range.y - range.x);                 // workgroup-uniform; empty on overflow
-        if (n == 0) continue;
-        const unsigned long long* gkeys = a.bw.keys + range.x;
-        uint32_t* sorted = a.bw.sorted + range.x;
-        if (n <= 64) {
-            if (tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);
-        } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);      // (a plain O(n^2) rank sort of the whole
-        else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);        //  list was 40 % slower: LDS-pipe bound)
-        else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
-        else if (n <= 2048) lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
-        else   // longer lists: 2048 own keys at a time against the whole list (any length)
-            for (int first_key = 0; first_key < n; first_key += 8 * SBLOCK)
-                rank_sort_list<8>(gkeys, n, first_key, sorted, s_buf, tid);
+    // Only the sub-tiles of the ACTIVE cells hold lists (cell_order lists those cells first, heaviest first;
+    // header.active_cells counts them): an avatar view has ~3 800 non-empty lists in 16 384 sub-tiles, and the
+    // workgroups of the empty ones leave after ONE scalar load instead of two dependent vector loads.  (A
+    // grid-stride loop over the active sub-tiles with a smaller grid cost 2.5x the registers and ran slower.)
+    const int wg = (int)blockIdx.x - ORDER_WGS;
+    if (wg >= (int)a.tw.header->active_cells * SUBS_PER_CELL) return;
+    const int st = (int)a.tw.cell_order[wg >> 6] * SUBS_PER_CELL + (wg & 63);
+    const uint2 range = a.tw.ranges[st];
+    const int n = (int)(range.y - range.x);                     // workgroup-uniform; empty on overflow
+    if (n == 0) return;
+    const unsigned long long* gkeys = a.bw.keys + range.x;
+    uint32_t* sorted = a.bw.sorted + range.x;
+    if (n <= 64) {
+        if (tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);
+    } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);      // (a plain O(n^2) rank sort of the whole
+    else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);        //  list was 40 % slower: LDS-pipe bound)
+    else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
+    else if (n <= 2048) lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
+    else   // longer lists: 2048 own keys at a time against the whole list (any length)
+        for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
 #ifdef EXA_PROBE_SORT
-        __syncthreads();
-        if (tid == 0) a.tw.part_cnt[st] = (uint32_t)(__builtin_readcyclecounter() - t0);      // probe build only
+    __syncthreads();
+    if (tid == 0) a.tw.part_cnt[st] = (uint32_t)(__builtin_readcyclecounter() - t0);      // probe build only
 #endif
-    }
 }
 
 // ---- blend ---------------------------------------------------------------------------------------------
@@ -446,9 +441,7 @@ static int max_subtiles(const RenderFwdArgs* a, int K) {
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
-    // at most SORT_WGS sorting workgroups per job (two resident rounds of the chip): they stride over the active sub-tiles
-    constexpr int SORT_WGS = 4096;
-    sort_subtiles_kernel<<<dim3((subtiles < SORT_WGS ? subtiles : SORT_WGS) + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
+    sort_subtiles_kernel<<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
     return hipGetLastError();
 }
 

@@ -147,6 +147,223 @@ static SsimWindow make_window() {
     return w;
 }
 
+// =====================================================================================================================
+// Fused photometric loss: the weighted L1 + (1 - SSIM) objective of one render -- reference
+// avatar/main/model.py:197-198,204-205,214-215 with the classes of avatar/common/nets/loss.py:11-74 -- evaluated in TWO
+// kernels that hand render_bwd its dL/d(image) directly:
+//     loss = w_l1 * mean(l1w * |x - y|) + w_ssim * mean(1 - ssim(x * m, y * m))        over the bbox crop
+// photo_stats_kernel: SSIM statistics of a 32x32 output tile (42x42 halo tile in LDS, separable 11-tap passes with
+//     four outputs per thread so that every LDS value feeds four sums), the three partial-derivative maps, and this
+//     tile's partial sums of the SSIM map and of the L1 term (plain stores: deterministic, no atomics).
+// photo_grad_kernel: the second 11x11 pass over the derivative maps + the L1 sign term, scaled by the loss weights and
+//     the 1 / N of the two means -> dL/dx, written once.  The crop window is the image as far as SSIM's zero padding is
+//     concerned (the reference crops BEFORE the convolutions, loss.py:50-58).
+// Replaces, per render: 5 grouped conv2d + ~25 elementwise / reduction kernels forward and their autograd graph.
+// HBM bytes per pixel and channel: stats reads 8 (+ masks) and writes 12, grad reads 12 + 8 and writes 4.
+constexpr int PT = 32;                 // output tile edge
+constexpr int PI = PT + 2 * SR;        // 42: input tile edge with halo
+constexpr int PBLOCK2 = 256;
+
+struct PhotoArgs {
+    int C, H, W;                       // channels per image, full image size
+    int cx0, cy0, cw, ch;              // crop window (clamped bbox) = the image the SSIM convolutions see
+    const float* x; const float* y;    // [B, C, H, W]
+    const float* l1w;                  // [B, 1, H, W] weight of the L1 term, or NULL (= 1)
+    const float* smask;                // [B, 1, H, W] mask multiplied into both images before SSIM, or NULL
+    float* maps;                       // [3][B * C][ch][cw] derivative maps
+    float* partials;                   // [blocks][2]: sum of ssim, sum of l1w |x - y|
+    float k_l1, k_ssim;                // w_l1 / N and w_ssim / N
+    float* dL_dx;                      // [B, C, H, W] (only the crop window is written)
+};
+
+__device__ __forceinline__ float crop_load(const float* __restrict__ p, const float* __restrict__ m, int lx, int ly,
+                                           const PhotoArgs& a) {
+    if (lx < 0 || lx >= a.cw || ly < 0 || ly >= a.ch) return 0.0f;
+    const size_t o = (size_t)(a.cy0 + ly) * a.W + (a.cx0 + lx);
+    const float v = p[o];
+    return m ? v * m[o] : v;
+}
+
+__global__ __launch_bounds__(PBLOCK2) void photo_stats_kernel(PhotoArgs a, SsimWindow win) {
+    __shared__ float s_x[PI][PI + 1], s_y[PI][PI + 1];
+    __shared__ float s_h[5][PI][PT + 1];
+    __shared__ float s_red[2][PBLOCK2 / 64];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;                                   // plane = image * C + channel
+    const size_t plane = (size_t)n * a.H * a.W, mplane = (size_t)(n / a.C) * a.H * a.W;
+    const float* __restrict__ px = a.x + plane;
+    const float* __restrict__ py = a.y + plane;
+    const float* __restrict__ pm = a.smask ? a.smask + mplane : nullptr;
+    const int ox = blockIdx.x * PT - SR, oy = blockIdx.y * PT - SR;
+    for (int i = tid; i < PI * PI; i += PBLOCK2) {
+        const int ly = i / PI, lx = i - ly * PI;
+        s_x[ly][lx] = crop_load(px, pm, ox + lx, oy + ly, a);
+        s_y[ly][lx] = crop_load(py, pm, ox + lx, oy + ly, a);
+    }
+    __syncthreads();
+    // horizontal pass: PI rows x PT columns, four adjacent columns per item (14 LDS values feed 4 x 11 taps)
+    for (int i = tid; i < PI * (PT / 4); i += PBLOCK2) {
+        const int ly = i / (PT / 4), c0 = (i - ly * (PT / 4)) * 4;
+        float xv[14], yv[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { xv[k] = s_x[ly][c0 + k]; yv[k] = s_y[ly][c0 + k]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * SR + 1; ++k) {
+                const float wk = win.g[k], xx = xv[j + k], yy = yv[j + k];
+                m1 = fmaf(wk, xx, m1); m2 = fmaf(wk, yy, m2);
+                e11 = fmaf(wk, xx * xx, e11); e22 = fmaf(wk, yy * yy, e22); e12 = fmaf(wk, xx * yy, e12);
+            }
+            s_h[0][ly][c0 + j] = m1; s_h[1][ly][c0 + j] = m2; s_h[2][ly][c0 + j] = e11; s_h[3][ly][c0 + j] = e22;
+            s_h[4][ly][c0 + j] = e12;
+        }
+    }
+    __syncthreads();
+    // vertical pass: thread = (column tx, rows 4 ty .. 4 ty + 3)
+    const int tx = tid & (PT - 1), ty = tid / PT;
+    float acc[4][5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[j][q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[k] = s_h[q][ty * 4 + k][tx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 2 * SR + 1; ++k) acc[j][q] = fmaf(win.g[k], v[j + k], acc[j][q]);
+    }
+    float sum_ssim = 0.f, sum_l1 = 0.f;
+    const int lx = blockIdx.x * PT + tx;
+    const size_t map_plane = (size_t)a.cw * a.ch, n_planes = (size_t)gridDim.z;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ly = blockIdx.y * PT + ty * 4 + j;
+        if (lx >= a.cw || ly >= a.ch) continue;
+        const float mu1 = acc[j][0], mu2 = acc[j][1], e11 = acc[j][2], e22 = acc[j][3], e12 = acc[j][4];
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+        const float A = 2.0f * mu12 + SSIM_C1, B = 2.0f * s12 + SSIM_C2;
+        const float Cc = mu1_sq + mu2_sq + SSIM_C1, D = s1 + s2 + SSIM_C2;
+        const float inv_CD = 1.0f / (Cc * D);
+        sum_ssim += A * B * inv_CD;
+        const size_t o = (size_t)n * map_plane + (size_t)ly * a.cw + lx;
+        a.maps[o] = 2.0f * (mu2 * (B - A) * Cc * D - mu1 * A * B * (D - Cc)) * inv_CD * inv_CD;
+        a.maps[n_planes * map_plane + o] = -A * B * inv_CD / D;
+        a.maps[2 * n_planes * map_plane + o] = 2.0f * A * inv_CD;
+        const size_t g = (size_t)(a.cy0 + ly) * a.W + (a.cx0 + lx);
+        const float d = fabsf(px[g] - py[g]);
+        sum_l1 += a.l1w ? d * a.l1w[mplane + g] : d;
+    }
+    // deterministic block reduction -> one pair of partial sums per workgroup
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { sum_ssim += __shfl_xor(sum_ssim, d, 64); sum_l1 += __shfl_xor(sum_l1, d, 64); }
+    if ((tid & 63) == 0) { s_red[0][tid >> 6] = sum_ssim; s_red[1][tid >> 6] = sum_l1; }
+    __syncthreads();
+    if (tid == 0) {
+        const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        a.partials[2 * b] = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+        a.partials[2 * b + 1] = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+    }
+}
+
+__global__ __launch_bounds__(PBLOCK2) void photo_grad_kernel(PhotoArgs a, SsimWindow win) {
+    __shared__ float s_in[3][PI][PI + 1];
+    __shared__ float s_h[3][PI][PT + 1];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const size_t plane = (size_t)n * a.H * a.W, mplane = (size_t)(n / a.C) * a.H * a.W;
+    const size_t map_plane = (size_t)a.cw * a.ch, n_planes = (size_t)gridDim.z;
+    const int ox = blockIdx.x * PT - SR, oy = blockIdx.y * PT - SR;
+    for (int i = tid; i < PI * PI; i += PBLOCK2) {
+        const int ly = i / PI, lx = i - ly * PI;
+        const int x = ox + lx, y = oy + ly;
+        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+        if (x >= 0 && x < a.cw && y >= 0 && y < a.ch) {
+            const size_t o = (size_t)n * map_plane + (size_t)y * a.cw + x;
+            m0 = a.maps[o]; m1 = a.maps[n_planes * map_plane + o]; m2 = a.maps[2 * n_planes * map_plane + o];
+        }
+        s_in[0][ly][lx] = m0; s_in[1][ly][lx] = m1; s_in[2][ly][lx] = m2;
+    }
+    __syncthreads();
+    for (int i = tid; i < PI * (PT / 4); i += PBLOCK2) {
+        const int ly = i / (PT / 4), c0 = (i - ly * (PT / 4)) * 4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float v[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) v[k] = s_in[q][ly][c0 + k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * SR + 1; ++k) s = fmaf(win.g[k], v[j + k], s);
+                s_h[q][ly][c0 + j] = s;
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = tid & (PT - 1), ty = tid / PT;
+    float acc[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; ++k) v[k] = s_h[q][ty * 4 + k][tx];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 2 * SR + 1; ++k) acc[j][q] = fmaf(win.g[k], v[j + k], acc[j][q]);
+    }
+    const int lx = blockIdx.x * PT + tx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ly = blockIdx.y * PT + ty * 4 + j;
+        if (lx >= a.cw || ly >= a.ch) continue;
+        const size_t g = (size_t)(a.cy0 + ly) * a.W + (a.cx0 + lx);
+        const float xr = a.x[plane + g], yr = a.y[plane + g];
+        const float m = a.smask ? a.smask[mplane + g] : 1.0f;
+        // d mean(1 - ssim(x m, y m)) / dx = -(1/N) m [c0 + 2 (x m) c1 + (y m) c2]
+        const float gs = -a.k_ssim * m * (acc[j][0] + 2.0f * (xr * m) * acc[j][1] + (yr * m) * acc[j][2]);
+        const float d = xr - yr;
+        const float sgn = (d > 0.0f ? 1.0f : 0.0f) - (d < 0.0f ? 1.0f : 0.0f);
+        const float gl = a.k_l1 * sgn * (a.l1w ? a.l1w[mplane + g] : 1.0f);
+        a.dL_dx[plane + g] = gs + gl;
+    }
+}
+
+// L1 map of reference RGBLoss (avatar/common/nets/loss.py:11-29) as one kernel: |x - t| over the crop window with
+// t = y * mask + (1 - mask) * bg when a mask and a background colour are given; and its backward sign(x - t) * g.
+struct L1Args {
+    int C, H, W, cx0, cy0, cw, ch;
+    const float* x; const float* y; const float* mask; const float* bg;       // mask [B,1,H,W], bg [B,C] or NULL
+    const float* g; float* out;                                                 // forward: out = map [B,C,ch,cw];
+};                                                                              // backward: g = dL/dmap, out = dL/dx [B,C,H,W]
+template <bool BWD>
+__global__ __launch_bounds__(BLOCK) void l1_kernel(L1Args a, size_t total) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= total) return;
+    const int lx = (int)(i % a.cw), ly = (int)((i / a.cw) % a.ch);
+    const size_t n = i / ((size_t)a.cw * a.ch);                 // plane = image * C + channel
+    const size_t g = (size_t)(a.cy0 + ly) * a.W + (a.cx0 + lx);
+    const size_t o = n * a.H * a.W + g;
+    float t = a.y[o];
+    if (a.mask && a.bg) {
+        const float m = a.mask[(n / a.C) * (size_t)a.H * a.W + g];
+        t = t * m + (1.0f - m) * a.bg[n];
+    }
+    const float d = a.x[o] - t;
+    if (BWD) a.out[o] = ((d > 0.0f ? 1.0f : 0.0f) - (d < 0.0f ? 1.0f : 0.0f)) * a.g[i];
+    else a.out[i] = fabsf(d);
+}
+
 hipError_t launch_ssim_fwd(int N, int H, int W, const float* img1, const float* img2, float* map, float* dm_dmu1,
                            float* dm_dE11, float* dm_dE12, hipStream_t s) {
     if (N == 0 || H == 0 || W == 0) return hipSuccess;
@@ -161,6 +378,35 @@ hipError_t launch_ssim_bwd(int N, int H, int W, const float* img1, const float* 
     if (N == 0 || H == 0 || W == 0) return hipSuccess;
     const dim3 grid((W + ST - 1) / ST, (H + ST - 1) / ST, N), block(ST, ST, 1);
     ssim_bwd_kernel<<<grid, block, 0, s>>>(H, W, img1, img2, dL_dmap, dm_dmu1, dm_dE11, dm_dE12, dL_dimg1, make_window());
+    return hipGetLastError();
+}
+
+hipError_t launch_photo_loss(int B, int C, int H, int W, const int* crop, const float* x, const float* y, const float* l1w,
+                             const float* smask, float w_l1, float w_ssim, float* maps, float* partials, float* dL_dx,
+                             int stage, hipStream_t s) {
+    PhotoArgs a;
+    a.C = C; a.H = H; a.W = W; a.cx0 = crop[0]; a.cy0 = crop[1]; a.cw = crop[2]; a.ch = crop[3];
+    if (B * C == 0 || a.cw <= 0 || a.ch <= 0) return hipSuccess;
+    a.x = x; a.y = y; a.l1w = l1w; a.smask = smask; a.maps = maps; a.partials = partials; a.dL_dx = dL_dx;
+    const float inv_n = 1.0f / ((float)B * (float)C * (float)a.cw * (float)a.ch);
+    a.k_l1 = w_l1 * inv_n; a.k_ssim = w_ssim * inv_n;
+    const dim3 grid((a.cw + PT - 1) / PT, (a.ch + PT - 1) / PT, B * C);
+    if (stage == 0) photo_stats_kernel<<<grid, PBLOCK2, 0, s>>>(a, make_window());
+    else photo_grad_kernel<<<grid, PBLOCK2, 0, s>>>(a, make_window());
+    return hipGetLastError();
+}
+
+hipError_t launch_l1(int B, int C, int H, int W, const int* crop, const float* x, const float* y, const float* mask,
+                     const float* bg, const float* g, float* out, int backward, hipStream_t s) {
+    L1Args a;
+    a.C = C; a.H = H; a.W = W; a.cx0 = crop[0]; a.cy0 = crop[1]; a.cw = crop[2]; a.ch = crop[3];
+    a.x = x; a.y = y; a.mask = mask; a.bg = bg; a.g = g; a.out = out;
+    if (a.cw <= 0 || a.ch <= 0) return hipSuccess;
+    const size_t total = (size_t)B * C * a.cw * a.ch;
+    if (total == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((total + BLOCK - 1) / BLOCK);
+    if (backward) l1_kernel<true><<<blocks, BLOCK, 0, s>>>(a, total);
+    else l1_kernel<false><<<blocks, BLOCK, 0, s>>>(a, total);
     return hipGetLastError();
 }
 

@@ -222,6 +222,33 @@ int exa_ssim_backward(int32_t N, int32_t H, int32_t W, const float* img1, const 
                       void* stream);
 
 /*
+ * Fused photometric loss of one render: the weighted L1 + (1 - SSIM) objective the reference builds from
+ * class RGBLoss and class SSIM (avatar/common/nets/loss.py:11-74) at avatar/main/model.py:197-198, 204-205, 214-215
+ *     loss = w_l1 * mean(l1_weight * |x - y|) + w_ssim * mean(1 - ssim(x * ssim_mask, y * ssim_mask))
+ * over the crop window `crop` = {x0, y0, w, h} (the clamped bbox; the SSIM convolutions zero-pad at ITS border, as the
+ * reference crops first, loss.py:50-58).  img_out / img_target: [B, C, H, W]; l1_weight, ssim_mask: [B, 1, H, W] or NULL.
+ *   exa_photo_loss_forward  one kernel: SSIM statistics, the three partial-derivative maps (maps_ws: 3 * B * C * w * h
+ *       floats) and per-workgroup partial sums (partials: 2 floats x exa_photo_loss_blocks(): sum of the SSIM map, sum
+ *       of l1_weight |x - y|; the caller adds them up and forms the loss value).
+ *   exa_photo_loss_grad     one kernel: dL/d(img_out) inside the crop window (the caller zero-fills dL_dimg outside it),
+ *       ready to be handed to exa_raster_backward as dL_dcolor.
+ * exa_l1_forward / exa_l1_backward: the L1 map of RGBLoss alone -- |x - t| over the crop with t = y * mask + (1 - mask) * bg
+ * when mask [B,1,H,W] and bg [B,C] are given (loss.py:15-17) -- and sign(x - t) * dL_dmap.
+ */
+int64_t exa_photo_loss_blocks(int32_t B, int32_t C, int32_t crop_w, int32_t crop_h);
+int exa_photo_loss_forward(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                           const float* img_target, const float* l1_weight, const float* ssim_mask, float* maps_ws,
+                           float* partials, void* stream);
+int exa_photo_loss_grad(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                        const float* img_target, const float* l1_weight, const float* ssim_mask, float w_l1, float w_ssim,
+                        const float* maps_ws, float* dL_dimg, void* stream);
+int exa_l1_forward(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                   const float* img_target, const float* mask, const float* bg, float* l1_map, void* stream);
+int exa_l1_backward(int32_t B, int32_t C, int32_t H, int32_t W, const int32_t* crop, const float* img_out,
+                    const float* img_target, const float* mask, const float* bg, const float* dL_dmap, float* dL_dimg,
+                    void* stream);
+
+/*
  * Optional per-kernel timing for benchmarks (the only state the library ever keeps, process-wide,
  * off by default, not thread-safe).  While enabled, every kernel / memset the library enqueues is bracketed by a
  * pair of hipEvents recorded on the caller's stream.  exa_raster_timing_read() synchronises on the

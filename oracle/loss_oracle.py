@@ -63,3 +63,13 @@ def ssim_map(img_out, img_target, bbox=None, mask=None, window_size=11):
     C1 = 0.01 ** 2
     C2 = 0.03 ** 2
     return ((2 * mu1_mu2 + C1) * (2 * sigma1_sigma2 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
+
+
+def photometric_loss(img_out, img_target, bbox=None, l1_weight=None, ssim_mask=None, w_l1=0.8, w_ssim=0.2):
+    """The per-render objective the reference assembles from the two classes above (avatar/main/model.py:197-198 for the
+    human renders, :214-215 for the scene render with l1_weight = ssim_mask = 1 - mask; weights config.py:35-36; the
+    ``.mean()`` is avatar/main/train.py:43):  (rgb_loss * w_l1 [* l1_weight]).mean() + ((1 - ssim) * w_ssim).mean()."""
+    l1 = rgb_loss(img_out, img_target, bbox=bbox)
+    if l1_weight is not None:
+        l1 = l1 * (l1_weight if bbox is None else _crop(l1_weight, l1_weight, bbox)[0])
+    return (l1 * w_l1).mean() + ((1 - ssim_map(img_out, img_target, bbox=bbox, mask=ssim_mask)) * w_ssim).mean()

@@ -49,6 +49,19 @@ try:
         (m * Gm[:, :, :m.shape[2], :m.shape[3]]).sum().backward()
         out['rgb_' + name] = m.detach().numpy()
         out['rgb_' + name + '_grad'] = xi.grad.numpy()
+    # the per-render objectives of avatar/main/model.py:197-198 (human: bbox) and :214-215 (scene: 1 - mask), assembled
+    # from the reference's own classes with the weights of avatar/main/config.py:35-36 and train.py:43's .mean()
+    W_RGB, W_SSIM = 0.8, 0.2
+    xi = x.clone().requires_grad_(True)
+    L = (rgb(xi, y, bbox=bbox) * W_RGB).mean() + ((1 - ssim(xi, y, bbox=bbox)) * W_SSIM).mean()
+    L.backward()
+    out['photo_human'] = L.detach().numpy()
+    out['photo_human_grad'] = xi.grad.numpy()
+    xi = x.clone().requires_grad_(True)
+    L = (rgb(xi, y) * (1 - mask) * W_RGB).mean() + ((1 - ssim(xi, y, mask=1 - mask)) * W_SSIM).mean()
+    L.backward()
+    out['photo_scene'] = L.detach().numpy()
+    out['photo_scene_grad'] = xi.grad.numpy()
     out.update(x=x.numpy(), y=y.numpy(), mask=mask.numpy(), bbox=bbox.numpy(), bg=bg.numpy(), G=Gm.numpy())
 finally:
     torch.Tensor.cuda = _cuda

@@ -618,3 +618,64 @@ def test_fused_ssim_matches_oracle_at_other_sizes(dev, shape):
     (mg * G.to(dev)).sum().backward()
     assert float((mg.detach().cpu() - mc.detach()).abs().max()) <= SSIM_MAP_TOL
     assert float((xg.grad.cpu() - xc.grad).abs().max()) <= SSIM_GRAD_TOL * float(xc.grad.abs().max())
+
+
+def test_fused_photometric_loss_matches_reference_golden(dev, golden_dir):
+    """SURVEY 8f-4, PINNED: the two-kernel L1 + (1 - SSIM) objective and its dL/d(image) against values and autograd
+    gradients produced by the reference's own RGBLoss / SSIM classes combined as avatar/main/model.py:197-198 (human
+    render, bbox crop) and :214-215 (scene render, 1 - mask) do (tests/golden/make_golden_ssim.py)."""
+    z = np.load(os.path.join(golden_dir, 'ref_ssim.npz'))
+    t = lambda k: torch.tensor(z[k]).to(dev)
+    x, y, mask, bbox = t('x'), t('y'), t('mask'), torch.tensor(z['bbox'])
+    crit = exa.PhotometricLoss()
+    for name, kw in (('human', {'bbox': bbox}), ('scene', {'l1_weight': 1 - mask, 'ssim_mask': 1 - mask})):
+        xi = x.clone().requires_grad_(True)
+        L, l1m, ssm = crit(xi, y, return_terms=True, **kw)
+        (3.0 * L).backward()                                     # a non-unit upstream gradient
+        ref_L, ref_g = float(z['photo_' + name]), t('photo_' + name + '_grad')
+        assert abs(float(L) - ref_L) <= 2e-6, (name, float(L), ref_L)
+        assert float((xi.grad / 3.0 - ref_g).abs().max()) <= SSIM_GRAD_TOL * float(ref_g.abs().max()), name
+        assert abs(0.8 * float(l1m) + 0.2 * (1 - float(ssm)) - float(L)) <= 1e-6
+
+
+def test_fused_photometric_loss_feeds_the_rasterizer_backward(dev):
+    """End to end: render -> PhotometricLoss -> backward; same parameter gradients as the composed-ops loss built from the
+    SSIM / RGBLoss drop-ins on the same render (ragged size: tiles cut by the border, bbox crop)."""
+    H, W = 150, 200
+    f = 240.0
+    a = scenes.dist_a_random(3000, H, W, seed=51, focal=f)
+    cam = {k: v.to(dev) for k, v in scenes.neutral_camera(H, W, focal=f).items()}
+    g = torch.Generator().manual_seed(52)
+    target = torch.rand(1, 3, H, W, generator=g).to(dev)
+    bbox = torch.tensor([[20.0, -4.0, 150.0, 120.0]])
+    rend, crit = exa.GaussianRenderer(), exa.PhotometricLoss()
+    grads = []
+    for fused in (True, False):
+        ag = _to(a, dev)
+        img = rend(ag, (H, W), cam, torch.ones(3, device=dev))['img'][None]
+        if fused:
+            L = crit(img, target, bbox=bbox)
+        else:
+            L = (exa.RGBLoss()(img, target, bbox=bbox) * 0.8).mean() + ((1 - exa.SSIM()(img, target, bbox=bbox)) * 0.2).mean()
+        L.backward()
+        grads.append((float(L), {k: ag[k].grad.clone() for k in KEYS}))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6
+    for k in KEYS:
+        d = (grads[0][1][k] - grads[1][1][k]).abs().max()
+        assert float(d) <= 1e-4 * float(grads[1][1][k].abs().max()), k
+
+
+def test_ssim_is_differentiable_in_the_target_too(dev):
+    """The reference's SSIM is plain autograd and differentiates both arguments (loss.py:31-74); the fused kernels get the
+    target's gradient from the symmetric call."""
+    from oracle import loss_oracle as lo
+    g = torch.Generator().manual_seed(61)
+    x = torch.rand(1, 3, 45, 70, generator=g)
+    y = (x + 0.15 * torch.randn(1, 3, 45, 70, generator=g)).clamp(0, 1)
+    G = torch.randn(1, 3, 45, 70, generator=g)
+    xc, yc = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    (lo.ssim_map(xc, yc) * G).sum().backward()
+    xg, yg = x.to(dev).requires_grad_(True), y.to(dev).requires_grad_(True)
+    (exa.SSIM()(xg, yg) * G.to(dev)).sum().backward()
+    for got, ref in ((xg.grad, xc.grad), (yg.grad, yc.grad)):
+        assert float((got.cpu() - ref).abs().max()) <= SSIM_GRAD_TOL * float(ref.abs().max())

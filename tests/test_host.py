@@ -17,13 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     src = open(os.path.join(ROOT, 'include', 'exa_raster.h')).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
-    return sorted(set(re.findall(r'\b(exa_raster_\w+)\s*\(', src)))
+    return sorted(set(re.findall(r'\b(exa_(?:raster|ssim|photo|l1)_\w+)\s*\(', src)))
 
 
 def test_library_exports_every_symbol_the_header_declares():
     lib = _lib.load()
     names = _declared_functions()
-    assert len(names) >= 11
+    assert len(names) >= 23
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n

@@ -321,3 +321,10 @@ def test_loss_oracle_matches_reference_class_outputs(golden_dir):
         (m * G[:, :, :m.shape[2], :m.shape[3]]).sum().backward()
         assert torch.equal(m.detach(), torch.tensor(z['rgb_' + name]))
         assert torch.equal(xi.grad, torch.tensor(z['rgb_' + name + '_grad']))
+    # the per-render objective assembled from both classes (human render: bbox; scene render: 1 - mask)
+    for name, kw in (('human', {'bbox': bbox}), ('scene', {'l1_weight': 1 - mask, 'ssim_mask': 1 - mask})):
+        xi = x.clone().requires_grad_(True)
+        L = lo.photometric_loss(xi, y, **kw)
+        L.backward()
+        assert abs(float(L) - float(z['photo_' + name])) <= 1e-6
+        assert torch.allclose(xi.grad, torch.tensor(z['photo_' + name + '_grad']), rtol=1e-5, atol=1e-9)
