@@ -1,0 +1,271 @@
+"""Torch-only stand-ins for the ``pytorch3d`` operators on ExAvatar's path to the renderer.
+
+``pytorch3d`` has no ROCm wheel in this environment and the reference imports it at module import time
+(``avatar/common/nets/module.py:4-5,13``, ``avatar/common/utils/smpl_x.py:9-12``), which is what keeps every
+non-synthetic configuration from running on MI355X at all.  The reference uses a small, fixed subset:
+
+* ``knn_points(p1, p2, K, return_nn=True)`` -- ``module.py:86`` (K = 4: initial scale of the scene Gaussians from the
+  mean squared distance to the 3 nearest other points) and ``module.py:543`` (K = 1: nearest template vertex);
+* ``SubdivideMeshes`` / ``Meshes`` -- ``smpl_x.py:73-100`` (two 4:1 subdivisions of the SMPL-X template, with vertex
+  features carried along);
+* ``Meshes(...).verts_normals_packed()`` -- ``module.py:502``, ``smpl_x.py:140``, ``loss.py:156``;
+* ``matrix_to_rotation_6d`` / ``rotation_6d_to_matrix`` / ``matrix_to_quaternion`` / ``quaternion_to_matrix`` /
+  ``axis_angle_to_matrix`` -- ``module.py:4``.
+
+None of their source is in the reference tree (third-party package, not vendored): the functions below restate the
+PUBLISHED algorithms of pytorch3d (``ops/knn.py``, ``ops/subdivide_meshes.py`` ``subdivide_homogeneous``,
+``structures/meshes.py`` ``_compute_edges_packed`` / ``_compute_vertex_normals``, ``transforms/rotation_conversions.py``)
+with the same argument names, return types and orderings, in plain PyTorch -- they run on ROCm and CPU tensors alike and
+are differentiable wherever pytorch3d's are.  tests/test_standins.py pins them with brute-force and analytic checks.
+"""
+from collections import namedtuple
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_KNN = namedtuple('KNN', 'dists idx knn')
+
+
+def knn_points(p1, p2, lengths1=None, lengths2=None, norm: int = 2, K: int = 1, version: int = -1,
+               return_nn: bool = False, return_sorted: bool = True):
+    """K nearest neighbours in ``p2`` [N, P2, D] of every point of ``p1`` [N, P1, D].
+
+    Returns ``KNN(dists [N, P1, K] squared Euclidean distances (ascending), idx [N, P1, K], knn [N, P1, K, D] or None)``
+    like ``pytorch3d.ops.knn_points``.  Brute force in blocks of rows (a 150 k x 150 k distance matrix never exists in
+    memory); ties are broken towards the lower index, as a stable sort would.
+    """
+    if norm != 2:
+        raise NotImplementedError('knn_points stand-in: squared L2 distances only (what the reference uses)')
+    if lengths1 is not None or lengths2 is not None:
+        raise NotImplementedError('knn_points stand-in: padded batches are not used by the reference')
+    if p1.dim() != 3 or p2.dim() != 3 or p1.shape[0] != p2.shape[0] or p1.shape[2] != p2.shape[2]:
+        raise ValueError('knn_points expects p1 [N, P1, D] and p2 [N, P2, D]')
+    N, P1, D = p1.shape
+    P2 = p2.shape[1]
+    K = min(K, P2)
+    idx = torch.empty((N, P1, K), dtype=torch.int64, device=p1.device)
+    block = max(1, min(P1, (1 << 25) // max(P2, 1)))           # ~128 MiB of fp32 distances per block
+    with torch.no_grad():
+        for n in range(N):
+            b = p2[n]
+            b2 = (b * b).sum(1)
+            for s in range(0, P1, block):
+                a = p1[n, s:s + block]
+                # |a - b|^2 through the expansion for the candidate search, exact distances recomputed below
+                d = (a * a).sum(1, keepdim=True) - 2.0 * (a @ b.t()) + b2[None, :]
+                cand = min(P2, K + 8)
+                _, ci = torch.topk(d, cand, dim=1, largest=False, sorted=True)
+                exact = ((a[:, None, :] - b[ci]) ** 2).sum(2)
+                # lexicographic (distance, index) order through two stable sorts: ascending distance, ties -> lower index
+                o1 = torch.argsort(ci, dim=1, stable=True)
+                e1, c1 = torch.gather(exact, 1, o1), torch.gather(ci, 1, o1)
+                o2 = torch.argsort(e1, dim=1, stable=True)
+                ci_sorted = torch.gather(c1, 1, o2)
+                idx[n, s:s + block] = ci_sorted[:, :K]
+    # differentiable outputs are recomputed from the indices (gradients flow to both point sets, like pytorch3d)
+    nn_pts = torch.gather(p2[:, None, :, :].expand(N, P1, P2, D), 2, idx[..., None].expand(N, P1, K, D)) if P2 > 0 else \
+        p1.new_empty((N, P1, 0, D))
+    dists = ((p1[:, :, None, :] - nn_pts) ** 2).sum(3)
+    return _KNN(dists=dists, idx=idx, knn=nn_pts if return_nn else None)
+
+
+class Meshes:
+    """The subset of ``pytorch3d.structures.Meshes`` the reference touches: a batch of meshes that all share one
+    topology (``verts`` [N, V, 3] or a list of [V, 3]; ``faces`` [N, F, 3] int64), packed accessors, unique edges in
+    pytorch3d's order, area-weighted vertex normals."""
+
+    def __init__(self, verts, faces):
+        if isinstance(verts, (list, tuple)):
+            verts = torch.stack(list(verts))
+        if isinstance(faces, (list, tuple)):
+            faces = torch.stack(list(faces))
+        if verts.dim() != 3 or faces.dim() != 3 or verts.shape[0] != faces.shape[0]:
+            raise ValueError('Meshes stand-in expects verts [N, V, 3] and faces [N, F, 3]')
+        self._verts = verts
+        self._faces = faces.long()
+        self._edges = None
+        self._f2e = None
+
+    def __len__(self):
+        return self._verts.shape[0]
+
+    def verts_list(self):
+        return list(self._verts.unbind(0))
+
+    def faces_list(self):
+        return list(self._faces.unbind(0))
+
+    def verts_padded(self):
+        return self._verts
+
+    def faces_padded(self):
+        return self._faces
+
+    def verts_packed(self):
+        return self._verts.reshape(-1, 3)
+
+    def faces_packed(self):
+        V = self._verts.shape[1]
+        off = torch.arange(len(self), device=self._faces.device)[:, None, None] * V
+        return (self._faces + off).reshape(-1, 3)
+
+    def _compute_edges(self):
+        # pytorch3d Meshes._compute_edges_packed: per face the edges (v1, v2), (v2, v0), (v0, v1); each edge sorted
+        # (low, high); unique edges in ascending order of low * V_total + high
+        faces = self.faces_packed()
+        v0, v1, v2 = faces[:, 0], faces[:, 1], faces[:, 2]
+        e = torch.cat((torch.stack((v1, v2), 1), torch.stack((v2, v0), 1), torch.stack((v0, v1), 1)), 0)
+        lo, hi = e.min(1).values, e.max(1).values
+        Vt = self._verts.shape[0] * self._verts.shape[1]
+        key = lo * Vt + hi
+        uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+        self._edges = torch.stack((uniq // Vt, uniq % Vt), 1)
+        F_ = faces.shape[0]
+        self._f2e = inverse.view(3, F_).t().contiguous()          # [F, 3]: edge opposite v0, v1, v2
+
+    def edges_packed(self):
+        if self._edges is None:
+            self._compute_edges()
+        return self._edges
+
+    def faces_packed_to_edges_packed(self):
+        if self._f2e is None:
+            self._compute_edges()
+        return self._f2e
+
+    def verts_normals_packed(self):
+        """Area-weighted vertex normals (pytorch3d ``_compute_vertex_normals``): every face adds the cross product of
+        its two edges at each of its corners (= 2 * area * unit normal), the sums are normalised (eps 1e-6)."""
+        verts, faces = self.verts_packed(), self.faces_packed()
+        vf = verts[faces]                                            # [F, 3, 3]
+        n = torch.zeros_like(verts)
+        n = n.index_add(0, faces[:, 1], torch.cross(vf[:, 2] - vf[:, 1], vf[:, 0] - vf[:, 1], dim=1))
+        n = n.index_add(0, faces[:, 2], torch.cross(vf[:, 0] - vf[:, 2], vf[:, 1] - vf[:, 2], dim=1))
+        n = n.index_add(0, faces[:, 0], torch.cross(vf[:, 1] - vf[:, 0], vf[:, 2] - vf[:, 0], dim=1))
+        return F.normalize(n, eps=1e-6, dim=1)
+
+    def verts_normals_padded(self):
+        return self.verts_normals_packed().view_as(self._verts)
+
+
+class SubdivideMeshes(nn.Module):
+    """4:1 face subdivision with shared topology (pytorch3d ``SubdivideMeshes.subdivide_homogeneous``): one new vertex
+    at the midpoint of every unique edge, appended after the original vertices in edge order; every face (v0, v1, v2)
+    with edge midpoints (m0 opposite v0, m1, m2) becomes (v0, m2, m1), (v1, m0, m2), (v2, m1, m0), (m0, m1, m2), the
+    four groups concatenated in that order.  Vertex features are interpolated the same way."""
+
+    def __init__(self, meshes: Optional[Meshes] = None):
+        super().__init__()
+        self.precomputed = False
+        if meshes is not None:
+            if len(meshes) != 1:
+                raise ValueError('SubdivideMeshes stand-in: initialise with ONE mesh (the shared topology)')
+            self.register_buffer('_subdivided_faces', self.subdivide_faces(meshes))
+            self.register_buffer('_edges', meshes.edges_packed())
+            self.precomputed = True
+
+    @staticmethod
+    def subdivide_faces(meshes: Meshes):
+        with torch.no_grad():
+            faces = meshes.faces_packed()
+            V = meshes.verts_packed().shape[0]
+            new = meshes.faces_packed_to_edges_packed() + V           # midpoint vertex of the edge opposite v0, v1, v2
+            f0 = torch.stack((faces[:, 0], new[:, 2], new[:, 1]), 1)
+            f1 = torch.stack((faces[:, 1], new[:, 0], new[:, 2]), 1)
+            f2 = torch.stack((faces[:, 2], new[:, 1], new[:, 0]), 1)
+            return torch.cat((f0, f1, f2, new), 0)
+
+    def forward(self, meshes: Meshes, feats=None):
+        if self.precomputed:
+            faces, edges = self._subdivided_faces, self._edges
+        else:
+            if len(meshes) != 1:
+                raise ValueError('SubdivideMeshes stand-in without precomputed topology handles one mesh per call')
+            faces, edges = self.subdivide_faces(meshes), meshes.edges_packed()
+        verts = meshes.verts_padded()                                  # [N, V, 3], same topology for all N
+        N = verts.shape[0]
+        mid = verts[:, edges].mean(2)                                  # [N, E, 3]
+        new_mesh = Meshes(torch.cat((verts, mid), 1), faces[None].expand(N, -1, -1))
+        if feats is None:
+            return new_mesh
+        squeeze = feats.dim() == 2
+        f = feats[None] if squeeze else feats
+        if f.shape[0] != N or f.shape[1] != verts.shape[1]:
+            if squeeze and N * verts.shape[1] == feats.shape[0]:      # packed features of a batch
+                f = feats.view(N, verts.shape[1], -1)
+            else:
+                raise ValueError('feats must hold one row per vertex')
+        new_feats = torch.cat((f, f[:, edges].mean(2)), 1)
+        # pytorch3d returns features [N, V + E, D] for batched and for single meshes alike; the reference indexes
+        # feats[0] (smpl_x.py:98)
+        return new_mesh, new_feats
+
+
+# ---- rotation conversions (pytorch3d.transforms.rotation_conversions; real part first for quaternions) ------------
+def axis_angle_to_quaternion(axis_angle):
+    angles = torch.norm(axis_angle, p=2, dim=-1, keepdim=True)
+    half = angles * 0.5
+    eps = 1e-6
+    small = angles.abs() < eps
+    sin_half_over_angle = torch.empty_like(angles)
+    sin_half_over_angle[~small] = torch.sin(half[~small]) / angles[~small]
+    sin_half_over_angle[small] = 0.5 - (angles[small] * angles[small]) / 48
+    return torch.cat((torch.cos(half), axis_angle * sin_half_over_angle), dim=-1)
+
+
+def quaternion_to_matrix(quaternions):
+    r, i, j, k = torch.unbind(quaternions, -1)
+    two_s = 2.0 / (quaternions * quaternions).sum(-1)
+    o = torch.stack((
+        1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+        two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+        two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(quaternions.shape[:-1] + (3, 3))
+
+
+def axis_angle_to_matrix(axis_angle):
+    return quaternion_to_matrix(axis_angle_to_quaternion(axis_angle))
+
+
+def _sqrt_positive_part(x):
+    ret = torch.zeros_like(x)
+    pos = x > 0
+    ret[pos] = torch.sqrt(x[pos])
+    return ret
+
+
+def matrix_to_quaternion(matrix):
+    """Rotation matrices [..., 3, 3] -> quaternions (w, x, y, z) with a non-negative real part, computed from the best
+    conditioned of the four candidate formulas (pytorch3d's numerically stable variant)."""
+    if matrix.size(-1) != 3 or matrix.size(-2) != 3:
+        raise ValueError('Invalid rotation matrix shape %s.' % (tuple(matrix.shape),))
+    batch = matrix.shape[:-2]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch + (9,)), dim=-1)
+    q_abs = _sqrt_positive_part(torch.stack((1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
+                                             1.0 - m00 - m11 + m22), dim=-1))
+    quat_by_rijk = torch.stack((
+        torch.stack((q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01), dim=-1),
+        torch.stack((m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20), dim=-1),
+        torch.stack((m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21), dim=-1),
+        torch.stack((m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2), dim=-1)), dim=-2)
+    floor = torch.tensor(0.1).to(dtype=q_abs.dtype, device=q_abs.device)
+    cand = quat_by_rijk / (2.0 * q_abs[..., None].max(floor))
+    best = F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5
+    out = cand[best, :].reshape(batch + (4,))
+    return torch.where(out[..., 0:1] < 0, -out, out)
+
+
+def matrix_to_rotation_6d(matrix):
+    """First two rows of the rotation matrix, flattened (Zhou et al., CVPR 2019; pytorch3d's convention)."""
+    return matrix[..., :2, :].clone().reshape(matrix.shape[:-2] + (6,))
+
+
+def rotation_6d_to_matrix(d6):
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = F.normalize(a1, dim=-1)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = F.normalize(b2, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)

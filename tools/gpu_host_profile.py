@@ -8,7 +8,7 @@ human = {k: v.to(dev).requires_grad_(True) for k, v in scenes.dist_b_avatar(1500
 cam = {k: t.to(dev) for k, t in scenes.ring_camera(H, W, 7, 200).items()}
 bg = torch.ones(3, device=dev); G = torch.randn(3, H, W, device=dev)
 rend = exa.GaussianRenderer()
-exa.config.mode = 'capacity'
+exa.config.mode = os.environ.get('EXA_MODE', 'auto')
 def it():
     o = rend(human, (H, W), cam, bg)
     for v in human.values(): v.grad = None
@@ -17,7 +17,8 @@ for _ in range(10): it()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(50): it()
-torch.cuda.synchronize(); print('eager render fwd+bwd: %.3f ms' % ((time.perf_counter() - t0) / 50 * 1e3))
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+print('eager render fwd+bwd through GaussianRenderer (mode %s): %.3f ms -> %.0f renders/s' % (exa.config.mode, dt * 1e3, 1 / dt))
 pr = cProfile.Profile(); pr.enable()
 for _ in range(50): it()
 torch.cuda.synchronize(); pr.disable()

@@ -1,5 +1,5 @@
 """Measures SURVEY 8f-2 / 8f-3 on one GPU: the five same-camera renders of one ExAvatar iteration (fwd + bwd)
-issued sequentially vs with exa.render_many, and the fused densify statistics vs the reference's PyTorch bookkeeping."""
+issued sequentially vs as ONE batched call (exa.render_many), and the fused densify statistics vs the reference's PyTorch bookkeeping."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,7 +31,7 @@ def iteration(concurrent):
     return outs
 
 
-for mode in ('exact', 'capacity'):
+for mode in ('exact', 'auto'):
     exa.config.mode = mode
     for conc in (False, True):
         for _ in range(5):
@@ -41,7 +41,7 @@ for mode in ('exact', 'capacity'):
         for _ in range(n):
             iteration(conc)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-        print('5 renders fwd+bwd, mode %-8s %-10s: %.3f ms / iteration' % (mode, 'concurrent' if conc else 'sequential', dt * 1e3))
+        print('5 renders fwd+bwd, mode %-8s %-10s: %.3f ms / iteration' % (mode, 'batched' if conc else 'sequential', dt * 1e3))
 exa.check_overflow()
 
 outs = iteration(False)

@@ -1,15 +1,29 @@
 #!/bin/bash
-# Round profile: default bench line, rocprofv3 kernel stats of the bench command, HBM-traffic and SQ PMC passes.
+# Round profile: default bench line, rocprofv3 kernel stats of the bench command, HBM-traffic and SQ PMC passes
+# (counters only with --kernel-trace, each counter group in its own run), FETCH/WRITE_SIZE calibration probe.
 # Usage on the GPU box: bash tools/profile_round.sh <tag>   (outputs under gpurun_out/<tag>/)
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 ( cd $R && timeout 600 python bench.py > $O/bench.json 2> $O/bench.err )
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-concurrent > $O/stats_bench.json 2> $O/stats.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq1 -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq2 -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-concurrent > $O/stats_bench.json 2> $O/stats.err
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/pmc_sq1 -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $O/pmc_sq2 -- python $R/tools/gpu_kernel_times.py 0 > /dev/null 2>&1
+if [ -x $R/tools/probe/fetch_calib ]; then
+  timeout 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/calib_fetch -- $R/tools/probe/fetch_calib > $O/calib.log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/calib_write -- $R/tools/probe/fetch_calib >> $O/calib.log 2>&1
+  python - <<PY
+import csv, glob, collections
+for d, c in (('$O/calib_fetch', 'FETCH_SIZE'), ('$O/calib_write', 'WRITE_SIZE')):
+    rows = collections.defaultdict(list)
+    for p in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r['Counter_Name'] == c: rows[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    for k, v in rows.items(): print('calib', c, k, 'mean KB', sum(v) / len(v))
+PY
+fi
 cat $O/bench.json; tail -2 $O/bench.err
 python $R/tools/pmc_summary.py $O/pmc_fetch; python $R/tools/pmc_summary.py $O/pmc_write
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs head -15
