@@ -131,9 +131,11 @@ def _drain_pending(block=False):
             ev.synchronize()
         (todo if ev.query() else rest).append(item)
     _pending = rest
-    for _, host, jobs in todo:
-        for k, (key, cap) in enumerate(jobs):
-            _note_header(key, cap, int(host[k, 0]), int(host[k, 1]))
+    for ev, host, jobs in todo:
+        vals = host[:len(jobs)].tolist()
+        _hdr_release(ev, host)
+        for (key, cap), row in zip(jobs, vals):
+            _note_header(key, cap, row[0], row[1])
 
 
 def check_overflow():
@@ -149,6 +151,20 @@ def read_header(tile_ws):
 def last_header():
     """Header of the most recent forward; needs ``config.keep_debug = True`` (developer probes only)."""
     return read_header(_debug_last['tile'])
+
+
+_hdr_pool = []    # recycled (event, pinned [8, 4] int32 buffer) pairs of completed header read-backs
+
+
+def _hdr_slot(K):
+    if K <= 8 and _hdr_pool:
+        return _hdr_pool.pop()
+    return torch.cuda.Event(), torch.empty((max(K, 8), 4), dtype=torch.int32, pin_memory=True)
+
+
+def _hdr_release(ev, host):
+    if len(_hdr_pool) < 64 and host.shape[0] == 8:
+        _hdr_pool.append((ev, host))
 
 
 _size_cache = {}
@@ -272,10 +288,9 @@ class _Rasterize(torch.autograd.Function):
             else:
                 _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
                 if not capturing:
-                    host = torch.empty((K, 4), dtype=torch.int32, pin_memory=True)
+                    ev, host = _hdr_slot(K)                      # pinned buffer + event from a small pool
                     rows = [j.ws[j.gb:j.gb + 16].view(torch.int32) for j in jobs]
-                    host.copy_(rows[0].view(1, 4) if K == 1 else torch.stack(rows), non_blocking=True)
-                    ev = torch.cuda.Event()
+                    host[:K].copy_(rows[0].view(1, 4) if K == 1 else torch.stack(rows), non_blocking=True)
                     ev.record(torch.cuda.current_stream(device))
                     hdr_check = (ev, host, [(j.key, j.capacity) for j in jobs])
                     if not need_ctx:
@@ -385,8 +400,10 @@ class _Rasterize(torch.autograd.Function):
             ev, host, jobs = ctx.hdr_check
             ctx.hdr_check = None
             ev.synchronize()
-            for k, (key, cap) in enumerate(jobs):
-                _note_header(key, cap, int(host[k, 0]), int(host[k, 1]))
+            vals = host[:len(jobs)].tolist()
+            _hdr_release(ev, host)
+            for (key, cap), row in zip(jobs, vals):
+                _note_header(key, cap, row[0], row[1])
         return tuple(ret)
 
 
