@@ -73,15 +73,6 @@ __device__ __forceinline__ Ops4 load_ops4(const BatchLds& s, int k) {
     o.op = *reinterpret_cast<const v4f*>(&s.op[k]);
     return o;
 }
-// Everything a group of four needs from LDS -- operands and colours -- fetched together one group AHEAD of its use
-// (ten broadcast ds_read_b128), so that no LDS latency sits between the alpha evaluation and the accumulation.
-struct Group4 { Ops4 o; float4 col[4]; };
-__device__ __forceinline__ Group4 load_group4(const BatchLds& s, int k) {
-    Group4 g;
-    g.o = load_ops4(s, k);
-    g.col[0] = s.col[k]; g.col[1] = s.col[k + 1]; g.col[2] = s.col[k + 2]; g.col[3] = s.col[k + 3];
-    return g;
-}
 // alphas (and falloffs) of four splats at pixel (fx, fy)
 struct Alpha4 { float alpha[4], G[4]; };
 __device__ __forceinline__ Alpha4 splat_alpha4(const Ops4& o, float fx, float fy) {

@@ -158,9 +158,9 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
         {
-            auto group4 = [&](const Group4& grp, int k) {
-                const float4 (&col)[4] = grp.col;
-                const Alpha4 e = splat_alpha4(grp.o, fx, fy);
+            auto group4 = [&](const Ops4& ops, int k) {
+                const float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
+                const Alpha4 e = splat_alpha4(ops, fx, fy);
                 float aeff[4], Tb[4], w[4];
                 blend_group4(T, live, e.alpha, aeff, Tb, w);
                 float2* x = xw_row + (k - c0) * (XROW / 2);
@@ -176,13 +176,13 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
                 }
             };
             // two groups per trip, ping-pong operand registers (next group's operands in flight, no register rotation)
-            Group4 grpA = load_group4(s_b, c0);
+            Ops4 opsA = load_ops4(s_b, c0);
             for (int k = c0; k < cend; k += 8) {
-                const Group4 grpB = load_group4(s_b, (k + 4) & 63);
-                group4(grpA, k);
+                const Ops4 opsB = load_ops4(s_b, (k + 4) & 63);
+                group4(opsA, k);
                 if (k + 4 >= cend) break;
-                grpA = load_group4(s_b, (k + 8) & 63);
-                group4(grpB, k + 4);
+                opsA = load_ops4(s_b, (k + 8) & 63);
+                group4(opsB, k + 4);
             }
         }
         wave_lds_fence();

@@ -366,9 +366,9 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         // ~60 % of the entries of the batches the forward enters (tools/cpu_blend_stats.py).
         unsigned long long blended = 0ull;
         // One group of four splats; returns true when every pixel of the sub-tile has stopped.
-        auto group4 = [&](const Group4& grp, int k) -> bool {
-            const float4 c0 = grp.col[0], c1 = grp.col[1], c2 = grp.col[2], c3 = grp.col[3];
-            const Alpha4 e = splat_alpha4(grp.o, fx, fy);
+        auto group4 = [&](const Ops4& ops, int k) -> bool {
+            const float4 c0 = s_b.col[k], c1 = s_b.col[k + 1], c2 = s_b.col[k + 2], c3 = s_b.col[k + 3];
+            const Alpha4 e = splat_alpha4(ops, fx, fy);
             const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
             if (!__any(amax > 0.0f)) return false;
             float aeff[4], Tb[4], w[4];
@@ -391,13 +391,13 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         };
         // two groups per trip with ping-pong operand registers: the operands of the next group are in flight during the
         // current one, and no register-to-register rotation is needed (a `cur = nxt` copy cost 12 v_mov_b64 per group)
-        Group4 grpA = load_group4(s_b, 0);
+        Ops4 opsA = load_ops4(s_b, 0);
         for (int k = 0; k < cnt; k += 8) {
-            const Group4 grpB = load_group4(s_b, (k + 4) & 63);
-            if (group4(grpA, k)) break;
+            const Ops4 opsB = load_ops4(s_b, (k + 4) & 63);
+            if (group4(opsA, k)) break;
             if (k + 4 >= cnt) break;
-            grpA = load_group4(s_b, (k + 8) & 63);
-            if (group4(grpB, k + 4)) break;
+            opsA = load_ops4(s_b, (k + 8) & 63);
+            if (group4(opsB, k + 4)) break;
         }
         if (STORE && lane == 0) a.bw.bmask[range.x / BATCH + (uint32_t)(entered - 1)] = blended;
         wave_lds_fence();
