@@ -121,6 +121,100 @@ __device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restr
     }
 }
 
+// ---- bucket sort: the fast path for lists of 65 .. SORT_TILE keys -------------------------------------------
+// The merge sort above spends ~600 thread-instructions per key (64 comparisons of the run rank sort + a dozen
+// binary-search steps per merge level, all on 64-bit keys); the sort launch was VALU-bound on exactly that (9.3 M
+// wave-instructions for 0.9 M keys).  The depths of one sub-tile's list are floats in a narrow range, so a
+// DISTRIBUTION sort gets each key (almost) to its place in one pass:
+//   1. block-wide min / max of the depth;  bucket = (depth - min) * (NB - 1) / (max - min), NB = padded list length
+//      (monotone in the depth: a float subtraction, a multiplication by a positive scale and a truncation all are);
+//   2. LDS histogram (one atomic per key, its return value is the key's arrival slot in the bucket), exclusive scan;
+//   3. keys scattered into their bucket's range;
+//   4. every key counts the keys of ITS bucket that are smaller (full 64-bit compare: depth bits, then Gaussian id) --
+//      buckets hold ~1-5 keys -- and stores its id at bucket start + that count.
+// The output is the exact total order by (depth bits, id) and does not depend on the atomics' arrival order.
+// ~50 thread-instructions per key.  A list whose depths pile up in one bucket (> BUCKET_MAX keys: e.g. hundreds of splats at
+// one depth) is left to the merge sort: returns false before anything was written.
+constexpr int BUCKET_MAX = 48;
+template <int E>      // E = keys per thread: lists of up to 256 * E keys, 256 * E buckets
+__device__ __forceinline__ bool lds_bucket_sort(const unsigned long long* __restrict__ gkeys, int n,
+                                                uint32_t* __restrict__ sorted, unsigned long long* buf, uint32_t* cnt,
+                                                uint32_t* s_misc, int tid) {
+    constexpr int NB = SBLOCK * E;
+    const int lane = tid & 63, wave = tid >> 6;
+    unsigned long long key[E];
+    uint32_t dmin = 0xffffffffu, dmax = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * SBLOCK + tid;
+        key[e] = i < n ? gkeys[i] : ~0ull;
+        if (i < n) {
+            const uint32_t d = (uint32_t)(key[e] >> 32);
+            dmin = min(dmin, d); dmax = max(dmax, d);
+        }
+        cnt[i] = 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
+        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64));
+    }
+    if (lane == 0) { s_misc[wave] = dmin; s_misc[4 + wave] = dmax; }
+    __syncthreads();
+    dmin = min(min(s_misc[0], s_misc[1]), min(s_misc[2], s_misc[3]));
+    dmax = max(max(s_misc[4], s_misc[5]), max(s_misc[6], s_misc[7]));
+    // depths are positive floats: bit order == value order
+    const float fmin = __uint_as_float(dmin);
+    const float scale = (float)(NB - 1) / fmaxf(__uint_as_float(dmax) - fmin, 1e-30f);
+    uint32_t bkt[E], slot[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        bkt[e] = 0u; slot[e] = 0u;
+        if (e * SBLOCK + tid < n) {
+            const float f = (__uint_as_float((uint32_t)(key[e] >> 32)) - fmin) * scale;
+            bkt[e] = (uint32_t)min(NB - 1, (int)f);
+            slot[e] = __hip_atomic_fetch_add(&cnt[bkt[e]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the NB counters (thread t owns counters t * E .. t * E + E - 1) and the largest bucket
+    uint32_t c[E], sum = 0u, mx = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { c[e] = cnt[tid * E + e]; sum += c[e]; mx = max(mx, c[e]); }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
+    if (lane == 63) s_misc[8 + wave] = incl;
+    if (lane == 0) s_misc[12 + wave] = mx;
+    __syncthreads();
+    mx = max(max(s_misc[12], s_misc[13]), max(s_misc[14], s_misc[15]));
+    if (mx > (uint32_t)BUCKET_MAX) return false;                 // workgroup-uniform; nothing written yet
+    uint32_t run = incl - sum;
+    for (int w2 = 0; w2 < wave; ++w2) run += s_misc[8 + w2];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { cnt[tid * E + e] = run; run += c[e]; }      // counters -> bucket starts
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if (e * SBLOCK + tid < n) buf[cnt[bkt[e]] + slot[e]] = key[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (e * SBLOCK + tid < n) {
+            const uint32_t s0 = cnt[bkt[e]], s1 = bkt[e] + 1u < (uint32_t)NB ? cnt[bkt[e] + 1u] : (uint32_t)n;
+            uint32_t rank = s0;
+            for (uint32_t j = s0; j < s1; ++j) rank += buf[j] < key[e] ? 1u : 0u;
+            sorted[rank] = (uint32_t)key[e];
+        }
+    }
+    return true;
+}
+
 // Single-wave variant for short lists (<= 64 keys): one rank-sort pass, no barriers.
 __device__ __forceinline__ void wave_rank_sort64(const unsigned long long* __restrict__ gkeys, int n,
                                                  uint32_t* __restrict__ sorted, unsigned long long* buf, int lane) {
@@ -258,6 +352,8 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
 
 __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
+    __shared__ uint32_t s_cnt[SORT_TILE];                        // bucket counters / starts of the distribution sort
+    __shared__ uint32_t s_misc[16];
     const RenderFwdArgs& a = batch.v[blockIdx.y];
     if ((int)blockIdx.x >= a.grid.subtiles + ORDER_WGS) return;   // a job with a smaller image than the largest of the batch
     const int tid = threadIdx.x;
@@ -283,12 +379,24 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     uint32_t* sorted = a.bw.sorted + range.x;
     if (n <= 64) {
         if (tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);
-    } else if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);      // (a plain O(n^2) rank sort of the whole
+        return;
+    }
+    if (n > SORT_TILE) {   // longer lists: 2048 own keys at a time against the whole list (any length)
+        for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
+        return;
+    }
+    // distribution sort first; the merge sort takes the (rare) lists whose depths pile up in one bucket
+    bool done;
+    if (n <= 256) done = lds_bucket_sort<1>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
+    else if (n <= 512) done = lds_bucket_sort<2>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
+    else if (n <= 1024) done = lds_bucket_sort<4>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
+    else done = lds_bucket_sort<8>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
+    if (done) return;
+    __syncthreads();
+    if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);             // (a plain O(n^2) rank sort of the whole
     else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);        //  list was 40 % slower: LDS-pipe bound)
     else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
-    else if (n <= 2048) lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
-    else   // longer lists: 2048 own keys at a time against the whole list (any length)
-        for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
+    else lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
 #ifdef EXA_PROBE_SORT
     __syncthreads();
     if (tid == 0) a.tw.part_cnt[st] = (uint32_t)(__builtin_readcyclecounter() - t0);      // probe build only

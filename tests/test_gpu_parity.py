@@ -138,6 +138,25 @@ def test_deep_lists(dev, n_deep, o_min):
         assert float(ref['aux']['final_T'].min()) < 2e-4          # some pixels ran into the T < 1e-4 stop
 
 
+def test_equal_depth_ties_are_broken_by_index(dev):
+    """Hundreds of splats at EXACTLY the same view depth in one sub-tile list (a fronto-parallel plane): the
+    distribution sort finds them all in one bucket and hands the list to the merge sort; the blend order must be the
+    ascending Gaussian index, as upstream's stable sort gives it."""
+    H, W = 64, 96
+    f = 80.0
+    g = torch.Generator().manual_seed(91)
+    n_plane = 420
+    a = scenes.dist_a_random(n_plane + 200, H, W, seed=92, focal=f)
+    a['mean_3d'][:n_plane, 2] = 3.0                               # R = I, t = 0: view depth == z, bit for bit
+    a['mean_3d'][:n_plane, 0] = (20.0 + 10.0 * torch.rand(n_plane, generator=g) - W / 2 + 0.5) / f * 3.0
+    a['mean_3d'][:n_plane, 1] = (12.0 + 10.0 * torch.rand(n_plane, generator=g) - H / 2 + 0.5) / f * 3.0
+    a['scale'][:n_plane] = 0.05 + 0.05 * torch.rand(n_plane, 3, generator=g)
+    a['opacity'][:n_plane] = 0.02 + 0.05 * torch.rand(n_plane, 1, generator=g)
+    cam = scenes.neutral_camera(H, W, focal=f)
+    out, ref = _cmp_render(a, (H, W), cam, torch.rand(3, generator=g), dev, torch.randn(3, H, W, generator=g))
+    assert int((ref['aux']['pre']['depth'][:n_plane] == 3.0).sum()) == n_plane
+
+
 def test_empty_and_all_culled(dev):
     H, W = 40, 72
     cam = {k: v.to(dev) for k, v in scenes.neutral_camera(H, W).items()}
