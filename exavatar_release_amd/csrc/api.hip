@@ -129,7 +129,7 @@ int check_forward_job(const ExaRasterForwardJob& j, bool stage1, bool stage2) {
 
 BinArgs bin_args(const ExaRasterForwardJob& j) {
     BinArgs b;
-    b.P = j.P; b.chunks = num_chunks(j.P);
+    b.P = j.P; b.chunks = num_chunks(j.P); b.merged = 0;
     b.grid = make_grid(j.settings->image_width, j.settings->image_height);
     b.splats = static_cast<Splat*>(j.geom_ws);
     b.tw = carve_tile_ws(j.tile_ws, b.grid.cells, b.chunks);
@@ -139,7 +139,19 @@ BinArgs bin_args(const ExaRasterForwardJob& j) {
 }
 
 // stage 1 of up to MAX_BATCH jobs: one launch per kernel
-int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st) {
+// the scans can move into cell_scatter_kernel when every job's count matrix is small (fused stage 1 + 2 calls only:
+// the two-stage protocol needs the header on the host before stage 2 is launched)
+bool can_merge_scans(const ExaRasterForwardJob* jobs, int K) {
+    for (int k = 0; k < K; ++k) {
+        const int cells = make_grid(jobs[k].settings->image_width, jobs[k].settings->image_height).cells;
+        const int chunks = num_chunks(jobs[k].P);
+        if (cells == 0 || cells > MERGE_MAX_CELLS || chunks > MERGE_MAX_CHUNKS || (int64_t)cells * chunks > MERGE_MAX_MATRIX)
+            return false;
+    }
+    return true;
+}
+
+int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st, bool skip_scans = false) {
     PreprocessArgs pa[MAX_BATCH];
     BinArgs ba[MAX_BATCH];
     const ExaRasterSettings* s0 = jobs[0].settings;
@@ -163,18 +175,20 @@ int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st) {
     int rc;
     EXA_TIMED(K_PREPROCESS_FWD, launch_preprocess_fwd(pa, K, st), "preprocess_fwd");
     if ((rc = debug_sync(s0, st, "preprocess_fwd"))) return rc;
+    if (skip_scans) return 0;
     EXA_TIMED(K_CELL_SCAN, launch_cell_scan(ba, K, st), "cell_scan");
     if ((rc = debug_sync(s0, st, "cell_scan"))) return rc;
     return 0;
 }
 
-int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, hipStream_t st) {
+int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, hipStream_t st, bool merged = false) {
     BinArgs ba[MAX_BATCH];
     RenderFwdArgs ra[MAX_BATCH];
     const ExaRasterSettings* s0 = jobs[0].settings;
     for (int k = 0; k < K; ++k) {
         const ExaRasterForwardJob& j = jobs[k];
         ba[k] = bin_args(j);
+        ba[k].merged = merged ? 1 : 0;
         RenderFwdArgs& r = ra[k];
         r.grid = ba[k].grid; r.splats = ba[k].splats; r.tw = ba[k].tw; r.bw = ba[k].bw; r.capacity = j.capacity;
         r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
@@ -288,9 +302,10 @@ int exa_raster_forward_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
         const int n = K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH;
-        int rc = forward_bin_group(jobs + k0, n, st);
+        const bool merged = can_merge_scans(jobs + k0, n);
+        int rc = forward_bin_group(jobs + k0, n, st, merged);
         if (rc) return rc;
-        rc = forward_render_group(jobs + k0, n, store_ctx, st);
+        rc = forward_render_group(jobs + k0, n, store_ctx, st, merged);
         if (rc) return rc;
     }
     return 0;

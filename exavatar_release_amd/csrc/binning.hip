@@ -121,6 +121,34 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
     return base + incl - v;
 }
 
+// Launch order of the per-cell kernels: cells bucketed by floor(log2(instances)) (33 buckets), heaviest bucket first,
+// so the heaviest cells start early and the tail of the launch is light; the empty cells come last and
+// header.active_cells counts the others.  One workgroup; `inst_of(c)` returns the instance count of cell c.
+template <typename F>
+__device__ __forceinline__ void write_cell_order(const TileWs& w, int cells, F inst_of) {
+    __shared__ uint32_t s_bucket[34];
+    const int tid = threadIdx.x;
+    if (tid < 34) s_bucket[tid] = 0u;
+    __syncthreads();
+    for (int c = tid; c < cells; c += (int)blockDim.x) {
+        const uint32_t n = inst_of(c);
+        atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u);       // bucket 0 = empty, 32 = largest
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int b = 32; b >= 0; --b) { const uint32_t n = s_bucket[b]; s_bucket[b] = run; run += n; }
+        // the empty cells sit at the end of cell_order: the per-cell kernels that follow stop at this count instead of
+        // sending a workgroup through three dependent loads for every empty cell (~75 % of the cells of an avatar view)
+        w.header->active_cells = s_bucket[0];
+    }
+    __syncthreads();
+    for (int c = tid; c < cells; c += (int)blockDim.x) {
+        const uint32_t n = inst_of(c);
+        w.cell_order[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = (uint32_t)c;
+    }
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> batch) {
     __shared__ unsigned long long s_tmp[SCAN_THREADS / 64];
     const BinArgs& a = batch.v[blockIdx.y];
@@ -169,28 +197,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
         w.header->num_instances = (uint32_t)ti_tot;
     }
     if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
-    // Launch order of the per-cell kernels: cells bucketed by floor(log2(instances)) (33 buckets),
-    // heaviest bucket first, so the heaviest cells start early and the tail of the launch is light.
-    __shared__ uint32_t s_bucket[34];
-    if (tid < 34) s_bucket[tid] = 0u;
-    __syncthreads();
-    for (int c = tid; c < cells; c += SCAN_THREADS) {
-        const uint32_t n = (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32);
-        atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u);       // bucket 0 = empty, 32 = largest
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (int b = 32; b >= 0; --b) { const uint32_t n = s_bucket[b]; s_bucket[b] = run; run += n; }
-        // the empty cells sit at the end of cell_order: the per-cell kernels that follow stop at this count instead of
-        // sending a workgroup through three dependent loads for every empty cell (~75 % of the cells of an avatar view)
-        w.header->active_cells = s_bucket[0];
-    }
-    __syncthreads();
-    for (int c = tid; c < cells; c += SCAN_THREADS) {
-        const uint32_t n = (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32);
-        w.cell_order[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = (uint32_t)c;
-    }
+    write_cell_order(w, cells, [&](int c) { return (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32); });
 }
 
 // CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
@@ -199,8 +206,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
 // workgroup's slice of the batch-owner array.
 constexpr int SC_BLOCK = CHUNK;        // one Gaussian per thread
 __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> batch) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];   // cnt[cells] | base[cells] | cnt2[cells]
+    // base[cells] | cnt2[cells] (u32)  [ | tot[cells] | bef[cells] (u64) when the scans are merged into this kernel ]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     __shared__ uint32_t s_tmp[SC_BLOCK / 64];
+    __shared__ unsigned long long s_tmp64[SC_BLOCK / 64];
+    __shared__ uint32_t s_bcast[2];
     const BinArgs& a = batch.v[blockIdx.y];
     const int P = a.P;
     Splat* __restrict__ splats = a.splats;
@@ -208,23 +218,97 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     const uint64_t capacity = a.capacity;
+    const int tid = threadIdx.x, cells = g.cells;
     {   // this workgroup's slice of the zero-filled section of the bin workspace: batch owners (written by
         // subtile_bin_kernel, the next launch), blended masks (render_fwd), touched bytes (render_bwd)
         const size_t n16 = bin_zero_bytes(capacity) / 16, per = (n16 + gridDim.x - 1) / gridDim.x;
         const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
         for (size_t i = lo + threadIdx.x; i < hi; i += SC_BLOCK) b.owner[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if ((int)blockIdx.x >= a.chunks) return;                    // a job with fewer Gaussians than the largest of the batch
-    const uint32_t D = w.header->num_rendered;
-    if ((uint64_t)D > capacity) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) w.header->overflow = 1u;
+    uint32_t* s_base = s_dyn;
+    uint32_t* s_cnt2 = s_dyn + cells;
+    if ((int)blockIdx.x >= a.chunks) {                          // a job with fewer Gaussians than the largest of the batch
+        if (a.merged && a.chunks == 0 && blockIdx.x == 0) {     // no Gaussians at all: nobody else writes the tile state
+            for (int c = tid; c <= cells; c += SC_BLOCK) w.cell_off[c] = make_uint2(0u, 0u);
+            for (int c = tid; c < cells; c += SC_BLOCK) w.cell_order[c] = (uint32_t)c;
+            if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+            if (tid == 0) {
+                w.header->num_rendered = 0u; w.header->overflow = 0u; w.header->max_tile_list = 0u;
+                w.header->num_visible = 0u; w.header->num_instances = 0u; w.header->active_cells = 0u;
+            }
+        }
         return;
     }
-    uint32_t* s_cnt = s_dyn;
-    uint32_t* s_base = s_dyn + g.cells;
-    uint32_t* s_cnt2 = s_dyn + 2 * g.cells;
-    const int tid = threadIdx.x;
-    for (int c = tid; c < 3 * g.cells; c += SC_BLOCK) s_dyn[c] = 0u;
+    uint32_t D, chunk_off;
+    if (a.merged) {
+        // The scans of the (chunk, cell) count matrix, done redundantly by EVERY scatter workgroup instead of by two
+        // tiny launches in front of it (col_scan + cell_scan: ~12 us of pure launch and memory latency for C3): column
+        // totals, this chunk's entry offset in every cell, the prefix over the cells, the prefix of the chunks'
+        // instance counts.  The matrix (chunks x cells x 8 B, <= 512 KB here) is L2-resident; workgroup 0 also publishes
+        // what the later kernels read (cell_off, header, cell order).
+        unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(s_dyn + 2 * cells);
+        unsigned long long* s_bef = s_tot + cells;
+        for (int c = tid; c < cells; c += SC_BLOCK) { s_tot[c] = 0ull; s_bef[c] = 0ull; }
+        __syncthreads();
+        {
+            const int G = SC_BLOCK / cells;                     // row groups (cells <= SC_BLOCK on this path)
+            const int c = tid % cells, q = tid / cells;
+            if (q < G) {
+                unsigned long long tot = 0ull, bef = 0ull;
+                const unsigned long long* m = w.chunk_cell + c;
+#pragma unroll 4
+                for (int r = q; r < a.chunks; r += G) {
+                    const unsigned long long v = m[(size_t)r * cells];
+                    tot += v;
+                    bef += r < (int)blockIdx.x ? (v & 0xffffffffull) : 0ull;
+                }
+                __hip_atomic_fetch_add(&s_tot[c], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_bef[c], bef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        __syncthreads();
+        const unsigned long long v = tid < cells ? s_tot[tid] : 0ull;
+        const unsigned long long packed = ((unsigned long long)(cell_slots((uint32_t)(v >> 32)) * BATCH) << 32) | (uint32_t)v;
+        unsigned long long tot_all;
+        const unsigned long long x = block_excl_scan64(packed, s_tmp64, tot_all);     // (slot space << 32 | entries) prefix
+        if (tid < cells) s_base[tid] = (uint32_t)x + (uint32_t)s_bef[tid];
+        D = (uint32_t)(tot_all >> 32);
+        // instances of the chunks in front of this one (chunks <= SC_BLOCK on this path)
+        const uint32_t ci = tid < a.chunks ? w.chunk_inst[tid] : 0u;
+        uint32_t inst_total;
+        const uint32_t cx = block_excl_scan(ci, s_tmp, inst_total);
+        if (tid == (int)blockIdx.x) s_bcast[0] = cx;
+        if (blockIdx.x == 0) {
+            if (tid < cells) w.cell_off[tid] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
+            uint32_t vis_total;
+            block_excl_scan(tid < a.chunks ? w.chunk_vis[tid] : 0u, s_tmp, vis_total);
+            if (tid == 0) {
+                w.cell_off[cells] = make_uint2((uint32_t)tot_all, (uint32_t)(tot_all >> 32));
+                w.header->num_rendered = D;
+                w.header->overflow = (uint64_t)D > capacity ? 1u : 0u;
+                w.header->max_tile_list = (uint32_t)tot_all;     // reused slot: number of (Gaussian, cell) entries
+                w.header->num_visible = vis_total;
+                w.header->num_instances = inst_total;
+            }
+            if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+            write_cell_order(w, cells, [&](int c) { return (uint32_t)(s_tot[c] >> 32); });
+        }
+        __syncthreads();
+        chunk_off = s_bcast[0];
+        if ((uint64_t)D > capacity) return;                      // overflow latched in the header by workgroup 0
+        for (int c = tid; c < cells; c += SC_BLOCK) s_cnt2[c] = 0u;
+    } else {
+        D = w.header->num_rendered;
+        if ((uint64_t)D > capacity) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) w.header->overflow = 1u;
+            return;
+        }
+        chunk_off = w.chunk_off[blockIdx.x];
+        for (int c = tid; c < cells; c += SC_BLOCK) {
+            s_cnt2[c] = 0u;
+            s_base[c] = w.cell_off[c].x + (uint32_t)w.chunk_cell[(size_t)blockIdx.x * cells + c];
+        }
+    }
     __syncthreads();
 
     constexpr int PER = CHUNK / SC_BLOCK;
@@ -244,25 +328,12 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
         mine += r3[it].z;
     }
     uint32_t total;
-    uint32_t off = w.chunk_off[blockIdx.x] + block_excl_scan(mine, s_tmp, total);
+    uint32_t off = chunk_off + block_excl_scan(mine, s_tmp, total);
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
         if (r3[it].z) {
             splats[ids[it]].inst_off = off;
             off += r3[it].z;
-            const int sx0 = r3[it].x & 0xffff, sx1 = r3[it].x >> 16, sy0 = r3[it].y & 0xffff, sy1 = r3[it].y >> 16;
-            for (int cy = sy0 >> 3; cy <= (sy1 - 1) >> 3; ++cy)
-                for (int cx = sx0 >> 3; cx <= (sx1 - 1) >> 3; ++cx)
-                    __hip_atomic_fetch_add(&s_cnt[cy * g.cx + cx], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < g.cells; c += SC_BLOCK)
-        s_base[c] = w.cell_off[c].x + (uint32_t)w.chunk_cell[(size_t)blockIdx.x * g.cells + c];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        if (r3[it].z) {
             const int sx0 = r3[it].x & 0xffff, sx1 = r3[it].x >> 16, sy0 = r3[it].y & 0xffff, sy1 = r3[it].y >> 16;
             for (int cy = sy0 >> 3; cy <= (sy1 - 1) >> 3; ++cy)
                 for (int cx = sx0 >> 3; cx <= (sx1 - 1) >> 3; ++cx) {
@@ -400,7 +471,7 @@ hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s) {
         chunks = max(chunks, a[k].chunks);
         cells = max(cells, a[k].grid.cells);
     }
-    cell_scatter_kernel<<<dim3(chunks, K), SC_BLOCK, (size_t)cells * 12, s>>>(b);
+    cell_scatter_kernel<<<dim3(chunks, K), SC_BLOCK, (size_t)cells * (a[0].merged ? 24 : 8), s>>>(b);
     return hipGetLastError();
 }
 

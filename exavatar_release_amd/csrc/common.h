@@ -247,8 +247,11 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmat
 
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
 
+// cell_scatter_kernel can do the scans of the count matrix itself (no col_scan / cell_scan launches): worth it while
+// the matrix is small enough for every scatter workgroup to re-read it from L2
+constexpr int MERGE_MAX_CELLS = 1024, MERGE_MAX_CHUNKS = 1024, MERGE_MAX_MATRIX = 1 << 16;
 struct BinArgs {           // one job of the binning stages (binning.hip)
-    int P, chunks;
+    int P, chunks, merged;
     Grid grid;
     Splat* splats; TileWs tw; BinWs bw; uint64_t capacity;
 };

@@ -325,6 +325,42 @@ def test_c3_full_size_properties(dev):
         exa.config.mode = 'exact'
 
 
+@pytest.mark.parametrize('scene', ['c1', 'ragged', 'avatar', 'empty'])
+def test_fused_call_equals_two_stage_call_bitwise(dev, scene):
+    """The fused forward (capacity / auto mode: one C-ABI call, no host round trip; the scans of the count matrix run
+    inside the scatter kernel) against the two-stage protocol (exact mode): images, radii and every gradient bit for bit."""
+    if scene == 'c1':
+        a, shape, cam = scenes.make_config('c1')
+    elif scene == 'ragged':
+        shape = (135, 240)
+        a = scenes.dist_a_random(2500, shape[0], shape[1], seed=3, focal=300.0)
+        cam = scenes.neutral_camera(shape[0], shape[1], focal=300.0)
+    elif scene == 'avatar':
+        shape = (256, 192)
+        a = scenes.dist_b_avatar(20000, seed=4)
+        cam = scenes.ring_camera(256, 192, 13, 200, focal=300.0)
+    else:
+        shape = (40, 72)
+        a = scenes.dist_a_random(0, 40, 72, seed=1)
+        cam = scenes.neutral_camera(40, 72)
+    camd = {k: v.to(dev) for k, v in cam.items()}
+    G = torch.randn(3, *shape, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    res = {}
+    try:
+        for mode in ('exact', 'capacity'):
+            exa.config.mode = mode                 # capacity: sized from the exact call of the same shape just before
+            ag = _to(a, dev)
+            out = exa.GaussianRenderer()(ag, shape, camd, torch.tensor([0.3, 0.2, 0.1], device=dev))
+            (out['img'] * G).sum().backward()
+            exa.check_overflow()
+            res[mode] = ([out[k].detach().clone() for k in ('img', 'depthmap', 'mask', 'radius')],
+                         [ag[k].grad.clone() for k in KEYS] + [out['mean_2d'].grad.clone()])
+    finally:
+        exa.config.mode = 'exact'
+    for x, y in zip(res['exact'][0] + res['exact'][1], res['capacity'][0] + res['capacity'][1]):
+        assert torch.equal(x, y)
+
+
 def test_capacity_overflow_is_reported(dev):
     assets, shape, cam = scenes.make_config('c1')
     exa.config.mode = 'capacity'
