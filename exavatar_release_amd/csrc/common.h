@@ -58,12 +58,13 @@ static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 
 // Per-instance partial gradients written (plain stores, no atomics) by render-backward: the sums over the 64 pixels
 // of one sub-tile, for every instance the forward pass actually blended somewhere (its `touched` byte is set; the
-// rows of all other instances are never written and never read).  Indexed Gaussian-major:
-// inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).  Three naturally aligned arrays, 40 bytes per instance:
-//   row0 = (sum s dx, sum s dy, sum s dx^2, sum s dx dy)        s = dL/dG * G
-//   row1 = (sum s dy^2, sum G dL/dalpha, sum w dL/dC_r, sum w dL/dC_g)    w = alpha T
-//   row2 = (sum w dL/dC_b, sum w dL/dDepth)
-struct PartialWs { float4* row0; float4* row1; float2* row2; };
+// records of all other instances are never written and never read).  Indexed Gaussian-major:
+// inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).  One 48-byte record = three 16-byte rows (one or two cache lines:
+// three separate arrays dirtied twice as many 32-byte sectors, profiles/r02_hbm_traffic.md):
+//   row 0 = (sum s dx, sum s dy, sum s dx^2, sum s dx dy)        s = dL/dG * G
+//   row 1 = (sum s dy^2, sum G dL/dalpha, sum w dL/dC_r, sum w dL/dC_g)    w = alpha T
+//   row 2 = (sum w dL/dC_b, sum w dL/dDepth, -, -)
+struct PartialWs { float4* rec; };
 
 struct Grid {
     int W, H;
@@ -180,14 +181,11 @@ __host__ __device__ inline uint32_t cell_slots(uint32_t inst) {
     return inst ? (inst + BATCH - 1) / BATCH + 2 * SUBS_PER_CELL : 0u;
 }
 
-// backward scratch: the three partial-sum arrays (40 bytes per instance).
-__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return 2 * align256(cap * 16) + align256(cap * 8); }
-__host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t cap) {
+// backward scratch: one 48-byte partial record per instance.
+__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * 48); }
+__host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t) {
     PartialWs w;
-    char* p = static_cast<char*>(base);
-    w.row0 = reinterpret_cast<float4*>(p); p += align256(cap * 16);
-    w.row1 = reinterpret_cast<float4*>(p); p += align256(cap * 16);
-    w.row2 = reinterpret_cast<float2*>(p);
+    w.rec = reinterpret_cast<float4*>(base);
     return w;
 }
 

@@ -10,7 +10,7 @@
 // (pixel gradient * (W/2, H/2), z = 0), which is what the reference's densification reads
 // (avatar/main/train.py:51).
 //
-// HBM traffic per Gaussian: reads 1 B per instance + 40 B per BLENDED instance + 32 B of the splat record + 44 B
+// HBM traffic per Gaussian: reads 1 B per instance + 48 B per BLENDED instance + 32 B of the splat record + 44 B
 // inputs, writes 68 B of gradients (SH: + 12 * M B).
 #include "common.h"
 
@@ -65,9 +65,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         // reported to the host through the header, include/exa_raster.h)
         const bool vis = valid && a.header->overflow == 0u && a.radii[idc] > 0;
         const uint8_t* __restrict__ touched = a.touched;
-        const float4* __restrict__ row0 = a.partials.row0;
-        const float4* __restrict__ row1 = a.partials.row1;
-        const float2* __restrict__ row2 = a.partials.row2;
+        const float4* __restrict__ prec = a.partials.rec;
 
         // Large splats (scene Gaussians: hundreds to > 1000 sub-tiles) would turn the per-lane gather below into a
         // serial tail of hundreds of trips in ONE lane: from COOP_MIN instances on, the whole wave fetches that
@@ -85,8 +83,8 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
                     float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
                         if (touched[off + j]) {
-                            const float4 q0 = row0[off + j], q1 = row1[off + j];
-                            const float2 q2 = row2[off + j];
+                            const float4* src = prec + (size_t)(off + j) * 3;
+                            const float4 q0 = src[0], q1 = src[1], q2 = src[2];
                             acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
                             acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
                             acc[8] += q2.x; acc[9] += q2.y;
@@ -125,14 +123,13 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         if (((fl >> (4 * half)) & 15u) == 0u) continue;
-                        float4 q0[4], q1[4];
-                        float2 q2[4];
+                        float4 q0[4], q1[4], q2[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const bool ok = (fl >> (4 * half + u)) & 1u;
-                            const uint32_t src = off + (ok ? i + 4 * half + u : i);
-                            q0[u] = row0[src]; q1[u] = row1[src]; q2[u] = row2[src];
-                            if (!ok) { q0[u] = make_float4(0.f, 0.f, 0.f, 0.f); q1[u] = q0[u]; q2[u] = make_float2(0.f, 0.f); }
+                            const float4* src = prec + (size_t)(off + (ok ? i + 4 * half + u : i)) * 3;
+                            q0[u] = src[0]; q1[u] = src[1]; q2[u] = src[2];
+                            if (!ok) { q0[u] = make_float4(0.f, 0.f, 0.f, 0.f); q1[u] = q0[u]; q2[u] = q0[u]; }
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {

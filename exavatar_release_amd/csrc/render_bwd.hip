@@ -32,7 +32,7 @@
 //           dx, dy -- and shifted to the splat centre once per chunk; + 3 (4) FMAs for the colour (depth) sums.
 //           The four pixel groups are combined with two shuffle steps.
 //
-// Only blended instances get their 40-byte Gaussian-major partial record written (exactly once: no memset, NO atomic
+// Only blended instances get their 48-byte Gaussian-major partial record written (exactly once: no memset, NO atomic
 // in the whole backward pass -- device-scope fp32 atomics run at ~12 G/s on MI355X -- bit-deterministic) and their
 // `touched` byte set; preprocess_bwd.hip reads the bytes and fetches only those records.
 //
@@ -43,7 +43,7 @@
 // (sum s dx, s dy, s dx^2, s dx dy, s dy^2); preprocess_bwd.hip turns them into d/d(mean2D, conic).
 //
 // Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered (blended) splat, 12 (+8) B/pixel of
-// incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 41 B per blended instance.
+// incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 49 B per blended instance.
 #include "blend.h"
 
 namespace exa {
@@ -148,9 +148,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     const int g = lane & (GC - 1), h = lane >> 4;               // phase B role: splat g of the chunk, pixel group h
     float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane >> 4) * XGROUP + 2 * (lane & 15));   // phase A: my column
     const float4* const xr_row = reinterpret_cast<const float4*>(s_x + h * XGROUP + g * XROW);          // phase B: my row
-    float4* __restrict__ prow0 = a.partials.row0;
-    float4* __restrict__ prow1 = a.partials.row1;
-    float2* __restrict__ prow2 = a.partials.row2;
+    float4* __restrict__ prec = a.partials.rec;
     uint8_t* __restrict__ touched = a.bw.touched;
 
     for (int c0 = 0; c0 < cnt; c0 += GC) {
@@ -229,9 +227,10 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             if (h == 0 && kk < cend) {
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
                 const uint32_t ps = s_pslot[kk];
-                prow0[ps] = make_float4(o * mx, o * my, o * mxx, o * mxy);
-                prow1[ps] = make_float4(o * myy, dop, dr, dg);
-                prow2[ps] = make_float2(db, dz);
+                float4* dst = prec + (size_t)ps * 3;
+                dst[0] = make_float4(o * mx, o * my, o * mxx, o * mxy);
+                dst[1] = make_float4(o * myy, dop, dr, dg);
+                dst[2] = make_float4(db, dz, 0.f, 0.f);
                 touched[ps] = (uint8_t)1;
             }
         }

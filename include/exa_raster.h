@@ -62,7 +62,7 @@ typedef struct ExaRasterWorkspaceSizes {
     uint64_t geom_bytes;   /* per-Gaussian splat records, 64 B * P                         */
     uint64_t tile_bytes;   /* header, (chunk, cell) count matrix, prefixes, per-sub-tile ranges   */
     uint64_t bin_bytes;    /* keys, sorted ids, cell buckets, batch owners / masks, checkpoints: ~50 B * capacity */
-    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 40 B * capacity  */
+    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
 /* Device-side header at the start of the tile workspace (readable with a 24-byte D2H copy). */
