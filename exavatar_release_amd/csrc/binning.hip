@@ -123,7 +123,9 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
 
 // Launch order of the per-cell kernels: cells bucketed by floor(log2(instances)) (33 buckets), heaviest bucket first,
 // so the heaviest cells start early and the tail of the launch is light; the empty cells come last and
-// header.active_cells counts the others.  One workgroup; `inst_of(c)` returns the instance count of cell c.
+// header.active_cells counts the others.  One workgroup; `inst_of(c)` returns the instance count of cell c.  Every
+// record carries the cell's entry range and first instance slot (cell_off, already written to global memory by this
+// workgroup), so that the per-cell workgroups of the next kernels need ONE load instead of a chain of three.
 template <typename F>
 __device__ __forceinline__ void write_cell_order(const TileWs& w, int cells, F inst_of) {
     __shared__ uint32_t s_bucket[34];
@@ -145,7 +147,8 @@ __device__ __forceinline__ void write_cell_order(const TileWs& w, int cells, F i
     __syncthreads();
     for (int c = tid; c < cells; c += (int)blockDim.x) {
         const uint32_t n = inst_of(c);
-        w.cell_order[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = (uint32_t)c;
+        const uint2 o0 = w.cell_off[c], o1 = w.cell_off[c + 1];
+        w.cell_desc[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = make_uint4((uint32_t)c, o0.x, o1.x, o0.y);
     }
 }
 
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
         w.header->num_instances = (uint32_t)ti_tot;
     }
     if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+    __syncthreads();                                             // cell_off (all of it) visible to the whole workgroup
     write_cell_order(w, cells, [&](int c) { return (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32); });
 }
 
@@ -230,7 +234,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     if ((int)blockIdx.x >= a.chunks) {                          // a job with fewer Gaussians than the largest of the batch
         if (a.merged && a.chunks == 0 && blockIdx.x == 0) {     // no Gaussians at all: nobody else writes the tile state
             for (int c = tid; c <= cells; c += SC_BLOCK) w.cell_off[c] = make_uint2(0u, 0u);
-            for (int c = tid; c < cells; c += SC_BLOCK) w.cell_order[c] = (uint32_t)c;
+            for (int c = tid; c < cells; c += SC_BLOCK) w.cell_desc[c] = make_uint4((uint32_t)c, 0u, 0u, 0u);
             if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
             if (tid == 0) {
                 w.header->num_rendered = 0u; w.header->overflow = 0u; w.header->max_tile_list = 0u;
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                 w.header->num_instances = inst_total;
             }
             if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+            __syncthreads();                                     // cell_off (all of it) visible to the whole workgroup
             write_cell_order(w, cells, [&](int c) { return (uint32_t)(s_tot[c] >> 32); });
         }
         __syncthreads();
@@ -357,15 +362,19 @@ constexpr int BIN_THREADS = 1024;
 //   subtile_bin_kernel    reads the cell's BIN_PARTS x 64 counts (totals -> 64-aligned ranges; earlier parts ->
 //                         its own first slot in every sub-tile) and scatters its quarter of the keys.
 // Plain stores and a kernel boundary instead of any cross-workgroup atomics; part 0 publishes ranges and owners.
-struct CellPart { int cell, part; uint32_t e0, e1, lo, hi; bool overflow; };
+struct CellPart { int cell, part; uint32_t e0, e1, lo, hi, slot0; bool overflow, active; };
 __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * BIN_PARTS
     CellPart c;
-    c.cell = (int)w.cell_order[blockIdx.x / BIN_PARTS];
+    // the header and the cell record are independent loads: one round trip
+    const uint4 d = w.cell_desc[blockIdx.x / BIN_PARTS];
+    const uint32_t active = w.header->active_cells, need = w.header->num_rendered;
+    c.cell = (int)d.x;
     c.part = (int)(blockIdx.x % BIN_PARTS);
-    c.overflow = (uint64_t)w.header->num_rendered > capacity;
-    const uint2 o0 = w.cell_off[c.cell], o1 = w.cell_off[c.cell + 1];
-    c.e0 = o0.x;
-    c.e1 = c.overflow ? o0.x : o1.x;
+    c.active = blockIdx.x / BIN_PARTS < active;
+    c.overflow = (uint64_t)need > capacity;
+    c.e0 = d.y;
+    c.e1 = c.overflow ? d.y : d.z;
+    c.slot0 = d.w;
     const uint32_t per = (c.e1 - c.e0 + BIN_PARTS - 1) / BIN_PARTS;
     c.lo = min(c.e1, c.e0 + (uint32_t)c.part * per);
     c.hi = min(c.e1, c.lo + per);
@@ -379,8 +388,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
-    if (blockIdx.x / BIN_PARTS >= w.header->active_cells) return;      // empty cell: nothing to count
     const CellPart cp = cell_part(w, a.capacity);
+    if (!cp.active) return;                                             // empty cell: nothing to count
     const int tid = threadIdx.x;
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
@@ -405,12 +414,11 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
-    if (blockIdx.x / BIN_PARTS >= w.header->active_cells) {             // empty cell: part 0 publishes 64 empty ranges
-        if (blockIdx.x % BIN_PARTS == 0 && threadIdx.x < SUBS_PER_CELL)
-            w.ranges[w.cell_order[blockIdx.x / BIN_PARTS] * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+    const CellPart cp = cell_part(w, a.capacity);
+    if (!cp.active) {                                                   // empty cell: part 0 publishes 64 empty ranges
+        if (cp.part == 0 && threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
         return;
     }
-    const CellPart cp = cell_part(w, a.capacity);
     const int cell = cp.cell, tid = threadIdx.x;
     if (tid < 64) {
         uint32_t n = 0, before = 0;
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         }
         const uint32_t nslot = n ? (n + BATCH - 1) / BATCH + 1 : 0u;       // real batches + one end slot
         const uint32_t incl = wave_incl_scan(nslot);
-        const uint32_t begin = cp.overflow ? 0u : w.cell_off[cell].y + (incl - nslot) * BATCH;
+        const uint32_t begin = cp.overflow ? 0u : cp.slot0 + (incl - nslot) * BATCH;
         s_off[tid] = begin + before;
         s_cnt2[tid] = 0u;
         if (cp.part == 0) {

@@ -92,7 +92,10 @@ __host__ __device__ inline int num_chunks(int P) { return (P + CHUNK - 1) / CHUN
 
 // Layout of the tile workspace (all sections 256-byte aligned).  Nothing in it needs zeroing by the caller or by
 // a memset: every section is fully written by the kernel that produces it before anyone reads it.
-constexpr int BIN_PARTS = 4;           // workgroups per cell in the sub-tile binning (binning.hip)
+#ifndef EXA_BIN_PARTS
+#define EXA_BIN_PARTS 4
+#endif
+constexpr int BIN_PARTS = EXA_BIN_PARTS;   // workgroups per cell in the sub-tile binning (binning.hip)
 struct TileWs {
     ExaRasterHeader* header;          // [1]          written by cell_scan_kernel
     uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class (zeroed by cell_scan)
@@ -105,7 +108,9 @@ struct TileWs {
     uint32_t* chunk_inst;             // [chunks]     instances emitted by each chunk
     uint32_t* chunk_vis;              // [chunks]     Gaussians of the chunk that passed the culls
     uint32_t* chunk_off;              // [chunks]     exclusive prefix of chunk_inst
-    uint32_t* cell_order;             // [cells]      cells by descending instance count (heavy work first)
+    uint4* cell_desc;                 // [cells]      cells by descending instance count (heavy work first):
+                                      //              {cell, first entry, end entry, first instance slot * 64} -- ONE load
+                                      //              gives a per-cell workgroup its work
     uint2* ranges;                    // [subtiles]   [begin, end) into the instance arrays, cell-major
     uint4* slots;                     // [subtiles]   launch-order records {begin, end, st, 0}: ONE load gives a
                                       //              per-pixel-kernel workgroup everything it needs
@@ -115,7 +120,7 @@ struct TileWs {
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return HEADER_BYTES + align256(uint64_t(chunks) * cells * 8) + align256(uint64_t(cells) * 8) +
            align256(uint64_t(cells + 1) * 8) + 3 * align256(uint64_t(chunks + 1) * 4) +
-           align256(uint64_t(cells) * 4) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
+           align256(uint64_t(cells) * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4);
 }
@@ -131,7 +136,7 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.chunk_inst = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.chunk_vis = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.chunk_off = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
-    w.cell_order = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
+    w.cell_desc = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * 16);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.slots = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 16);
     w.fwd_exit = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);

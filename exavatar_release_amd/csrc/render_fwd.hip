@@ -365,13 +365,13 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     const unsigned long long t0 = __builtin_readcyclecounter();
 #endif
     if (blockIdx.x == ORDER_WGS && tid == 0 && (uint64_t)a.tw.header->num_rendered > a.capacity) a.tw.header->overflow = 1u;
-    // Only the sub-tiles of the ACTIVE cells hold lists (cell_order lists those cells first, heaviest first;
+    // Only the sub-tiles of the ACTIVE cells hold lists (cell_desc lists those cells first, heaviest first;
     // header.active_cells counts them): an avatar view has ~3 800 non-empty lists in 16 384 sub-tiles, and the
     // workgroups of the empty ones leave after ONE scalar load instead of two dependent vector loads.  (A
     // grid-stride loop over the active sub-tiles with a smaller grid cost 2.5x the registers and ran slower.)
     const int wg = (int)blockIdx.x - ORDER_WGS;
     if (wg >= (int)a.tw.header->active_cells * SUBS_PER_CELL) return;
-    const int st = (int)a.tw.cell_order[wg >> 6] * SUBS_PER_CELL + (wg & 63);
+    const int st = (int)a.tw.cell_desc[wg >> 6].x * SUBS_PER_CELL + (wg & 63);
     const uint2 range = a.tw.ranges[st];
     const int n = (int)(range.y - range.x);                     // workgroup-uniform; empty on overflow
     if (n == 0) return;
