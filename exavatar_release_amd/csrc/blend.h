@@ -47,8 +47,8 @@ struct Alpha2 { v2f alpha, G; };
 __device__ __forceinline__ Alpha2 splat_alpha2(v2f px, v2f py, v2f ca, v2f cb, v2f cc, v2f op, float fx, float fy) {
 #pragma clang fp contract(off)
     const v2f dx = px - fx, dy = py - fy;
-    const v2f q = __builtin_elementwise_fma(cc * dy, dy, (ca * dx) * dx);
-    const v2f p2 = __builtin_elementwise_fma(-(cb * dx), dy, -0.5f * q);     // log2 of the falloff
+    // (ca, cb, cc) = (-A/2, -B, -C/2) log2(e): log2 of the falloff in four multiplies and two fmas
+    const v2f p2 = __builtin_elementwise_fma(ca * dx, dx, __builtin_elementwise_fma(cc * dy, dy, (cb * dx) * dy));
     Alpha2 r;
     r.G.x = __builtin_amdgcn_exp2f(p2.x);
     r.G.y = __builtin_amdgcn_exp2f(p2.y);

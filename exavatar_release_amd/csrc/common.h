@@ -49,7 +49,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 // 64-byte per-Gaussian splat record: one cache line per gather in the per-pixel kernels.
 struct alignas(64) Splat {
     float px, py, depth; int32_t radius;          // row 0
-    float ca, cb, cc, opacity;                    // row 1: conic (A, B, C) * log2(e), opacity
+    float ca, cb, cc, opacity;                    // row 1: (-A/2, -B, -C/2) * log2(e) of the conic (A, B, C), opacity
     float r, g, b; uint32_t flags;                // row 2: colour + SH clamp bits (bit c: channel c clamped)
     uint32_t sub_x, sub_y, n_inst, inst_off;      // row 3: sx0 | sx1 << 16, sy0 | sy1 << 16 (sub-tile rect,
                                                   //        exclusive upper), instances, Gaussian-major offset
@@ -221,10 +221,9 @@ __device__ __forceinline__ SubTile decode_subtile(int st, const Grid& g) {
 // compiler-chosen contraction) so both kernels take bit-identical skip decisions and the backward
 // pass divides out exactly the alphas the forward pass multiplied in.  The conic is pre-scaled by
 // log2(e): returns log2 of the Gaussian falloff;  G = exp2(power2).
-__device__ __forceinline__ float gauss_power2(float A, float B, float C, float dx, float dy) {
+__device__ __forceinline__ float gauss_power2(float A, float B, float C, float dx, float dy) {   // pre-scaled conic
 #pragma clang fp contract(off)
-    const float q = __builtin_fmaf(C * dy, dy, (A * dx) * dx);
-    return __builtin_fmaf(-(B * dx), dy, -0.5f * q);
+    return __builtin_fmaf(A * dx, dx, __builtin_fmaf(C * dy, dy, (B * dx) * dy));
 }
 __device__ __forceinline__ float gauss_falloff2(float power2) { return __builtin_amdgcn_exp2f(power2); }
 

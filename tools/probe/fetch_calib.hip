@@ -4,6 +4,8 @@
 // 1 GiB buffer (larger than L2 + Infinity Cache), each with a known byte count:
 //   stream_read   every lane reads 16 B, coalesced           (the per-Gaussian / per-pixel streams)
 //   gather64      every lane reads 48 B of a random 64-B record (the splat-record gathers of the render kernels)
+//   stream_read4  every lane reads 4 B, coalesced            (sorted ids, checkpoints, pixel gradients)
+//   stream_read12 every lane reads 3 x 4 B at stride 12 B    (means3D / colours in the per-Gaussian kernels)
 //   stream_write  every lane writes 16 B, coalesced
 // Build: hipcc -w --offload-arch=gfx950 -O3 -o fetch_calib fetch_calib.hip ; run under
 //   rocprofv3 --kernel-trace --pmc FETCH_SIZE ...   and   rocprofv3 --kernel-trace --pmc WRITE_SIZE ...
@@ -14,6 +16,18 @@ __global__ void stream_read(const float4* p, size_t n, float* sink) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     float acc = 0.f;
     for (; i < n; i += (size_t)gridDim.x * blockDim.x) { float4 v = p[i]; acc += v.x + v.y + v.z + v.w; }
+    if (acc == 123.456f) *sink = acc;
+}
+__global__ void stream_read4(const float* p, size_t n, float* sink) {          // 4 B per lane, coalesced (ids, checkpoints)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) acc += p[i];
+    if (acc == 123.456f) *sink = acc;
+}
+__global__ void stream_read12(const float* p, size_t n3, float* sink) {        // 3 x 4 B per lane at stride 12 B (means3D, colours)
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    for (; i < n3; i += (size_t)gridDim.x * blockDim.x) acc += p[3 * i] + p[3 * i + 1] + p[3 * i + 2];
     if (acc == 123.456f) *sink = acc;
 }
 __global__ void gather64(const float4* p, size_t nrec, size_t reads, float* sink) {
@@ -39,6 +53,8 @@ int main() {
     for (int rep = 0; rep < 3; ++rep) {
         stream_read<<<4096, 256>>>(buf, n16, sink);
         gather64<<<4096, 256>>>(buf, nrec, reads, sink);
+        stream_read4<<<4096, 256>>>((const float*)buf, bytes / 4, sink);
+        stream_read12<<<4096, 256>>>((const float*)buf, bytes / 12, sink);
         stream_write<<<4096, 256>>>(buf, n16);
     }
     hipDeviceSynchronize();
