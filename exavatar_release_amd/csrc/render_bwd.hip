@@ -44,29 +44,34 @@
 //
 // Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered (blended) splat, 12 (+8) B/pixel of
 // incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 49 B per blended instance.
+#include <stdlib.h>
 #include "blend.h"
 
 namespace exa {
 
 constexpr int RBLOCK = 64;            // ONE wave per workgroup
-constexpr int GC = 16;                // splats per chunk
-constexpr int XROW = 36;              // floats per (pixel group, splat) row of the transposition buffer: 16 pixels x
-                                      // {aG, w} + 4 pad -> the 16 rows read together by ds_read_b128 start 9 quads
-                                      // apart: all 64 banks, no conflict
-constexpr int XGROUP = GC * XROW;     // floats per pixel group
+// Chunk = GC splats x 64 pixels in the transposition buffer; lane (g, h) of phase B sums splat g over the GC pixels of
+// pixel group h (64 / GC groups).  Layouts found by exhaustive search for conflict-free ds_read_b128 rows:
+//   GC = 16: row = 16 pixels x {aG, w} + 4 pad = 36 floats, group stride 16 rows            (9 216 B, 3 waves / SIMD)
+//   GC =  8: row =  8 pixels x {aG, w}         = 16 floats, group stride 132 floats         (4 224 B, 5 waves / SIMD;
+//            one pixel ROW per group: no y moments inside the loop, but three shuffle steps instead of two)
+template <int GC> struct XLayout;
+template <> struct XLayout<16> { static constexpr int ROW = 36, GROUP = 16 * 36, FLOATS = 4 * 16 * 36; };
+template <> struct XLayout<8> { static constexpr int ROW = 16, GROUP = 132, FLOATS = 8 * 132; };
 
 __device__ __forceinline__ int mask_rank(uint32_t lo, uint32_t hi) {          // set bits of (hi:lo) below this lane
     return (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
 }
 
-template <bool HAS_DEPTH>
+template <bool HAS_DEPTH, int GC>
 __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
+    constexpr int XROW = XLayout<GC>::ROW, XGROUP = XLayout<GC>::GROUP;
     __shared__ BatchLds s_b;
     __shared__ float4 s_pg[4 * 17];             // incoming gradient of each pixel (r, g, b, depth), 16 per pixel group;
                                                 // group stride 17: the two groups one ds_read_b128 quarter-wave sees
                                                 // sit on different banks
     __shared__ uint32_t s_pslot[64];            // Partial slot of each staged splat
-    __shared__ __attribute__((aligned(16))) float s_x[4 * XGROUP];   // {aG, w}[pixel group][splat][pixel of the group]
+    __shared__ __attribute__((aligned(16))) float s_x[XLayout<GC>::FLOATS];   // {aG, w}[pixel group][splat][pixel of the group]
 
     const RenderBwdArgs& a = batch.v[blockIdx.y];
     const uint32_t slot = blockIdx.x;
@@ -145,8 +150,8 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     if (HAS_DEPTH) R = fmaf(cf4 - sd, gd, R);
     wave_lds_fence();
 
-    const int g = lane & (GC - 1), h = lane >> 4;               // phase B role: splat g of the chunk, pixel group h
-    float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane >> 4) * XGROUP + 2 * (lane & 15));   // phase A: my column
+    const int g = lane % GC, h = lane / GC;                     // phase B role: splat g of the chunk, pixel group h
+    float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane / GC) * XGROUP + 2 * (lane % GC));    // phase A: my column
     const float4* const xr_row = reinterpret_cast<const float4*>(s_x + h * XGROUP + g * XROW);          // phase B: my row
     float4* __restrict__ prec = a.partials.rec;
     uint8_t* __restrict__ touched = a.bw.touched;
@@ -156,9 +161,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
         {
-            auto group4 = [&](const Ops4& ops, int k) {
-                const float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
-                const Alpha4 e = splat_alpha4(ops, fx, fy);
+            auto grad4 = [&](const Alpha4& e, const float4 (&col)[4], int k) {
                 float aeff[4], Tb[4], w[4];
                 blend_group4(T, live, e.alpha, aeff, Tb, w);
                 float2* x = xw_row + (k - c0) * (XROW / 2);
@@ -172,6 +175,10 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
                     const float dLda = fmaf(Tb[u], cg, -(R * inv));
                     x[u * (XROW / 2)] = make_float2(w[u] > 0.0f ? e.G[u] * dLda : 0.0f, w[u]);
                 }
+            };
+            auto group4 = [&](const Ops4& ops, int k) {
+                const float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
+                grad4(splat_alpha4(ops, fx, fy), col, k);
             };
             // two groups per trip, ping-pong operand registers (next group's operands in flight, no register rotation)
             Ops4 opsA = load_ops4(s_b, c0);
@@ -189,13 +196,14 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             const int kk = c0 + g;                              // rows >= cend hold stale data: never stored
             float S0 = 0.f, Sx = 0.f, Sxx = 0.f, Sy = 0.f, Sxy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dz = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < GC / 2; ++j) {
                 const float4 v = xr_row[j];                     // {aG, w} of pixels q = 2j, 2j + 1 of the group
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int q = 2 * j + t;
                     const float aG = t ? v.z : v.x, wq = t ? v.w : v.y;
-                    const float4 pg = s_pg[h * 17 + q];
+                    const int pp = h * GC + q;                  // pixel of the sub-tile
+                    const float4 pg = s_pg[(pp >> 4) * 17 + (pp & 15)];
                     const float X = (float)((q & 7) - 4);       // compile-time pixel coordinates (about column 4, row 2h)
                     S0 += aG;
                     if ((q & 7) != 4) { Sx = fmaf(aG, X, Sx); Sxx = fmaf(aG, X * X, Sxx); }
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             }
             // moments about the splat centre: d = (gx, gy) - pixel;  with u = gx - (ox + 4), v = gy - (oy + 2h):
             //   sum aG dx = u S0 - Sx, sum aG dy = v S0 - Sy, sum aG dx^2 = u (u S0 - 2 Sx) + Sxx, ...  (Syy = Sy)
-            const float u0 = s_b.px[kk] - (float)(sub.ox + 4), v0 = s_b.py[kk] - (float)(sub.oy + 2 * h);
+            const float u0 = s_b.px[kk] - (float)(sub.ox + 4), v0 = s_b.py[kk] - (float)(sub.oy + (GC / 8) * h);
             float mx = fmaf(u0, S0, -Sx), my = fmaf(v0, S0, -Sy);
             float mxx = fmaf(u0, mx - Sx, Sxx);
             float mxy = fmaf(v0, mx, fmaf(-u0, Sy, Sxy));
@@ -246,10 +254,15 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
         depth = depth || a[k].dL_ddepth != nullptr;
     }
     if (slots == 0) return hipSuccess;
-    if (depth)
-        render_bwd_kernel<true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(make_batch(a, K));
-    else
-        render_bwd_kernel<false><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(make_batch(a, K));
+    static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();   // developer knob
+    const dim3 grid((unsigned)slots, K);
+    if (gc == 8) {
+        if (depth) render_bwd_kernel<true, 8><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
+        else render_bwd_kernel<false, 8><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
+    } else {
+        if (depth) render_bwd_kernel<true, 16><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
+        else render_bwd_kernel<false, 16><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
+    }
     return hipGetLastError();
 }
 

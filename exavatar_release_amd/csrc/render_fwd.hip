@@ -473,10 +473,8 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         // entry that stops a pixel counts).  The backward pass replays exactly those: on avatar-like scenes only
         // ~60 % of the entries of the batches the forward enters (tools/cpu_blend_stats.py).
         unsigned long long blended = 0ull;
-        // One group of four splats; returns true when every pixel of the sub-tile has stopped.
-        auto group4 = [&](const Ops4& ops, int k) -> bool {
-            const float4 c0 = s_b.col[k], c1 = s_b.col[k + 1], c2 = s_b.col[k + 2], c3 = s_b.col[k + 3];
-            const Alpha4 e = splat_alpha4(ops, fx, fy);
+        // Blend one group of four splats whose alphas are known; returns true when every pixel of the sub-tile has stopped.
+        auto blend4 = [&](const Alpha4& e, const float4& c0, const float4& c1, const float4& c2, const float4& c3, int k) -> bool {
             const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
             if (!__any(amax > 0.0f)) return false;
             float aeff[4], Tb[4], w[4];
@@ -499,6 +497,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         };
         // two groups per trip with ping-pong operand registers: the operands of the next group are in flight during the
         // current one, and no register-to-register rotation is needed (a `cur = nxt` copy cost 12 v_mov_b64 per group)
+        auto group4 = [&](const Ops4& ops, int k) -> bool {
+            const float4 c0 = s_b.col[k], c1 = s_b.col[k + 1], c2 = s_b.col[k + 2], c3 = s_b.col[k + 3];
+            return blend4(splat_alpha4(ops, fx, fy), c0, c1, c2, c3, k);
+        };
         Ops4 opsA = load_ops4(s_b, 0);
         for (int k = 0; k < cnt; k += 8) {
             const Ops4 opsB = load_ops4(s_b, (k + 4) & 63);
