@@ -67,6 +67,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
         ('grad_ws', c_void_p),
         ('dL_dmeans2D', c_void_p), ('dL_dmeans3D', c_void_p), ('dL_dcolors', c_void_p), ('dL_dopacity', c_void_p),
         ('dL_dscales', c_void_p), ('dL_drotations', c_void_p), ('dL_dsh', c_void_p), ('dL_dcov3D', c_void_p),
+        ('densify_grad_accum', c_void_p), ('densify_track_cnt', c_void_p), ('densify_radius_max', c_void_p),
     ]
 
 

@@ -250,6 +250,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipS
         b.dL_dmeans2D = j.dL_dmeans2D; b.dL_dmeans3D = j.dL_dmeans3D; b.dL_dcolors = j.dL_dcolors;
         b.dL_dopacity = j.dL_dopacity; b.dL_dscales = j.dL_dscales; b.dL_drotations = j.dL_drotations;
         b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;
+        b.dens_accum = j.densify_grad_accum; b.dens_cnt = j.densify_track_cnt; b.dens_rmax = j.densify_radius_max;
         ++n;
     }
     if (n == 0) return 0;
@@ -391,6 +392,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     j.dL_dcolor = dL_dcolor; j.dL_ddepth = dL_ddepth; j.dL_dalpha = dL_dalpha; j.grad_ws = grad_ws;
     j.dL_dmeans2D = dL_dmeans2D; j.dL_dmeans3D = dL_dmeans3D; j.dL_dcolors = dL_dcolors; j.dL_dopacity = dL_dopacity;
     j.dL_dscales = dL_dscales; j.dL_drotations = dL_drotations; j.dL_dsh = dL_dsh; j.dL_dcov3D = dL_dcov3D;
+    j.densify_grad_accum = nullptr; j.densify_track_cnt = nullptr; j.densify_radius_max = nullptr;
     return exa_raster_backward_batch(&j, 1, 0, stream);
 }
 

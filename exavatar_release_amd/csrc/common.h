@@ -288,6 +288,7 @@ struct PreprocessBwdArgs {
     const ExaRasterHeader* header;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
+    float* dens_accum; float* dens_cnt; float* dens_rmax;       // optional fused densification statistics (per view)
 };
 // sum_shared != 0: the K jobs are K views of the SAME Gaussians (identical input pointers and P): one thread
 // per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).

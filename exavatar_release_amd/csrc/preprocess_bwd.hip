@@ -351,6 +351,13 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         if (valid && a.dL_dmeans2D) {
             a.dL_dmeans2D[idx * 3 + 0] = vm2[0]; a.dL_dmeans2D[idx * 3 + 1] = vm2[1]; a.dL_dmeans2D[idx * 3 + 2] = 0.f;
         }
+        // fused densification statistics of this view (reference avatar/main/model.py:279-285 + module.py:155-157): the
+        // screen-space gradient is in registers here, no separate pass over the Gaussians
+        if (vis) {
+            if (a.dens_accum) a.dens_accum[idx] += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
+            if (a.dens_cnt) a.dens_cnt[idx] += 1.0f;
+            if (a.dens_rmax) a.dens_rmax[idx] = fmaxf(a.dens_rmax[idx], (float)a.radii[idc]);
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { dmean[i] += vmean[i]; dscale[i] += vscale[i]; dcol[i] += vcol[i]; }
 #pragma unroll

@@ -192,10 +192,12 @@ N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, 
 
 
 class _Rasterize(torch.autograd.Function):
-    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, *tensors[8 K])."""
+    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, densify, *tensors[8 K]).
+    ``densify``: None or a K-list of None / (xyz_grad_accum, track_cnt, radius_max) tensors updated IN PLACE by that
+    render's backward (fused densification statistics, include/exa_raster.h)."""
 
     @staticmethod
-    def forward(ctx, K, settings, grad_enabled, shared, *tensors):
+    def forward(ctx, K, settings, grad_enabled, shared, densify, *tensors):
         lib = _lib.load()
         device = tensors[0].device
         if device.type != 'cuda':
@@ -307,6 +309,7 @@ class _Rasterize(torch.autograd.Function):
             outs += [j.planes[0:3], j.radii, j.planes[3:4], j.planes[4:5]]
         if need_ctx:
             ctx.K = K
+            ctx.densify = densify
             ctx.shared = bool(shared) and K > 1
             ctx.hdr_check = hdr_check
             ctx.meta = [(j.rs, j.P, j.H, j.W, j.sh_M, j.capacity, j.gb, j.tb, j.settings, j.keep, j.ws, j.bins,
@@ -337,9 +340,9 @@ class _Rasterize(torch.autograd.Function):
         saved = ctx.saved_tensors
         device = saved[0].device
         f32 = dict(dtype=torch.float32, device=device)
-        need = ctx.needs_input_grad[4:]
+        need = ctx.needs_input_grad[5:]
         arr = (_lib.ExaRasterBackwardJob * K)()
-        keep, ret = [], [None, None, None, None]
+        keep, ret = [], [None, None, None, None, None]
         with torch.cuda.device(device):
             for k in range(K):
                 rs, P, H, W, sh_M, cap, gb, tb, st, _skeep, ws, bins, has = ctx.meta[k]
@@ -391,6 +394,13 @@ class _Rasterize(torch.autograd.Function):
                 a.dL_dmeans2D, a.dL_dmeans3D, a.dL_dcolors = _addr(d_means2D), _addr(d_means3D), _addr(d_colors)
                 a.dL_dopacity, a.dL_dscales, a.dL_drotations = _addr(d_opac), _addr(d_scales), _addr(d_rot)
                 a.dL_dsh, a.dL_dcov3D = _addr(d_sh), _addr(d_cov)
+                dens = ctx.densify[k] if ctx.densify is not None else None
+                if dens is not None:
+                    if d_means2D is None:          # the statistics need the screen-space gradient: compute it anyway
+                        d_tmp = torch.empty((P, 3), **f32)
+                        keep.append(d_tmp)
+                        a.dL_dmeans2D = d_tmp.data_ptr()
+                    a.densify_grad_accum, a.densify_track_cnt, a.densify_radius_max = [_addr(t) for t in dens]
                 ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
             _lib.check(lib.exa_raster_backward_batch(arr, K, int(ctx.shared), _stream_ptr(device)))
         if ctx.hdr_check is not None:
@@ -407,10 +417,25 @@ class _Rasterize(torch.autograd.Function):
         return tuple(ret)
 
 
+def _check_densify(dens, P, device):
+    if dens is None:
+        return None
+    dens = tuple(dens)
+    if len(dens) != 3:
+        raise ValueError('densify_stats = (xyz_grad_accum, track_cnt, radius_max), any of them None')
+    for name, t in zip(('xyz_grad_accum', 'track_cnt', 'radius_max'), dens):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P or t.device != device):
+            raise ValueError('%s must be a contiguous float32 tensor with %d elements on %s' % (name, P, device))
+    return dens
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
-    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, means3D, means2D, sh, colors_precomp,
-                            opacities, scales, rotations, cov3Ds_precomp)
+                        raster_settings, densify_stats=None):
+    """``densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` float32 tensors of P elements that THIS
+    render's backward updates in place (fused densification statistics, see ``densify.track_densify_stats``)."""
+    dens = None if densify_stats is None else [_check_densify(densify_stats, int(means3D.shape[0]), means3D.device)]
+    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, dens, means3D, means2D, sh,
+                            colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
 
 
 _IN_NAMES = ('means3D', 'means2D', 'shs', 'colors_precomp', 'opacities', 'scales', 'rotations', 'cov3D_precomp')
@@ -420,7 +445,7 @@ def rasterize_gaussians_batch(jobs):
     """K renders in one launch per pipeline stage.
 
     ``jobs``: sequence of dicts with the keyword arguments of ``GaussianRasterizer.forward`` plus
-    ``raster_settings``.  Returns a list of ``(color, radii, depth, alpha)`` tuples, bit-identical to K single
+    ``raster_settings`` (and optionally ``densify_stats``, see :func:`rasterize_gaussians`).  Returns a list of ``(color, radii, depth, alpha)`` tuples, bit-identical to K single
     calls.  When every job passes the SAME tensor objects for the Gaussians (K views of one model), the backward
     sums the K views' gradients inside the per-Gaussian kernel (one thread walks the K views) instead of letting
     autograd add K gradient tensors.
@@ -436,7 +461,10 @@ def rasterize_gaussians_batch(jobs):
     shared = K > 1 and all(all(jobs[k].get(n) is jobs[0].get(n) for n in _IN_NAMES if n != 'means2D') for k in range(1, K))
     if shared and K > 8:
         shared = False
-    outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, *flat)
+    dens = None
+    if any(j.get('densify_stats') is not None for j in jobs):
+        dens = [_check_densify(j.get('densify_stats'), int(j['means3D'].shape[0]), j['means3D'].device) for j in jobs]
+    outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, dens, *flat)
     return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
 
 

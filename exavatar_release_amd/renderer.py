@@ -12,7 +12,8 @@ import torch
 import torch.nn as nn
 
 from .camera import make_raster_matrices
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_batch
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,
+                         rasterize_gaussians_batch)
 
 
 _CAM_KEYS = ('focal', 'princpt', 'R', 't')
@@ -52,7 +53,7 @@ def _camera_block(cam_param, img_shape, device):
     return res
 
 
-def _raster_job(gaussian_assets, img_shape, cam_param, bg):
+def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None):
     """Settings tuple + rasterizer keyword arguments of one render, built exactly as module.py:594-640 does."""
     mean_3d = gaussian_assets['mean_3d']
     device = mean_3d.device
@@ -81,7 +82,8 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg):
     mean_2d.retain_grad()
     return dict(raster_settings=raster_settings, means3D=mean_3d, means2D=mean_2d, shs=None,
                 colors_precomp=gaussian_assets['rgb'], opacities=gaussian_assets['opacity'],
-                scales=gaussian_assets['scale'], rotations=gaussian_assets['rotation'], cov3D_precomp=None)
+                scales=gaussian_assets['scale'], rotations=gaussian_assets['rotation'], cov3D_precomp=None,
+                densify_stats=densify_stats)
 
 
 def _output_dict(job, outs):
@@ -98,18 +100,25 @@ class GaussianRenderer(nn.Module):
     def __init__(self):
         super(GaussianRenderer, self).__init__()
 
-    def forward(self, gaussian_assets, img_shape, cam_param, bg=None):
-        job = _raster_job(gaussian_assets, img_shape, cam_param, bg)
-        rasterizer = GaussianRasterizer(raster_settings=job['raster_settings'])
-        outs = rasterizer(
-            means3D=job['means3D'],
-            means2D=job['means2D'],
-            shs=None,
-            colors_precomp=job['colors_precomp'],
-            opacities=job['opacities'],
-            scales=job['scales'],
-            rotations=job['rotations'],
-            cov3D_precomp=None)
+    def forward(self, gaussian_assets, img_shape, cam_param, bg=None, densify_stats=None):
+        """Same call and output dict as module.py:592-647.  ``densify_stats`` (not in the reference): optional
+        ``(xyz_grad_accum, track_cnt, radius_max)`` tensors that this render's backward updates in place -- the
+        bookkeeping of avatar/main/model.py:279-285 + module.py:155-157 fused into the backward pass."""
+        job = _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats)
+        if densify_stats is not None:
+            outs = rasterize_gaussians(job['means3D'], job['means2D'], None, job['colors_precomp'], job['opacities'],
+                                       job['scales'], job['rotations'], None, job['raster_settings'], densify_stats)
+        else:
+            rasterizer = GaussianRasterizer(raster_settings=job['raster_settings'])
+            outs = rasterizer(
+                means3D=job['means3D'],
+                means2D=job['means2D'],
+                shs=None,
+                colors_precomp=job['colors_precomp'],
+                opacities=job['opacities'],
+                scales=job['scales'],
+                rotations=job['rotations'],
+                cov3D_precomp=None)
         return _output_dict(job, outs)
 
 
@@ -124,7 +133,7 @@ def render_many(renderer, jobs):
     instead of 2 K in the backward, one autograd node, and the renders' workgroups fill the chip together.  Results
     are bit-identical to sequential calls (the pipeline has no atomics).
 
-    ``jobs``: sequence of ``(gaussian_assets, img_shape, cam_param, bg)`` tuples (``bg`` may be ``None``).
+    ``jobs``: sequence of ``(gaussian_assets, img_shape, cam_param, bg[, densify_stats])`` tuples (``bg`` may be ``None``).
     Returns the list of output dicts of ``renderer.forward``.
     """
     jobs = list(jobs)
@@ -133,7 +142,7 @@ def render_many(renderer, jobs):
     device = jobs[0][0]['mean_3d'].device
     if device.type != 'cuda':
         raise RuntimeError('exavatar_release_amd: render_many runs on a ROCm device only')
-    rj = [_raster_job(j[0], j[1], j[2], j[3] if len(j) > 3 else None) for j in jobs]
+    rj = [_raster_job(j[0], j[1], j[2], j[3] if len(j) > 3 else None, j[4] if len(j) > 4 else None) for j in jobs]
     outs = rasterize_gaussians_batch(rj)
     return [_output_dict(j, o) for j, o in zip(rj, outs)]
 

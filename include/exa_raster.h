@@ -182,6 +182,9 @@ typedef struct ExaRasterBackwardJob {
     void* grad_ws;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
+    /* optional fused densification statistics (all three NULL = off): updated in place by the per-Gaussian backward
+     * kernel exactly as exa_raster_densify_stats would do it with this job's dL_dmeans2D and radii -- no extra pass */
+    float* densify_grad_accum; float* densify_track_cnt; float* densify_radius_max;
 } ExaRasterBackwardJob;
 
 int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream);
@@ -202,6 +205,8 @@ int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const 
  *     track_cnt[i]      += 1
  *     radius_max[i]      = max(radius_max[i], (float)radii[i])
  * All arrays are device pointers of P elements ([P,3] for dL_dmeans2D); any of the three outputs may be NULL.
+ * The same update can ride along in the backward pass itself (ExaRasterBackwardJob.densify_*): the screen-space gradient
+ * is in registers there, so the statistics cost no extra P-sized pass.
  */
 int exa_raster_densify_stats(int32_t P, const float* dL_dmeans2D, const int32_t* radii,
                              float* xyz_grad_accum, float* track_cnt, float* radius_max, void* stream);

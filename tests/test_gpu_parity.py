@@ -449,6 +449,7 @@ def test_fused_densify_stats_match_reference_bookkeeping(dev):
     cnt = torch.randint(0, 5, (P, 1)).float()
     rmax = torch.rand(P) * 3
     acc_g, cnt_g, rmax_g = acc.to(dev), cnt.to(dev), rmax.to(dev)
+    acc0, cnt0, rmax0 = acc.clone(), cnt.clone(), rmax.clone()
     for v in range(3):
         cam = scenes.ring_camera(H, W, v, 12, radius=3.0, center=(0, 0, 4.0), focal=180.0)
         ag = _to(a, dev)
@@ -460,6 +461,15 @@ def test_fused_densify_stats_match_reference_bookkeeping(dev):
     assert torch.equal(cnt_g.cpu(), cnt) and torch.equal(rmax_g.cpu(), rmax)
     assert torch.allclose(acc_g.cpu(), acc, rtol=1e-6, atol=0)
     assert float(cnt[:500].max()) <= 4.0 and torch.equal(cnt_g.cpu()[:500], cnt[:500])
+    # the same statistics riding along in the backward pass itself (ExaRasterBackwardJob.densify_*): no extra kernel
+    acc2, cnt2, rmax2 = acc0.to(dev), cnt0.to(dev), rmax0.to(dev)
+    for v in range(3):
+        cam = scenes.ring_camera(H, W, v, 12, radius=3.0, center=(0, 0, 4.0), focal=180.0)
+        ag = _to(a, dev)
+        out = exa.GaussianRenderer()(ag, (H, W), {k: t.to(dev) for k, t in cam.items()}, torch.ones(3, device=dev),
+                                     densify_stats=(acc2, cnt2, rmax2))
+        out['img'].square().sum().backward()
+    assert torch.equal(cnt2, cnt_g) and torch.equal(rmax2, rmax_g) and torch.equal(acc2, acc_g)
 
 
 def test_render_many_is_bit_identical_to_sequential_renders(dev):
