@@ -34,8 +34,9 @@ def iteration(concurrent):
 for mode in ('exact', 'auto'):
     exa.config.mode = mode
     for conc in (False, True):
-        for _ in range(5):
+        for _ in range(60):          # long warm-up: the first phase after a protocol switch measured slow for dozens of iterations
             iteration(conc)
+            torch.cuda.synchronize()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 30
         for _ in range(n):

@@ -53,22 +53,45 @@ with open(os.path.join(out, prefix + '_kernel_stats.md'), 'w') as f:
 # ---- HBM traffic -----------------------------------------------------------------------------------------
 fe, wr = counters('pmc_fetch'), counters('pmc_write')
 alg = bench['roofline'].get('algorithmic_bytes_per_launch')
-tr = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes), python '
-                'tools/gpu_kernel_times.py 0 (C3, ring view 0, eager, mean of the launches); bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, '
-                'no gfx950 wide-read x2 correction applied (access pattern is 16-B gathers, uncalibrated)', 'kernels': {}}
+# calibration of the two counters on THIS box (tools/probe/fetch_calib.hip run under the same two PMC passes by
+# tools/profile_round.sh): factor = known bytes / reported bytes
+calib = {}
+for d, c in (('calib_fetch', 'FETCH_SIZE'), ('calib_write', 'WRITE_SIZE')):
+    rows = collections.defaultdict(list)
+    for path in glob.glob(os.path.join(src, d, '**', '*counter_collection.csv'), recursive=True):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                if r['Counter_Name'] == c:
+                    rows[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
+    calib[c] = {k: sum(v) / len(v) for k, v in rows.items()}
+GIB_KB = float(1 << 20)
+known = {'stream_read': GIB_KB, 'stream_read4': GIB_KB, 'stream_read12': GIB_KB, 'gather64': 4 * (1 << 20) * 64 / 1024.0}
+factors = {k: known[k] / calib['FETCH_SIZE'][k] for k in known if calib['FETCH_SIZE'].get(k)}
+if calib['WRITE_SIZE'].get('stream_write'):
+    factors['stream_write'] = GIB_KB / calib['WRITE_SIZE']['stream_write']
+tr = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (two separate passes, counters only), python '
+                'tools/gpu_kernel_times.py 0 (C3, ring view 0, eager, mean of the launches).  hbm_bytes_raw = (FETCH_SIZE + '
+                'WRITE_SIZE) * 1024; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 = the gfx950 correction of '
+                'MI355X_MICROARCH.md applied to ALL reads (an upper bound: the calibration probe shows factor 2 for coalesced '
+                '4 / 12 / 16 B-per-lane streams but factor 1 for 64-byte record gathers, and these kernels mix both)',
+      'calibration_factors': factors, 'kernels': {}}
 with open(os.path.join(out, prefix + '_hbm_traffic.md'), 'w') as f:
     f.write('# %s: HBM-side traffic per kernel launch (PMC)\n\n' % prefix)
-    f.write('Two separate PMC passes (no other trace domains): `rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- '
-            'python tools/gpu_kernel_times.py 0` and the same with `--pmc WRITE_SIZE`. Config C3, ring view 0. '
-            'bytes = (FETCH_SIZE + WRITE_SIZE) x 1024. MI355X_MICROARCH.md notes FETCH_SIZE under-reports wide coalesced '
-            '16-B/lane streams by 2x on gfx950 and is uncalibrated for other patterns; these kernels mostly gather 64-byte '
-            'records, so the raw value is listed (read side may be up to 2x higher).\n\n')
-    f.write('| kernel | FETCH_SIZE (KB) | WRITE_SIZE (KB) | HBM bytes |\n|---|---|---|---|\n')
+    f.write('Two separate PMC passes (counters only, `--kernel-trace`, no other trace domains): `rocprofv3 --kernel-trace --pmc '
+            'FETCH_SIZE --output-format csv -- python tools/gpu_kernel_times.py 0` and the same with `--pmc WRITE_SIZE`. Config '
+            'C3, ring view 0 (exact mode: the two-stage protocol, so col_scan / cell_scan appear as launches).\n\n'
+            'Calibration on the same box in the same two passes (`tools/probe/fetch_calib.hip`, 1 GiB buffer, known byte '
+            'counts; factor = actual / reported): ' + ', '.join('%s x%.2f' % (k, v) for k, v in sorted(factors.items())) +
+            '. I.e. FETCH_SIZE reports HALF of every coalesced streaming read (4, 12 and 16 bytes per lane alike, as '
+            'MI355X_MICROARCH.md says for 16 B/lane) but the full 64 bytes of a gathered record; WRITE_SIZE is exact. The '
+            'render kernels mix record gathers with streams (ids, checkpoints, pixel gradients), so both the raw sum and the '
+            'all-reads-doubled upper bound are listed; `bench.py` reports the upper bound as `roofline.traffic`.\n\n')
+    f.write('| kernel | FETCH_SIZE (KB) | WRITE_SIZE (KB) | raw bytes | upper bound (2 x FETCH + WRITE) |\n|---|---|---|---|---|\n')
     for k in SHORT.values():
         if k in fe and k in wr:
             a, b = fe[k].get('FETCH_SIZE', 0.0), wr[k].get('WRITE_SIZE', 0.0)
-            tr['kernels'][k] = {'fetch_KB': a, 'write_KB': b, 'hbm_bytes': (a + b) * 1024}
-            f.write('| %s | %.0f | %.0f | %.3g |\n' % (k, a, b, (a + b) * 1024))
+            tr['kernels'][k] = {'fetch_KB': a, 'write_KB': b, 'hbm_bytes_raw': (a + b) * 1024, 'hbm_bytes': (2 * a + b) * 1024}
+            f.write('| %s | %.0f | %.0f | %.3g | %.3g |\n' % (k, a, b, (a + b) * 1024, (2 * a + b) * 1024))
 with open(os.path.join(out, prefix + '_hbm_traffic.json'), 'w') as f:
     json.dump(tr, f, indent=1)
 
