@@ -564,6 +564,43 @@ def test_batched_views_equal_single_renders_and_sum_gradients(dev):
                            abs_scale=rotation_grad_scale(a_cpu['scale'], a_cpu['scale'].grad) if k == 'rotation' else 0.0)
 
 
+def test_batched_views_with_in_kernel_sh_sum_gradients(dev):
+    """The `shs` path through a batch of views of the same Gaussians (the per-Gaussian backward then walks the views in
+    one thread and accumulates dL/dsh in place): equals the sum of single renders; P is no multiple of 64."""
+    H, W = 96, 128
+    f = 150.0
+    P = 1500 + 13
+    a = scenes.dist_a_random(P, H, W, seed=71, focal=f)
+    sh0 = scenes.sh_from_rgb(a['rgb'], 2, seed=3, rest_sigma=0.3)
+    g = torch.Generator().manual_seed(72)
+    Gs = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(3)]
+    bg = torch.rand(3, generator=g).to(dev)
+    sts = []
+    for v in (0, 7, 19):
+        tanx, tany, view, proj, campos = make_raster_matrices(
+            scenes.ring_camera(H, W, v, 40, radius=4.0, center=(0, 0, 4.0), focal=f), (H, W))
+        sts.append(exa.GaussianRasterizationSettings(H, W, tanx, tany, bg, 1.0, view.to(dev), proj.to(dev), 2, campos.to(dev),
+                                                     False, False))
+
+    def leaves():
+        t = {k: a[k].to(dev).requires_grad_(True) for k in ('mean_3d', 'scale', 'rotation', 'opacity')}
+        t['sh'] = sh0.to(dev).requires_grad_(True)
+        return t
+    ts, tb = leaves(), leaves()
+    kw = lambda t, st: dict(means3D=t['mean_3d'], means2D=torch.zeros(P, 3, device=dev, requires_grad=True), shs=t['sh'],
+                            colors_precomp=None, opacities=t['opacity'], scales=t['scale'], rotations=t['rotation'],
+                            cov3D_precomp=None, raster_settings=st)
+    outs_s = [exa.rasterize_gaussians_batch([kw(ts, st)])[0] for st in sts]
+    sum((o[0] * G).sum() for o, G in zip(outs_s, Gs)).backward()
+    outs_b = exa.rasterize_gaussians_batch([kw(tb, st) for st in sts])
+    sum((o[0] * G).sum() for o, G in zip(outs_b, Gs)).backward()
+    for ob, os_ in zip(outs_b, outs_s):
+        assert torch.equal(ob[0], os_[0]) and torch.equal(ob[1], os_[1])
+    for k in ts:
+        gs, gb = ts[k].grad, tb[k].grad
+        assert float((gb - gs).abs().max()) <= 3e-6 * float(gs.abs().max()), k
+
+
 def test_batch_of_heterogeneous_jobs_and_more_than_eight(dev):
     """Jobs with different Gaussian counts AND different image sizes in one batched call, and more jobs than one launch
     holds (groups of eight): every job equals its single render bit for bit, gradients included."""
