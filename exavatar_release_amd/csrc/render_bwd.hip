@@ -1,4 +1,5 @@
-// Per-batch backward of the alpha compositing for gfx950 -- atomic-free, one wave per 64-entry batch.
+// Per-batch backward of the alpha compositing for gfx950 -- atomic-free, one wave at a time per 64-entry batch,
+// persistent waves that prefetch the next two batches while they compute the current one.
 //
 // Unit of work = a BATCH SLOT: 64 consecutive entries of one sub-tile's sorted list x the 64 pixels of that
 // sub-tile.  The forward pass checkpoints the per-pixel state (T, C_rgb, depth; stopped pixels as -T) at the
@@ -63,6 +64,21 @@ __device__ __forceinline__ int mask_rank(uint32_t lo, uint32_t hi) {          //
     return (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
 }
 
+// What a wave needs to know about a batch slot before it can fetch the batch (round trip 1) ...
+struct BwdHdr {
+    uint32_t st1, begin, n;          // owner record: sub-tile + 1 (0 = unused / end slot), list begin, list length
+    uint32_t bm_lo, bm_hi;           // blended mask
+    uint32_t id;                     // this lane's sorted id (garbage past the end of the list; only flagged lanes use theirs)
+};
+// ... and the batch itself (round trip 2): this lane's splat record, partial slot, the per-pixel state at the start of the
+// batch and at the forward's exit, the incoming pixel gradient.
+struct BwdPay {
+    float4 r0, r1, r2;
+    uint32_t pslot;
+    float cs0, cs1, cs2, cs3, cs4, cf0, cf1, cf2, cf3, cf4;
+    float gr, gg, gb, gd, ga;
+};
+
 template <bool HAS_DEPTH, int GC>
 __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
     constexpr int XROW = XLayout<GC>::ROW, XGROUP = XLayout<GC>::GROUP;
@@ -74,87 +90,113 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     __shared__ __attribute__((aligned(16))) float s_x[XLayout<GC>::FLOATS];   // {aG, w}[pixel group][splat][pixel of the group]
 
     const RenderBwdArgs& a = batch.v[blockIdx.y];
-    const uint32_t slot = blockIdx.x;
-    if ((uint64_t)slot >= a.capacity / BATCH) return;           // a job with a smaller instance space than the largest
+    const uint32_t nslots = (uint32_t)(a.capacity / BATCH), stride = gridDim.x;
     const int lane = threadIdx.x;
-    // Round trip 1: the owner record, the batch's blended mask and -- speculatively, the instance space being
-    // 64-aligned per sub-tile -- this slot's 64 sorted ids (garbage past the end of the list; only flagged lanes use theirs).
-    const uint4 own = a.bw.owner[slot];
-    const unsigned long long bm_v = a.bw.bmask[slot];
-    const uint32_t id_raw = a.bw.sorted[(size_t)slot * BATCH + lane];
-    const uint32_t bm_lo = __builtin_amdgcn_readfirstlane((uint32_t)bm_v);
-    const uint32_t bm_hi = __builtin_amdgcn_readfirstlane((uint32_t)(bm_v >> 32));
-    if (own.x == 0 || (bm_lo | bm_hi) == 0u) return;            // unused / end slot, or nothing of this batch was blended
-    const int st = (int)own.x - 1;
-    const int n = (int)own.z;
-    const int b0 = (int)(own.y / BATCH);                        // first slot of the sub-tile
+    const float* __restrict__ bg = a.bg;
+    float4* __restrict__ prec = a.partials.rec;
+    uint8_t* __restrict__ touched = a.bw.touched;
+
+    // PERSISTENT waves with a two-deep prefetch: a wave walks the slots blockIdx.x, + gridDim.x, ...; while it computes
+    // batch i the records / checkpoints / gradients of batch i + 1 and the owner / mask / ids of batch i + 2 are in flight.
+    // (One wave per slot, as before, exposed two dependent memory round trips -- ~3 us -- per ~2 us of arithmetic, and half
+    // of the ~24 k slots of a C3 view are empty: end slots, batches behind the forward's exit, slack of the 64-aligned space.)
+    auto load_hdr = [&](uint32_t slot) -> BwdHdr {
+        BwdHdr h = {0u, 0u, 0u, 0u, 0u, 0u};
+        if (slot < nslots) {
+            const uint4 own = a.bw.owner[slot];
+            const unsigned long long bm = a.bw.bmask[slot];
+            h.id = a.bw.sorted[(size_t)slot * BATCH + lane];
+            h.st1 = own.x; h.begin = own.y; h.n = own.z;
+            h.bm_lo = (uint32_t)bm; h.bm_hi = (uint32_t)(bm >> 32);
+        }
+        return h;
+    };
+    auto is_active = [&](const BwdHdr& h) -> bool {              // wave-uniform
+        return __builtin_amdgcn_readfirstlane(h.st1) != 0u &&
+               (__builtin_amdgcn_readfirstlane(h.bm_lo) | __builtin_amdgcn_readfirstlane(h.bm_hi)) != 0u;
+    };
+    auto load_pay = [&](const BwdHdr& h, uint32_t slot) -> BwdPay {
+        BwdPay p;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        p.r0 = zero4; p.r1 = zero4; p.r2 = zero4; p.pslot = 0u;
+        p.cs0 = 1.0f; p.cs1 = p.cs2 = p.cs3 = p.cs4 = 0.f;
+        p.cf0 = p.cf1 = p.cf2 = p.cf3 = p.cf4 = 0.f;
+        p.gr = p.gg = p.gb = p.gd = p.ga = 0.f;
+        if (!is_active(h)) return p;
+        const uint32_t bm_lo = __builtin_amdgcn_readfirstlane(h.bm_lo), bm_hi = __builtin_amdgcn_readfirstlane(h.bm_hi);
+        const int st = (int)__builtin_amdgcn_readfirstlane(h.st1) - 1;
+        const int n = (int)__builtin_amdgcn_readfirstlane(h.n);
+        const int b0 = (int)(__builtin_amdgcn_readfirstlane(h.begin) / BATCH);
+        const SubTile sub = decode_subtile(st, a.grid);
+        const bool flagged = (((lane < 32 ? bm_lo : bm_hi) >> (lane & 31)) & 1u) != 0u;
+        if (flagged) {
+            const float4* rec = reinterpret_cast<const float4*>(a.splats + min(h.id, (uint32_t)(a.P - 1)));
+            p.r0 = rec[0]; p.r1 = rec[1]; p.r2 = rec[2];
+            const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
+            const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
+            p.pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
+        }
+        // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
+        const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;
+        const float* cs = a.bw.ckpt + (size_t)slot * (5 * 64) + lane;
+        if ((int)slot > b0) { p.cs0 = cs[0]; p.cs1 = cs[64]; p.cs2 = cs[128]; p.cs3 = cs[192]; p.cs4 = HAS_DEPTH ? cs[256] : 0.f; }
+        p.cf0 = cf[0]; p.cf1 = cf[64]; p.cf2 = cf[128]; p.cf3 = cf[192]; p.cf4 = HAS_DEPTH ? cf[256] : 0.f;
+        const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
+        if (pxi < a.grid.W && pyi < a.grid.H) {
+            const size_t HW = (size_t)a.grid.W * a.grid.H;
+            const size_t pix = (size_t)pyi * a.grid.W + pxi;
+            p.gr = a.dL_dcolor[pix];
+            p.gg = a.dL_dcolor[HW + pix];
+            p.gb = a.dL_dcolor[2 * HW + pix];
+            if (HAS_DEPTH && a.dL_ddepth) p.gd = a.dL_ddepth[pix];
+            if (a.dL_dalpha) p.ga = a.dL_dalpha[pix];
+        }
+        return p;
+    };
+
+    uint32_t slot = blockIdx.x;
+    BwdHdr h0 = load_hdr(slot), h1 = load_hdr(slot + stride);
+    BwdPay p0 = load_pay(h0, slot);
+    for (; slot < nslots; slot += stride) {
+    const BwdHdr h2 = load_hdr(slot + 2 * stride);
+    const BwdPay p1 = load_pay(h1, slot + stride);
+    if (is_active(h0)) {
+    // ================================= one batch =================================================================
+    const uint32_t bm_lo = __builtin_amdgcn_readfirstlane(h0.bm_lo), bm_hi = __builtin_amdgcn_readfirstlane(h0.bm_hi);
+    const int st = (int)__builtin_amdgcn_readfirstlane(h0.st1) - 1;
+    const int b0 = (int)(__builtin_amdgcn_readfirstlane(h0.begin) / BATCH);   // first slot of the sub-tile
     const int bq = (int)slot - b0;                              // batch index inside the sub-tile
     const int cnt = __popc(bm_lo) + __popc(bm_hi);              // blended entries of this batch
     const bool flagged = (((lane < 32 ? bm_lo : bm_hi) >> (lane & 31)) & 1u) != 0u;
     const int below = mask_rank(bm_lo, bm_hi);
     const int dst = flagged ? below : cnt + (lane - below);     // a permutation of 0..63: blended entries first, in order
-
-    // Round trip 2: everything else (records, checkpoints, pixel gradients) is issued together.
     const SubTile sub = decode_subtile(st, a.grid);
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 r0 = zero4, r1 = zero4, r2 = zero4;
-    uint4 r3 = make_uint4(0u, 0u, 0u, 0u);
-    if (flagged) {
-        const float4* rec = reinterpret_cast<const float4*>(a.splats + min(id_raw, (uint32_t)(a.P - 1)));
-        r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-        r3 = reinterpret_cast<const uint4*>(rec)[3];
-    }
-    // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
-    const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;
-    const float* cs = a.bw.ckpt + (size_t)slot * (5 * 64) + lane;
-    float cs0 = 1.0f, cs1 = 0.f, cs2 = 0.f, cs3 = 0.f, cs4 = 0.f;
-    if (bq > 0) { cs0 = cs[0]; cs1 = cs[64]; cs2 = cs[128]; cs3 = cs[192]; cs4 = HAS_DEPTH ? cs[256] : 0.f; }
-    const float cf0 = cf[0], cf1 = cf[64], cf2 = cf[128], cf3 = cf[192], cf4 = HAS_DEPTH ? cf[256] : 0.f;
-
-    // ---- per-pixel set-up --------------------------------------------------------------------------
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
     const bool inside = pxi < a.grid.W && pyi < a.grid.H;
     const float fx = (float)pxi, fy = (float)pyi;
-    float gr = 0.f, gg = 0.f, gb = 0.f, gd = 0.f, ga = 0.f;
-    if (inside) {
-        const size_t HW = (size_t)a.grid.W * a.grid.H;
-        const size_t pix = (size_t)pyi * a.grid.W + pxi;
-        gr = a.dL_dcolor[pix];
-        gg = a.dL_dcolor[HW + pix];
-        gb = a.dL_dcolor[2 * HW + pix];
-        if (HAS_DEPTH && a.dL_ddepth) gd = a.dL_ddepth[pix];
-        if (a.dL_dalpha) ga = a.dL_dalpha[pix];
-    }
+    const float gr = p0.gr, gg = p0.gg, gb = p0.gb, gd = p0.gd, ga = p0.ga;
 
-    uint32_t pslot = 0;
-    if (flagged) {
-        const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
-        pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
-    }
-    stage_splat(s_b, dst, r0, r1, r2);                          // unflagged lanes stage all-zero records (alpha 0) behind the list
-    s_pslot[dst] = pslot;
+    stage_splat(s_b, dst, p0.r0, p0.r1, p0.r2);                 // unflagged lanes stage all-zero records (alpha 0) behind the list
+    s_pslot[dst] = p0.pslot;
     s_pg[(lane >> 4) * 17 + (lane & 15)] = make_float4(gr, gg, gb, gd);
 
     float T = 1.0f, live = inside ? 1.0f : 0.0f;
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
     if (bq > 0) {
-        T = fabsf(cs0);
-        live = cs0 > 0.0f ? 1.0f : 0.0f;
-        sr = cs1; sg = cs2; sb = cs3; sd = cs4;
+        T = fabsf(p0.cs0);
+        live = p0.cs0 > 0.0f ? 1.0f : 0.0f;
+        sr = p0.cs1; sg = p0.cs2; sb = p0.cs3; sd = p0.cs4;
     }
-    const float T_final = cf0;
-    const float* __restrict__ bg = a.bg;
+    const float T_final = p0.cf0;
     // d/d(alpha_i) of [T_final * bg . g] and of [ga * (1 - T_final)]:  (T_final / (1 - alpha_i)) * (ga - bg.g)
     const float tail = T_final * (ga - (bg[0] * gr + bg[1] * gg + bg[2] * gb));
-    float R = (cf1 - sr) * gr + (cf2 - sg) * gg + (cf3 - sb) * gb - tail;
-    if (HAS_DEPTH) R = fmaf(cf4 - sd, gd, R);
+    float R = (p0.cf1 - sr) * gr + (p0.cf2 - sg) * gg + (p0.cf3 - sb) * gb - tail;
+    if (HAS_DEPTH) R = fmaf(p0.cf4 - sd, gd, R);
     wave_lds_fence();
 
     const int g = lane % GC, h = lane / GC;                     // phase B role: splat g of the chunk, pixel group h
     float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane / GC) * XGROUP + 2 * (lane % GC));    // phase A: my column
     const float4* const xr_row = reinterpret_cast<const float4*>(s_x + h * XGROUP + g * XROW);          // phase B: my row
-    float4* __restrict__ prec = a.partials.rec;
-    uint8_t* __restrict__ touched = a.bw.touched;
 
     for (int c0 = 0; c0 < cnt; c0 += GC) {
         if (__all(live == 0.0f)) break;                         // (only after a 1e-7-probability stop flip, see header)
@@ -242,8 +284,12 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
                 touched[ps] = (uint8_t)1;
             }
         }
-        wave_lds_fence();                                       // the next chunk overwrites s_x
+        wave_lds_fence();                                       // the next chunk / batch overwrites the LDS buffers
     }
+    // =============================================================================================================
+    }   // active batch
+    h0 = h1; h1 = h2; p0 = p1;
+    }   // slots of this wave
 }
 
 hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
@@ -255,7 +301,9 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
     }
     if (slots == 0) return hipSuccess;
     static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();   // developer knob
-    const dim3 grid((unsigned)slots, K);
+    // persistent waves: what fits the chip at once (12 one-wave workgroups per CU by LDS), each strides over its job's slots
+    static const uint64_t RESIDENT = [] { const char* e = getenv("EXA_BWD_WAVES_PER_CU"); return (uint64_t)(e ? atoi(e) : 12) * 256; }();
+    const dim3 grid((unsigned)(slots < RESIDENT ? slots : RESIDENT), K);
     if (gc == 8) {
         if (depth) render_bwd_kernel<true, 8><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
         else render_bwd_kernel<false, 8><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
