@@ -1,5 +1,4 @@
-// Per-batch backward of the alpha compositing for gfx950 -- atomic-free, one wave at a time per 64-entry batch,
-// persistent waves that prefetch the next two batches while they compute the current one.
+// Per-batch backward of the alpha compositing for gfx950 -- atomic-free, one wave per 64-entry batch slot.
 //
 // Unit of work = a BATCH SLOT: 64 consecutive entries of one sub-tile's sorted list x the 64 pixels of that
 // sub-tile.  The forward pass checkpoints the per-pixel state (T, C_rgb, depth; stopped pixels as -T) at the
@@ -79,7 +78,7 @@ struct BwdPay {
     float gr, gg, gb, gd, ga;
 };
 
-template <bool HAS_DEPTH, int GC>
+template <bool HAS_DEPTH, int GC, int SPW>
 __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
     constexpr int XROW = XLayout<GC>::ROW, XGROUP = XLayout<GC>::GROUP;
     __shared__ BatchLds s_b;
@@ -90,16 +89,12 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     __shared__ __attribute__((aligned(16))) float s_x[XLayout<GC>::FLOATS];   // {aG, w}[pixel group][splat][pixel of the group]
 
     const RenderBwdArgs& a = batch.v[blockIdx.y];
-    const uint32_t nslots = (uint32_t)(a.capacity / BATCH), stride = gridDim.x;
+    const uint32_t nslots = (uint32_t)(a.capacity / BATCH);
     const int lane = threadIdx.x;
     const float* __restrict__ bg = a.bg;
     float4* __restrict__ prec = a.partials.rec;
     uint8_t* __restrict__ touched = a.bw.touched;
 
-    // PERSISTENT waves with a two-deep prefetch: a wave walks the slots blockIdx.x, + gridDim.x, ...; while it computes
-    // batch i the records / checkpoints / gradients of batch i + 1 and the owner / mask / ids of batch i + 2 are in flight.
-    // (One wave per slot, as before, exposed two dependent memory round trips -- ~3 us -- per ~2 us of arithmetic, and half
-    // of the ~24 k slots of a C3 view are empty: end slots, batches behind the forward's exit, slack of the 64-aligned space.)
     auto load_hdr = [&](uint32_t slot) -> BwdHdr {
         BwdHdr h = {0u, 0u, 0u, 0u, 0u, 0u};
         if (slot < nslots) {
@@ -154,12 +149,22 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         return p;
     };
 
-    uint32_t slot = blockIdx.x;
-    BwdHdr h0 = load_hdr(slot), h1 = load_hdr(slot + stride);
-    BwdPay p0 = load_pay(h0, slot);
-    for (; slot < nslots; slot += stride) {
-    const BwdHdr h2 = load_hdr(slot + 2 * stride);
-    const BwdPay p1 = load_pay(h1, slot + stride);
+    // SPW consecutive batch slots per wave (default 1): the headers of all of them are fetched in one round trip, their
+    // payloads in a second one, then the batches are computed one after the other.  Measured on C3: SPW 1 / 2 / 4 =
+    // 55.6 / 64.0 / 70.7 us, and persistent waves striding over the slots with a two-deep prefetch 81 us -- the batches'
+    // costs differ by an order of magnitude (1..64 blended entries), so anything that takes work distribution away from
+    // the hardware's wave dispatcher loses more to imbalance than it gains from hidden latency.
+    BwdHdr hh[SPW];
+    BwdPay pp[SPW];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) hh[i] = load_hdr(blockIdx.x * SPW + i);
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) pp[i] = load_pay(hh[i], blockIdx.x * SPW + i);
+#pragma unroll
+    for (int rep = 0; rep < SPW; ++rep) {
+    const BwdHdr& h0 = hh[rep];
+    const BwdPay& p0 = pp[rep];
+    const uint32_t slot = blockIdx.x * SPW + rep;
     if (is_active(h0)) {
     // ================================= one batch =================================================================
     const uint32_t bm_lo = __builtin_amdgcn_readfirstlane(h0.bm_lo), bm_hi = __builtin_amdgcn_readfirstlane(h0.bm_hi);
@@ -288,7 +293,6 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     }
     // =============================================================================================================
     }   // active batch
-    h0 = h1; h1 = h2; p0 = p1;
     }   // slots of this wave
 }
 
@@ -300,17 +304,18 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
         depth = depth || a[k].dL_ddepth != nullptr;
     }
     if (slots == 0) return hipSuccess;
-    static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();   // developer knob
-    // persistent waves: what fits the chip at once (12 one-wave workgroups per CU by LDS), each strides over its job's slots
-    static const uint64_t RESIDENT = [] { const char* e = getenv("EXA_BWD_WAVES_PER_CU"); return (uint64_t)(e ? atoi(e) : 12) * 256; }();
-    const dim3 grid((unsigned)(slots < RESIDENT ? slots : RESIDENT), K);
+    static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();     // developer knobs
+    static const int spw = [] { const char* e = getenv("EXA_BWD_SPW"); return e ? atoi(e) : 1; }();
+    const Batch<RenderBwdArgs> b = make_batch(a, K);
+#define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, 0, s>>>(b)
     if (gc == 8) {
-        if (depth) render_bwd_kernel<true, 8><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
-        else render_bwd_kernel<false, 8><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
+        if (depth) EXA_LAUNCH_BWD(true, 8, 1); else EXA_LAUNCH_BWD(false, 8, 1);
+    } else if (spw == 2) {
+        if (depth) EXA_LAUNCH_BWD(true, 16, 2); else EXA_LAUNCH_BWD(false, 16, 2);
     } else {
-        if (depth) render_bwd_kernel<true, 16><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
-        else render_bwd_kernel<false, 16><<<grid, RBLOCK, 0, s>>>(make_batch(a, K));
+        if (depth) EXA_LAUNCH_BWD(true, 16, 1); else EXA_LAUNCH_BWD(false, 16, 1);
     }
+#undef EXA_LAUNCH_BWD
     return hipGetLastError();
 }
 
