@@ -27,7 +27,7 @@ with torch.no_grad():
     ex = torch.sqrt(tau2*a2)*1.001+0.01
     ey = torch.sqrt(tau2*c2)*1.001+0.01
     bx0 = torch.floor(px-ex); bx1 = torch.ceil(px+ex); by0=torch.floor(py-ey); by1=torch.ceil(py+ey)
-    tot = dict(inst=0, entered=0, exact=0, box_batch=0, box_c16=0, box_g4=0, fp_c16=0, fp_batch=0, nb_ent=0)
+    tot = dict(fp_any=0, inst=0, entered=0, exact=0, box_batch=0, box_c16=0, box_g4=0, fp_c16=0, fp_batch=0, nb_ent=0)
     hist = torch.zeros(65, dtype=torch.long)
     for t in range(gx*gy):
         s0,e0 = ranges[t].tolist()
@@ -60,6 +60,7 @@ with torch.no_grad():
                     if not alive_any[b*64]: break
                     ent+=1
                 m = min(n, ent*64)
+                tot['fp_any']+=int(valid.any(1).sum())
                 tot['inst']+=n; tot['entered']+=m; tot['exact']+=int(anyt[:m].sum()); tot['nb_ent']+=ent
                 inbox = (X[None,:] >= bx0[l][:,None]) & (X[None,:] <= bx1[l][:,None]) & (Y[None,:] >= by0[l][:,None]) & (Y[None,:] <= by1[l][:,None])
                 idx = torch.arange(m)
