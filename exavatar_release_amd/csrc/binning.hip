@@ -14,6 +14,7 @@
 // rasterizer behind reference avatar/common/nets/module.py:632-640.
 // HBM traffic: reads 16 B of every visible splat record twice, writes 16 B per cell entry and 8 B per
 // instance, 4 B inst_off per Gaussian; scans are O(chunks x cells).
+#include <stdlib.h>
 #include "common.h"
 
 namespace exa {
@@ -207,34 +208,43 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
 // Exact footprint test.  The sub-tile rect of a splat (preprocess_fwd.hip) is the bounding box of {alpha >= 1/255}; an
 // ellipse leaves the corners of its box empty, and for avatar-sized splats (a box of 2x3 sub-tiles) that is 20 % of all
 // (splat, sub-tile) instances (C3 view 0: 893 k -> 709 k).  A sub-tile whose 8x8 pixel centres all fail the per-pixel
-// alpha test contributes nothing to the image or to any gradient, so it never enters a list.  The test maximises the
-// (concave) log2-falloff  f(d) = A dx^2 + B dx dy + C dy^2  over the rectangle of pixel centres: the maximiser is the
-// splat centre if it lies inside, else it sits on one of the (at most two) edges facing the centre, where f is a
-// 1-D parabola.  Conservative: a margin of 1e-3 + 1e-5 * (a bound of the term magnitudes) in the log2 domain covers the
-// rounding of the per-pixel evaluation (blend.h) and of the fast reciprocals here; any NaN keeps the sub-tile.
-struct Footprint { float px, py, A, B, C, kA, kC, thr; bool test; };
+// alpha test contributes nothing to the image or to any gradient, so it never enters a list.
+// Per ROW of sub-tiles (a band of 8 pixel rows, dy in [yl, yh] relative to the splat centre) the part of the ellipse
+//   f(d) = A dx^2 + B dx dy + C dy^2 >= thr      (log2 domain, conic pre-scaled as in blend.h; A, C < 0, thr < 0)
+// inside the band is convex, so the sub-tiles it reaches are exactly those whose pixel-centre range [xl, xl + 7] meets its
+// x-extent [xa, xb].  On the line dy = y0 the ellipse spans  kA y0 -+ sqrt(X2 - D4 y0^2)  (kA = -B / 2A, X2 = thr / A,
+// D4 = (4AC - B^2) / 4A^2); its rightmost (leftmost) point overall lies at dy = +ysr (-ysr), ysr = kC Xf with kC = -B / 2C and
+// Xf the half extent in x; the right (left) end of the band's part is the line point at y0 = clamp(+ysr (-ysr), yl, yh).
+// O(1) per row instead of a test per sub-tile -- a large scene splat crosses up to 64 sub-tiles of a cell.
+// Conservative: thr is relaxed by 1e-3 + 1e-5 * (a bound of the term magnitudes) to cover the rounding of the per-pixel
+// evaluation, the interval by 1e-3 (1 + |x|) px for the arithmetic here (tools/footprint_check.py compares this
+// arithmetic with the per-pixel rule by brute force); NaN / degenerate conics keep the whole rect.
+struct Footprint { float kA, ysr, X2, D4; bool test; };
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
-// xm, ym: the largest |pixel - centre| the caller is going to ask about (bounds the rounding margin once per splat)
-__device__ __forceinline__ Footprint make_footprint(const uint4& r0, const uint4& r1, float xm, float ym) {
+// xm, ym: the largest |pixel - centre| inside the part of the rect the caller is going to ask about
+__device__ __forceinline__ Footprint make_footprint(const uint4& r1, float xm, float ym) {
     Footprint f;
-    f.px = __uint_as_float(r0.x); f.py = __uint_as_float(r0.y);
-    f.A = __uint_as_float(r1.x); f.B = __uint_as_float(r1.y); f.C = __uint_as_float(r1.z);
-    f.test = f.A < 0.f && f.C < 0.f;                            // anything else (never for a visible splat): keep the rect
-    f.kA = -0.5f * f.B * __builtin_amdgcn_rcpf(f.A);            // argmax over dx of f(dx, dy) is kA * dy
-    f.kC = -0.5f * f.B * __builtin_amdgcn_rcpf(f.C);            // argmax over dy of f(dx, dy) is kC * dx
-    const float mag = fabsf(f.A) * xm * xm + fabsf(f.B) * xm * ym + fabsf(f.C) * ym * ym;
-    f.thr = -__log2f(255.0f * __uint_as_float(r1.w)) - 1e-3f - 1e-5f * mag;   // alpha >= 1/255  <=>  f >= -log2(255 o)
+    const float A = __uint_as_float(r1.x), B = __uint_as_float(r1.y), C = __uint_as_float(r1.z);
+    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+    const float As = A - 0.25f * B * B * rC;                    // f along the line of the x-extreme points: As dx^2
+    f.test = A < 0.f && C < 0.f && As < 0.f;                    // anything else (never for a visible splat): keep the rect
+    const float mag = fabsf(A) * xm * xm + fabsf(B) * xm * ym + fabsf(C) * ym * ym;
+    const float thr = -__log2f(255.0f * __uint_as_float(r1.w)) - 1e-3f - 1e-5f * mag;   // alpha >= 1/255 <=> f >= -log2(255 o)
+    f.kA = -0.5f * B * rA;
+    f.ysr = -0.5f * B * rC * __builtin_amdgcn_sqrtf(thr * __builtin_amdgcn_rcpf(As));
+    f.X2 = thr * rA;
+    f.D4 = C * As * rA * rA;
     return f;
 }
-// row part / full test for the sub-tile whose first pixel centre is (xl, yl) relative to the splat centre
-__device__ __forceinline__ bool footprint_reaches(const Footprint& f, float xl, float yl) {
-    const float xh = xl + (float)(SUB - 1), yh = yl + (float)(SUB - 1);
-    const float ex = clampf(0.f, xl, xh), ey = clampf(0.f, yl, yh);                 // point of the rect nearest the centre
-    const float dy1 = clampf(ex * f.kC, yl, yh);                // best point on the line dx = ex
-    const float dx2 = clampf(ey * f.kA, xl, xh);                // best point on the line dy = ey
-    const float f1 = f.A * ex * ex + dy1 * (f.B * ex + f.C * dy1);
-    const float f2 = f.C * ey * ey + dx2 * (f.B * ey + f.A * dx2);
-    return !(fmaxf(f1, f2) < f.thr);
+// x-extent of the footprint inside the band [yl, yl + 7]; false: the band misses it
+__device__ __forceinline__ bool footprint_row(const Footprint& f, float yl, float& xa, float& xb) {
+    const float yh = yl + (float)(SUB - 1);
+    const float yR = clampf(f.ysr, yl, yh), yL = clampf(-f.ysr, yl, yh);
+    const float hR2 = f.X2 - f.D4 * yR * yR, hL2 = f.X2 - f.D4 * yL * yL;
+    if (hR2 < 0.f || hL2 < 0.f) return false;
+    xb = f.kA * yR + __builtin_amdgcn_sqrtf(hR2);
+    xa = f.kA * yL - __builtin_amdgcn_sqrtf(hL2);
+    return true;
 }
 
 // CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
@@ -414,6 +424,7 @@ __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity
     return c;
 }
 
+template <bool FOOTPRINT>
 __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArgs> batch) {
     __shared__ uint32_t s_cnt[SUBS_PER_CELL];
     const BinArgs& a = batch.v[blockIdx.y];
@@ -430,21 +441,34 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
         const uint4 en = b.bucket[e];
         const uint4* rec = reinterpret_cast<const uint4*>(a.splats + en.x);
-        const uint4 r0 = rec[0], r1 = rec[1];
+        uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;          // (A = 0: no test, the whole rect)
+        if (FOOTPRINT) { r0 = rec[0]; r1 = rec[1]; }
         const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
         const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
         const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
-        const Footprint fp = make_footprint(r0, r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
+        const Footprint fp = make_footprint(r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
                                             fmaxf(fabsf(yl0), fabsf(yl0 + (float)((y1 - y0) * SUB))));
         // the sub-tiles of this cell the footprint really reaches, as a 64-bit mask (bit = y * 8 + x); it replaces the
         // rect in the entry, subtile_bin_kernel walks the same bits
         unsigned long long mask = 0ull;
-        for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x)
-                if (!fp.test || footprint_reaches(fp, xl0 + (float)((x - x0) * SUB), yl0 + (float)((y - y0) * SUB))) {
-                    mask |= 1ull << (y * CELL_SUBS + x);
-                    __hip_atomic_fetch_add(&s_cnt[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int y = y0; y < y1; ++y) {
+            int c0 = x0, c1 = x1 - 1;
+            if (fp.test) {
+                float xa, xb;
+                if (!footprint_row(fp, yl0 + (float)((y - y0) * SUB), xa, xb)) continue;
+                if (xa <= xb) {                                 // (NaN: keep the row)
+                    const float m = 1e-3f * (1.0f + fmaxf(fabsf(xa), fabsf(xb)));
+                    const float lo = clampf((xa - m - (float)(SUB - 1) - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
+                    const float hi = clampf((xb + m - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
+                    c0 = max(x0, x0 + (int)ceilf(lo));
+                    c1 = min(x1 - 1, x0 + (int)floorf(hi));
                 }
+            }
+            if (c1 < c0) continue;
+            mask |= (unsigned long long)((2u << c1) - (1u << c0)) << (y * CELL_SUBS);
+            for (int x = c0; x <= c1; ++x)
+                __hip_atomic_fetch_add(&s_cnt[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
     }
     __syncthreads();
@@ -529,7 +553,9 @@ hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
     int cells = 0;
     for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
     if (cells == 0) return hipSuccess;
-    subtile_count_kernel<<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    static const bool footprint = [] { const char* e = getenv("EXA_FOOTPRINT"); return !e || atoi(e) != 0; }();   // developer knob
+    if (footprint) subtile_count_kernel<true><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    else subtile_count_kernel<false><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
     subtile_bin_kernel<<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
     return hipGetLastError();
 }

@@ -7,7 +7,7 @@ cd $R
 timeout 300 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.log
 tail -2 $O/smoke.log
 if [ "$2" != "notest" ]; then
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/summary.log
+timeout 420 python -m pytest tests -m gpu -q --timeout 150 > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $O/summary.log
 grep -E "^E  |FAILED|passed|failed" $O/pytest.log | head -40
 fi
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?" | tee -a $O/summary.log
