@@ -45,7 +45,28 @@ __device__ __forceinline__ int floor_div8(int v) { return v >= 0 ? (v >> 3) : -(
 
 // One Gaussian: oracle steps 1-7 + splat record.  Returns the number of sub-tile instances and the
 // sub-tile rect through sxy (sx0, sx1, sy0, sy1; upper bounds exclusive).
-__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int idx, int sxy[4], bool& visible) {
+struct ShColour { float r, g, b; uint32_t flags; };           // SH colour evaluated from the LDS-staged coefficients
+
+// Colour of one Gaussian from its SH coefficients (reference module.py:258-266 semantics): direction from the camera
+// centre, + 0.5, clamped at 0 with the clamp recorded per channel for the backward.
+__device__ __forceinline__ ShColour sh_colour(const PreprocessArgs& a, const float* sh, float x, float y, float z) {
+    const float* cp = a.campos;
+    float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
+    const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    ShColour c;
+    c.flags = 0u;
+    c.r = sh_channel(a.sh_degree, sh, 0, dx, dy, dz) + 0.5f;
+    c.g = sh_channel(a.sh_degree, sh, 1, dx, dy, dz) + 0.5f;
+    c.b = sh_channel(a.sh_degree, sh, 2, dx, dy, dz) + 0.5f;
+    if (c.r < 0.f) { c.r = 0.f; c.flags |= 1u; }
+    if (c.g < 0.f) { c.g = 0.f; c.flags |= 2u; }
+    if (c.b < 0.f) { c.b = 0.f; c.flags |= 4u; }
+    return c;
+}
+
+__device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int idx, int sxy[4], bool& visible,
+                                                   const ShColour& shc) {
     const float* __restrict__ v = a.viewmatrix;
     const float* __restrict__ p = a.projmatrix;
     const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
@@ -165,17 +186,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
     float cr, cg, cbl;
     uint32_t flags = 0;
     if (a.shs) {
-        const float* cp = a.campos;
-        float dx = x - cp[0], dy = y - cp[1], dz = z - cp[2];
-        const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
-        dx *= inv; dy *= inv; dz *= inv;
-        const float* sh = a.shs + (size_t)idx * a.sh_M * 3;
-        cr = sh_channel(a.sh_degree, sh, 0, dx, dy, dz) + 0.5f;
-        cg = sh_channel(a.sh_degree, sh, 1, dx, dy, dz) + 0.5f;
-        cbl = sh_channel(a.sh_degree, sh, 2, dx, dy, dz) + 0.5f;
-        if (cr < 0.f) { cr = 0.f; flags |= 1u; }
-        if (cg < 0.f) { cg = 0.f; flags |= 2u; }
-        if (cbl < 0.f) { cbl = 0.f; flags |= 4u; }
+        cr = shc.r; cg = shc.g; cbl = shc.b; flags = shc.flags;
     } else {
         cr = in_c0;
         cg = in_c1;
@@ -216,9 +227,53 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
 // (chunk, cell) count matrix -- no global atomics at all: device-scope atomics run at only ~12 G/s chip-wide on
 // MI355X and ~150 chunks adding into the same few dozen cell counters serialise at the memory side
 // (that tail was ~8 us of this kernel).  cell_scan_kernel sums the columns.
-constexpr int PBLOCK = 1024;           // threads per chunk: one Gaussian each (no atomics left to contend on)
+constexpr int PBLOCK_PLAIN = 1024;     // threads per chunk: one Gaussian each (no atomics left to contend on)
+constexpr int PBLOCK_SH = 256;         // SH variant: four Gaussians per thread, one after the other; all four waves stage at once
+// SH coefficients ([P][M][3] floats, up to 192 B per Gaussian) are staged through LDS: a lane reading its own 48 floats
+// straight from global memory touches 64 different cache lines per load instruction, 16 waves of that thrash the L1 and
+// every dword load goes to L2 (C5, 300 k Gaussians at degree 3: 65 us for 75 MB).  Instead each wave reads the
+// CONTIGUOUS block of its 64 Gaussians with coalesced dword loads (all issued up front, held in registers), and
+// the waves take turns -- four at a time, 4 x 12.25 KiB -- to transpose their block through LDS (row stride F | 1 words:
+// conflict-free both ways) and evaluate the colours.
+constexpr int SH_MAX_F = 48;           // floats per Gaussian at degree 3
+constexpr int SH_WAVES = 4;            // waves staging at a time
+constexpr int SH_LDS_FLOATS = SH_WAVES * 64 * (SH_MAX_F | 1);
+// One wave: the contiguous block of its 64 Gaussians' coefficients (nf floats of it exist), global -> LDS rows of F | 1
+// words.  The whole block is in flight at once (48 KiB per phase and workgroup: enough bytes in flight to stream at HBM
+// rate); full blocks are loaded unconditionally (predicated loads compiled to 48 exec-mask branches), and the scheduling
+// barrier keeps the LDS addresses from being computed -- and held in registers -- while the loads are still out.
+template <int F>
+__device__ __forceinline__ void stage_sh_block(const float* __restrict__ blk, int nf, float* s_sh, int lane) {
+    constexpr int S = F | 1, DQ = 64 / F, DR = 64 % F;
+    int l2 = lane;                                              // opaque copy: the LDS addresses below depend on the lane only,
+    asm volatile("" : "+v"(l2));                                // and hoisted to the kernel's prologue they cost 200 registers
+    int g = l2 / F, j = l2 % F;                                 // float i * 64 + lane is coefficient j of Gaussian g of the block
+    if (nf < 64 * F) {                                          // the array's last, partial block: one float at a time
+#pragma unroll 1
+        for (int i = 0; i < F; ++i) {
+            if (i * 64 + lane < nf) s_sh[g * S + j] = blk[i * 64 + lane];
+            g += DQ; j += DR;
+            if (j >= F) { j -= F; g += 1; }
+        }
+        return;
+    }
+    float v[F];
+#pragma unroll
+    for (int i = 0; i < F; ++i) v[i] = blk[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < F; ++i) {
+        s_sh[g * S + j] = v[i];
+        g += DQ; j += DR;
+        if (j >= F) { j -= F; g += 1; }
+        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // (else all F addresses are computed first: +48 registers)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool SH, int PBLOCK>
 __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<PreprocessArgs> batch) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cell[];   // [cells]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_cell[];   // [cells] (+ SH staging area behind it)
     __shared__ uint32_t s_red[PBLOCK / 64];
     const PreprocessArgs& a = batch.v[blockIdx.y];              // this workgroup's job (kernarg segment: scalar loads)
     if ((int)blockIdx.x >= num_chunks(a.P)) return;             // a job with fewer Gaussians than the largest of the batch
@@ -230,10 +285,37 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
 #pragma unroll 1
     for (int it = 0; it < CHUNK / PBLOCK; ++it) {
         const int idx = blockIdx.x * CHUNK + it * PBLOCK + tid;
+        ShColour shc = {0.f, 0.f, 0.f, 0u};
+        if (SH && a.shs) {                                      // workgroup-uniform
+            const int F = a.sh_M * 3, S = F | 1;                // floats per Gaussian, LDS row stride
+            const int lane = tid & 63, wave = tid >> 6;
+            const int g0 = idx - lane;                          // first Gaussian of this wave
+            const float* blk = a.shs + (size_t)g0 * F;
+            const int nf = min(64, max(0, a.P - g0)) * F;       // floats of the block that exist
+            float mx = 0.f, my = 0.f, mz = 0.f;
+            if (idx < a.P) { mx = a.means3D[idx * 3 + 0]; my = a.means3D[idx * 3 + 1]; mz = a.means3D[idx * 3 + 2]; }
+            float* s_sh = reinterpret_cast<float*>(s_cell + a.grid.cells) + (wave % SH_WAVES) * 64 * (SH_MAX_F | 1);
+#pragma unroll 1
+            for (int ph = 0; ph < PBLOCK / 64 / SH_WAVES; ++ph) {
+                if (wave / SH_WAVES == ph) {
+                    if (nf > 0) {
+                        if (F == 48) stage_sh_block<48>(blk, nf, s_sh, lane);
+                        else if (F == 27) stage_sh_block<27>(blk, nf, s_sh, lane);
+                        else if (F == 12) stage_sh_block<12>(blk, nf, s_sh, lane);
+                        else stage_sh_block<3>(blk, nf, s_sh, lane);
+                    }
+                    wave_lds_fence();
+                    if (idx < a.P) shc = sh_colour(a, s_sh + lane * S, mx, my, mz);
+                }
+                __syncthreads();
+            }
+        }
+        if (!SH && a.shs && idx < a.P)                          // image too large for the staging area: straight from global
+            shc = sh_colour(a, a.shs + (size_t)idx * a.sh_M * 3, a.means3D[idx * 3 + 0], a.means3D[idx * 3 + 1], a.means3D[idx * 3 + 2]);
         if (idx < a.P) {
             int sxy[4];
             bool vis;
-            const uint32_t n = preprocess_one(a, idx, sxy, vis);
+            const uint32_t n = preprocess_one(a, idx, sxy, vis, shc);
             nvis += vis ? 1u : 0u;
             if (n) {
                 inst_sum += n;
@@ -287,7 +369,11 @@ hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s) 
     }
     for (int k = K; k < MAX_BATCH; ++k) b.v[k] = a[0];
     if (chunks == 0) return hipSuccess;
-    preprocess_fwd_kernel<<<dim3(chunks, K), PBLOCK, (size_t)cells * 8, s>>>(b);
+    bool sh = false;
+    for (int k = 0; k < K; ++k) sh = sh || a[k].shs != nullptr;
+    sh = sh && (size_t)cells * 8 + SH_LDS_FLOATS * sizeof(float) <= 64 * 1024;     // default dynamic-LDS limit
+    if (sh) preprocess_fwd_kernel<true, PBLOCK_SH><<<dim3(chunks, K), PBLOCK_SH, (size_t)cells * 8 + SH_LDS_FLOATS * sizeof(float), s>>>(b);
+    else preprocess_fwd_kernel<false, PBLOCK_PLAIN><<<dim3(chunks, K), PBLOCK_PLAIN, (size_t)cells * 8, s>>>(b);
     return hipGetLastError();
 }
 
