@@ -781,3 +781,32 @@ def test_ssim_is_differentiable_in_the_target_too(dev):
     (exa.SSIM()(xg, yg) * G.to(dev)).sum().backward()
     for got, ref in ((xg.grad, xc.grad), (yg.grad, yc.grad)):
         assert float((got.cpu() - ref).abs().max()) <= SSIM_GRAD_TOL * float(ref.abs().max())
+
+
+@pytest.mark.gpu
+def test_footprint_cull_leaves_the_result_alone(tmp_path):
+    """The exact footprint test of the sub-tile binning (csrc/binning.hip) drops (splat, sub-tile) instances whose 64 pixels
+    all fail the per-pixel alpha rule, so it may not change any output beyond the rounding of the transmittance products
+    (the blend multiplies them in groups of four list entries, and shorter lists group differently).  Same scene -- avatar
+    splats plus large anisotropic scene splats -- rendered fwd + bwd by two fresh processes with the test on and off."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ('1', '0'):
+        path = str(tmp_path / ('dump_%s.npz' % flag))
+        r = subprocess.run([sys.executable, os.path.join(root, 'tests', '_render_dump.py'), path], cwd=root,
+                           env=dict(os.environ, EXA_FOOTPRINT=flag), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(path))
+    on, off = outs
+    assert np.array_equal(on['radius'], off['radius'])
+    for k in ('img', 'depth', 'mask'):
+        d = np.abs(on[k] - off[k])
+        # a T < 1e-4 stop may flip where T (1 - alpha) sits within an ulp of the threshold: budget of 2 pixels
+        assert int((d > 2e-6 * max(1.0, float(np.abs(off[k]).max()))).sum()) <= 2 * on[k].shape[0], (k, float(d.max()))
+    for k in on.files:
+        if 'grad' not in k:
+            continue
+        scale = float(np.abs(off[k]).max()) + 1e-30
+        assert float(np.abs(on[k] - off[k]).max()) <= 2e-5 * scale, (k, float(np.abs(on[k] - off[k]).max()), scale)
