@@ -398,6 +398,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
 // LDS, turns the counts into [begin, end) ranges (cell-major sub-tile order) and scatters the sort keys.
 // Entries are 16-byte records read coalesced; no gather from the splat array.
 constexpr int BIN_THREADS = 1024;
+constexpr int SINGLE_PART_CELLS = 1024;   // from this many cells on (2048 x 2048 px) one workgroup per cell
 // An avatar's instances sit in a few dozen cells, and both halves of this digit -- LDS counting atomics and the
 // scattered 8-byte key stores, one per instance -- are throughput limits of ONE CU.  Every cell is therefore
 // handled by BIN_PARTS workgroups in two launches:
@@ -406,75 +407,82 @@ constexpr int BIN_THREADS = 1024;
 //                         its own first slot in every sub-tile) and scatters its quarter of the keys.
 // Plain stores and a kernel boundary instead of any cross-workgroup atomics; part 0 publishes ranges and owners.
 struct CellPart { int cell, part; uint32_t e0, e1, lo, hi, slot0; bool overflow, active; };
-__device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * BIN_PARTS
+template <int PARTS>
+__device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * PARTS
     CellPart c;
     // the header and the cell record are independent loads: one round trip
-    const uint4 d = w.cell_desc[blockIdx.x / BIN_PARTS];
+    const uint4 d = w.cell_desc[blockIdx.x / PARTS];
     const uint32_t active = w.header->active_cells, need = w.header->num_rendered;
     c.cell = (int)d.x;
-    c.part = (int)(blockIdx.x % BIN_PARTS);
-    c.active = blockIdx.x / BIN_PARTS < active;
+    c.part = (int)(blockIdx.x % PARTS);
+    c.active = blockIdx.x / PARTS < active;
     c.overflow = (uint64_t)need > capacity;
     c.e0 = d.y;
     c.e1 = c.overflow ? d.y : d.z;
     c.slot0 = d.w;
-    const uint32_t per = (c.e1 - c.e0 + BIN_PARTS - 1) / BIN_PARTS;
+    const uint32_t per = (c.e1 - c.e0 + PARTS - 1) / PARTS;
     c.lo = min(c.e1, c.e0 + (uint32_t)c.part * per);
     c.hi = min(c.e1, c.lo + per);
     return c;
 }
 
+// The sub-tiles of its cell (origin csx0, csy0 in sub-tiles) that the footprint of entry `en` = {id, depth, rect x, rect y}
+// really reaches, as a 64-bit mask (bit = y * 8 + x).  It replaces the rect in the entry; the scatter walks the same bits.
 template <bool FOOTPRINT>
+__device__ __forceinline__ unsigned long long entry_mask(const Splat* __restrict__ splats, const uint4& en, int csx0, int csy0) {
+    const uint4* rec = reinterpret_cast<const uint4*>(splats + en.x);
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;              // (A = 0: no test, the whole rect)
+    if (FOOTPRINT) { r0 = rec[0]; r1 = rec[1]; }
+    const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
+    const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
+    const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
+    const Footprint fp = make_footprint(r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
+                                        fmaxf(fabsf(yl0), fabsf(yl0 + (float)((y1 - y0) * SUB))));
+    unsigned long long mask = 0ull;
+    for (int y = y0; y < y1; ++y) {
+        int c0 = x0, c1 = x1 - 1;
+        if (fp.test) {
+            float xa, xb;
+            if (!footprint_row(fp, yl0 + (float)((y - y0) * SUB), xa, xb)) continue;
+            if (xa <= xb) {                                     // (NaN: keep the row)
+                const float m = 1e-3f * (1.0f + fmaxf(fabsf(xa), fabsf(xb)));
+                const float lo = clampf((xa - m - (float)(SUB - 1) - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
+                const float hi = clampf((xb + m - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
+                c0 = max(x0, x0 + (int)ceilf(lo));
+                c1 = min(x1 - 1, x0 + (int)floorf(hi));
+            }
+        }
+        if (c1 < c0) continue;
+        mask |= (unsigned long long)((2u << c1) - (1u << c0)) << (y * CELL_SUBS);
+    }
+    return mask;
+}
+
+template <bool FOOTPRINT, int PARTS>
 __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArgs> batch) {
     __shared__ uint32_t s_cnt[SUBS_PER_CELL];
     const BinArgs& a = batch.v[blockIdx.y];
     const TileWs& w = a.tw;
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
-    if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
-    const CellPart cp = cell_part(w, a.capacity);
+    if ((int)blockIdx.x >= g.cells * PARTS) return;
+    const CellPart cp = cell_part<PARTS>(w, a.capacity);
     if (!cp.active) return;                                             // empty cell: nothing to count
     const int tid = threadIdx.x;
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
     const int csx0 = (cp.cell % g.cx) * CELL_SUBS, csy0 = (cp.cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
-        const uint4 en = b.bucket[e];
-        const uint4* rec = reinterpret_cast<const uint4*>(a.splats + en.x);
-        uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;          // (A = 0: no test, the whole rect)
-        if (FOOTPRINT) { r0 = rec[0]; r1 = rec[1]; }
-        const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
-        const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
-        const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
-        const Footprint fp = make_footprint(r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
-                                            fmaxf(fabsf(yl0), fabsf(yl0 + (float)((y1 - y0) * SUB))));
-        // the sub-tiles of this cell the footprint really reaches, as a 64-bit mask (bit = y * 8 + x); it replaces the
-        // rect in the entry, subtile_bin_kernel walks the same bits
-        unsigned long long mask = 0ull;
-        for (int y = y0; y < y1; ++y) {
-            int c0 = x0, c1 = x1 - 1;
-            if (fp.test) {
-                float xa, xb;
-                if (!footprint_row(fp, yl0 + (float)((y - y0) * SUB), xa, xb)) continue;
-                if (xa <= xb) {                                 // (NaN: keep the row)
-                    const float m = 1e-3f * (1.0f + fmaxf(fabsf(xa), fabsf(xb)));
-                    const float lo = clampf((xa - m - (float)(SUB - 1) - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
-                    const float hi = clampf((xb + m - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
-                    c0 = max(x0, x0 + (int)ceilf(lo));
-                    c1 = min(x1 - 1, x0 + (int)floorf(hi));
-                }
-            }
-            if (c1 < c0) continue;
-            mask |= (unsigned long long)((2u << c1) - (1u << c0)) << (y * CELL_SUBS);
-            for (int x = c0; x <= c1; ++x)
-                __hip_atomic_fetch_add(&s_cnt[y * CELL_SUBS + x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        for (unsigned long long m = mask; m; m &= m - 1)
+            __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
     }
     __syncthreads();
-    if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * BIN_PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
+    if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
 }
 
+template <int PARTS>
 __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs> batch) {
     __shared__ uint32_t s_off[SUBS_PER_CELL];
     __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
@@ -482,8 +490,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     const TileWs& w = a.tw;
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
-    if ((int)blockIdx.x >= g.cells * BIN_PARTS) return;
-    const CellPart cp = cell_part(w, a.capacity);
+    if ((int)blockIdx.x >= g.cells * PARTS) return;
+    const CellPart cp = cell_part<PARTS>(w, a.capacity);
     if (!cp.active) {                                                   // empty cell: part 0 publishes 64 empty ranges
         if (cp.part == 0 && threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
         return;
@@ -492,8 +500,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     if (tid < 64) {
         uint32_t n = 0, before = 0;
 #pragma unroll
-        for (int p = 0; p < BIN_PARTS; ++p) {
-            const uint32_t v = w.part_cnt[((size_t)cell * BIN_PARTS + p) * SUBS_PER_CELL + tid];
+        for (int p = 0; p < PARTS; ++p) {
+            const uint32_t v = w.part_cnt[((size_t)cell * PARTS + p) * SUBS_PER_CELL + tid];
             before += p < cp.part ? v : 0u;
             n += v;
         }
@@ -507,6 +515,55 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
             for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
                 b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
         }
+    }
+    __syncthreads();
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
+        const uint4 en = b.bucket[e];
+        const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
+        for (unsigned long long m = ((unsigned long long)en.w << 32) | en.z; m; m &= m - 1) {
+            const int s = __builtin_ctzll(m);
+            const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            b.keys[s_off[s] + r] = key;
+        }
+    }
+}
+
+// One workgroup per cell, both halves in one launch: for images with >= SINGLE_PART_CELLS cells (2048 x 2048 px) there are
+// enough cells to fill the chip without splitting them, and the split only multiplies the fixed costs.
+template <bool FOOTPRINT>
+__global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<BinArgs> batch) {
+    __shared__ uint32_t s_cnt[SUBS_PER_CELL], s_off[SUBS_PER_CELL], s_cnt2[SUBS_PER_CELL];
+    const BinArgs& a = batch.v[blockIdx.y];
+    const TileWs& w = a.tw;
+    const Grid& g = a.grid;
+    const BinWs& b = a.bw;
+    if ((int)blockIdx.x >= g.cells) return;
+    const CellPart cp = cell_part<1>(w, a.capacity);
+    const int cell = cp.cell, tid = threadIdx.x;
+    if (!cp.active) {                                                   // empty cell: 64 empty ranges
+        if (tid < SUBS_PER_CELL) w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(0u, 0u);
+        return;
+    }
+    if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
+    __syncthreads();
+    const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        for (unsigned long long m = mask; m; m &= m - 1)
+            __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));   // read back by this thread
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const uint32_t n = s_cnt[tid];
+        const uint32_t nslot = n ? (n + BATCH - 1) / BATCH + 1 : 0u;       // real batches + one end slot
+        const uint32_t incl = wave_incl_scan(nslot);
+        const uint32_t begin = cp.overflow ? 0u : cp.slot0 + (incl - nslot) * BATCH;
+        s_off[tid] = begin;
+        s_cnt2[tid] = 0u;
+        w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
+        for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
+            b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
     }
     __syncthreads();
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
@@ -554,9 +611,18 @@ hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
     for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
     if (cells == 0) return hipSuccess;
     static const bool footprint = [] { const char* e = getenv("EXA_FOOTPRINT"); return !e || atoi(e) != 0; }();   // developer knob
-    if (footprint) subtile_count_kernel<true><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
-    else subtile_count_kernel<false><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
-    subtile_bin_kernel<<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    // Workgroups per cell: an avatar view fills a few dozen of its 256 cells, so every cell is split over BIN_PARTS
+    // workgroups (two launches) to get the chip busy; a large image (C5: 1024 cells, content everywhere) has enough
+    // cells already and takes one workgroup per cell that counts and scatters in ONE launch.
+    static const int single_cells = [] { const char* e = getenv("EXA_BIN_SINGLE_CELLS"); return e ? atoi(e) : SINGLE_PART_CELLS; }();
+    if (cells >= single_cells) {
+        if (footprint) subtile_count_bin_kernel<true><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
+        else subtile_count_bin_kernel<false><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
+    } else {
+        if (footprint) subtile_count_kernel<true, BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+        else subtile_count_kernel<false, BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+        subtile_bin_kernel<BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    }
     return hipGetLastError();
 }
 
