@@ -494,6 +494,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     const CellPart cp = cell_part<PARTS>(w, a.capacity);
     if (!cp.active) {                                                   // empty cell: part 0 publishes 64 empty ranges
         if (cp.part == 0 && threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+        if (cp.part == 0 && threadIdx.x == 0) w.cell_long[blockIdx.x / PARTS] = 0u;
         return;
     }
     const int cell = cp.cell, tid = threadIdx.x;
@@ -511,6 +512,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         s_off[tid] = begin + before;
         s_cnt2[tid] = 0u;
         if (cp.part == 0) {
+            const unsigned long long longer = __ballot(n > (uint32_t)BATCH);
+            if (tid == 0) w.cell_long[blockIdx.x / PARTS] = (uint32_t)__popcll(longer);
             w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
             for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
                 b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
     const int cell = cp.cell, tid = threadIdx.x;
     if (!cp.active) {                                                   // empty cell: 64 empty ranges
         if (tid < SUBS_PER_CELL) w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(0u, 0u);
+        if (tid == 0) w.cell_long[blockIdx.x] = 0u;
         return;
     }
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
@@ -561,6 +565,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
         const uint32_t begin = cp.overflow ? 0u : cp.slot0 + (incl - nslot) * BATCH;
         s_off[tid] = begin;
         s_cnt2[tid] = 0u;
+        const unsigned long long longer = __ballot(n > (uint32_t)BATCH);
+        if (tid == 0) w.cell_long[blockIdx.x] = (uint32_t)__popcll(longer);
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
         for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
             b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);

@@ -115,6 +115,7 @@ struct TileWs {
     uint4* slots;                     // [subtiles]   launch-order records {begin, end, st, 0}: ONE load gives a
                                       //              per-pixel-kernel workgroup everything it needs
     uint2* fwd_exit;                  // [subtiles]   {list length, batches the forward entered}
+    uint32_t* cell_long;              // [cells]      by rank in cell_desc: number of the cell's lists longer than 64 keys
     uint32_t* part_cnt;               // [cells][BIN_PARTS][64]  entries per sub-tile counted by each part of a cell
 };
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
@@ -122,7 +123,7 @@ __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
            align256(uint64_t(cells + 1) * 8) + 3 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
-           align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4);
+           align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4) + align256(uint64_t(cells) * 4);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -140,7 +141,8 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.slots = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 16);
     w.fwd_exit = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
-    w.part_cnt = reinterpret_cast<uint32_t*>(p);
+    w.part_cnt = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4);
+    w.cell_long = reinterpret_cast<uint32_t*>(p);
     return w;
 }
 

@@ -28,7 +28,8 @@ namespace exa {
 constexpr int RBLOCK = 64;            // threads per workgroup of the per-pixel kernels: ONE wave
 
 constexpr int SORT_TILE = 2048;       // keys of the LDS buffer (16 KiB)
-constexpr int SBLOCK = 256;           // threads of a sort workgroup: four waves co-operate on ONE list
+constexpr int SBLOCK = 256;
+constexpr int SPLIT_SORT_SUBTILES = 65536;   // from this many sub-tiles on the short lists get their own launch           // threads of a sort workgroup: four waves co-operate on ONE list
 
 // ---- sort of lists up to SORT_TILE keys: rank-sorted runs of 64 + rank-based merges, in place in LDS -----
 // A single wave issues roughly one VALU instruction per 5 cycles on gfx950 (probe: tools/probe/cmp_probe.hip),
@@ -350,6 +351,25 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
     }
 }
 
+// Short lists of a LARGE image (>= SPLIT_SORT_SUBTILES sub-tiles, e.g. 2048 x 2048 px): one wave per sub-tile, four
+// independent sub-tiles per workgroup, 512 B of LDS per wave.  With content everywhere (C5: a background scene behind the
+// avatar) most of the 65 536 lists hold a few dozen keys, and one 256-thread workgroup with 24 KiB of LDS per list -- six
+// per CU, three of the four waves idle -- spent 160 us on them; sort_subtiles_kernel<true> then only takes the lists
+// longer than one wave and skips cells without any after ONE scalar load.
+__global__ __launch_bounds__(SBLOCK) void sort_short_kernel(Batch<RenderFwdArgs> batch) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_buf[(SBLOCK / 64) * 64];
+    const RenderFwdArgs& a = batch.v[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int idx = (int)blockIdx.x * (SBLOCK / 64) + wave;     // sub-tile in cell_desc order
+    if (idx >= a.grid.subtiles) return;
+    if (idx >= (int)a.tw.header->active_cells * SUBS_PER_CELL) return;
+    const int st = (int)a.tw.cell_desc[idx >> 6].x * SUBS_PER_CELL + (idx & 63);
+    const uint2 range = a.tw.ranges[st];
+    const int n = (int)(range.y - range.x);
+    if (n > 0 && n <= 64) wave_rank_sort64(a.bw.keys + range.x, n, a.bw.sorted + range.x, s_buf + wave * 64, lane);
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
     __shared__ uint32_t s_cnt[SORT_TILE];                        // bucket counters / starts of the distribution sort
@@ -371,6 +391,7 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     // grid-stride loop over the active sub-tiles with a smaller grid cost 2.5x the registers and ran slower.)
     const int wg = (int)blockIdx.x - ORDER_WGS;
     if (wg >= (int)a.tw.header->active_cells * SUBS_PER_CELL) return;
+    if (SPLIT && a.tw.cell_long[wg >> 6] == 0u) return;         // the same word for the 64 workgroups of a cell
     const int st = (int)a.tw.cell_desc[wg >> 6].x * SUBS_PER_CELL + (wg & 63);
     const uint2 range = a.tw.ranges[st];
     const int n = (int)(range.y - range.x);                     // workgroup-uniform; empty on overflow
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     const unsigned long long* gkeys = a.bw.keys + range.x;
     uint32_t* sorted = a.bw.sorted + range.x;
     if (n <= 64) {
-        if (tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);
+        if (!SPLIT && tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);      // (SPLIT: sort_short_kernel did it)
         return;
     }
     if (n > SORT_TILE) {   // longer lists: 2048 own keys at a time against the whole list (any length)
@@ -551,7 +572,13 @@ static int max_subtiles(const RenderFwdArgs* a, int K) {
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
-    sort_subtiles_kernel<<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
+    static const int split_at = [] { const char* e = getenv("EXA_SORT_SPLIT_SUBTILES"); return e ? atoi(e) : SPLIT_SORT_SUBTILES; }();
+    if (subtiles >= split_at) {
+        sort_short_kernel<<<dim3((subtiles + SBLOCK / 64 - 1) / (SBLOCK / 64), K), SBLOCK, 0, s>>>(make_batch(a, K));
+        sort_subtiles_kernel<true><<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
+    } else {
+        sort_subtiles_kernel<false><<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
+    }
     return hipGetLastError();
 }
 

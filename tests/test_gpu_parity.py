@@ -814,14 +814,15 @@ def test_footprint_cull_leaves_the_result_alone(tmp_path):
 
 def test_one_workgroup_per_cell_binning_gives_the_same_lists(tmp_path):
     """Images of >= 1024 cells (2048 x 2048 px) bin their sub-tiles with ONE workgroup per cell that counts and scatters in
-    a single launch (csrc/binning.hip, SINGLE_PART_CELLS; the C5 full-size test runs through it, forward only).  Forced
-    on for a small scene through the developer knob: keys land in the same sub-tile ranges, the depth sort puts them in
-    the same order, so every output -- images and all gradients -- must be bit-identical to the four-part path."""
+    a single launch (csrc/binning.hip, SINGLE_PART_CELLS) and sort their short lists (<= 64 keys) one wave per list in a
+    launch of their own (csrc/render_fwd.hip, SPLIT_SORT_SUBTILES); the C5 full-size test runs through both, forward only.
+    Forced on for a small scene through the developer knobs: keys land in the same sub-tile ranges and the depth sort puts
+    them in the same order, so every output -- images and all gradients -- must be bit-identical to the default path."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for env in ({'EXA_BIN_SINGLE_CELLS': '1'}, {}):
+    for env in ({'EXA_BIN_SINGLE_CELLS': '1', 'EXA_SORT_SPLIT_SUBTILES': '1'}, {}):
         path = str(tmp_path / ('dump_%d.npz' % len(outs)))
         r = subprocess.run([sys.executable, os.path.join(root, 'tests', '_render_dump.py'), path], cwd=root,
                            env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
