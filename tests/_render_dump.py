@@ -15,6 +15,15 @@ dev = torch.device('cuda:0')
 H, W = 384, 512
 assets = scenes.cat_assets(scenes.dist_c_scene(4000, H, W, 3), scenes.dist_b_avatar(20000, 3))
 cam = scenes.neutral_camera(H, W, focal=560.0)
+# a stack of 700 faint splats over one 8x8 sub-tile: a list of more than 512 keys (the "long list" paths of the sort)
+g0 = torch.Generator().manual_seed(11)
+n_deep = 700
+depth = 2.0 + 4.0 * torch.rand(n_deep, generator=g0)
+for axis, centre in ((0, 100.0 - W / 2 + 0.5), (1, 60.0 - H / 2 + 0.5)):
+    assets['mean_3d'][:n_deep, axis] = (centre + (torch.rand(n_deep, generator=g0) - 0.5) * 5.0) / 560.0 * depth
+assets['mean_3d'][:n_deep, 2] = depth
+assets['scale'][:n_deep] = (0.003 + 0.003 * torch.rand(n_deep, 3, generator=g0)) * depth.view(-1, 1)
+assets['opacity'][:n_deep] = 0.006 + 0.004 * torch.rand(n_deep, 1, generator=g0)
 params = {k: assets[k].to(dev).requires_grad_(True) for k in ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')}
 renderer = exa.GaussianRenderer()
 res = renderer(params, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg=torch.tensor([0.2, 0.5, 0.8], device=dev))
