@@ -1,0 +1,43 @@
+"""gpurun_out/parity_stats.jsonl (written by tests/test_gpu_fullsize.py on the GPU box) -> profiles/<tag>_parity.md.
+Usage: python tools/make_parity_profile.py [tag=r02]   (the last record of every workload wins)"""
+import json
+import os
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+rows = {}
+for line in open(os.path.join(root, 'gpurun_out', 'parity_stats.jsonl')):
+    r = json.loads(line)
+    rows[r['tag']] = r
+order = [t for t in ('c3_P150000_view0', 'c3_P150000_view37', 'c3_P167000_view113', 'c2', 'c2l', 'c3s', 'c5_fwd_sh3') if t in rows]
+order += [t for t in rows if t not in order]
+out = ['# %s: HIP path vs CPU oracle at BASELINE.json\'s full sizes (MI355X, `pytest -m gpu tests/test_gpu_fullsize.py`)' % tag, '',
+       'Written by the tests themselves (`tests/helpers.record_stats` -> gpurun_out/parity_stats.jsonl, turned into this file by '
+       '`tools/make_parity_profile.py`), measured before the asserts.  "ambiguous" = pixels whose alpha >= 1/255, T < 1e-4 or '
+       'power > 0 decision lies within 1e-4 (relative) of its threshold in the ORACLE (a property of the scene, identical on any '
+       'machine); "off" = how many of them actually differ by > 1e-4 between the two fp32 implementations.  Gradients: max-norm and '
+       'L2 relative error over the whole tensor, and the absolute floor (in units of the mean per-Gaussian gradient magnitude) a '
+       'per-Gaussian `|err| <= 1e-3 |ref| + floor` check needs -- for Gaussians away from / near an ambiguous pixel.', '',
+       '| workload | P | image | ambiguous px | off (img / depth / alpha) | L-inf on unambiguous px (img / depth / alpha) | radii equal |',
+       '|---|---|---|---|---|---|---|']
+for t in order:
+    r = rows[t]
+    out.append('| %s | %d | %dx%d | %d | %d / %d / %d | %.1e / %.1e / %.1e | %s |' % (
+        t, r['P'], r['H'], r['W'], r['img']['n_ambiguous'], r['img']['n_ambiguous_off'], r['depth']['n_ambiguous_off'],
+        r['alpha']['n_ambiguous_off'], r['img']['linf_unambiguous'], r['depth']['linf_unambiguous'],
+        r['alpha']['linf_unambiguous'], r['radii_equal']))
+out += ['', '| workload | tensor | max-rel | L2-rel | per-Gaussian floor needed (clean) | (near ambiguous px) |', '|---|---|---|---|---|---|']
+for t in order:
+    r = rows[t]
+    for k in ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb', 'mean_2d'):
+        g = r.get('grad_' + k)
+        if g:
+            out.append('| %s | %s | %.2e | %.2e | %.2e | %.2e |' % (t, k, g['max_rel'], g['l2_rel'], g['per_gaussian_floor_needed'],
+                                                                  g['per_gaussian_floor_needed_near_ambiguous']))
+out += ['', 'Bars asserted by the tests: image L-inf 1e-4 on unambiguous pixels; ambiguous count <= ~1.3 x the oracle\'s own count per '
+        'workload; at most max(3, 1 %) of the ambiguous pixels off; radii bit-equal; gradients 1e-3 relative globally and per Gaussian '
+        '(floor 1e-3 clean, 1e-1 for Gaussians whose 3-sigma square covers an ambiguous pixel).']
+path = os.path.join(root, 'profiles', '%s_parity.md' % tag)
+open(path, 'w').write('\n'.join(out) + '\n')
+print('wrote', path, 'with', len(order), 'workloads')
