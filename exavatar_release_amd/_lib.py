@@ -68,6 +68,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
         ('dL_dmeans2D', c_void_p), ('dL_dmeans3D', c_void_p), ('dL_dcolors', c_void_p), ('dL_dopacity', c_void_p),
         ('dL_dscales', c_void_p), ('dL_drotations', c_void_p), ('dL_dsh', c_void_p), ('dL_dcov3D', c_void_p),
         ('densify_grad_accum', c_void_p), ('densify_track_cnt', c_void_p), ('densify_radius_max', c_void_p),
+        ('grad_first', ctypes.c_int32),
     ]
 
 
@@ -128,7 +129,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 110:
+    if lib.exa_raster_version() < 120:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

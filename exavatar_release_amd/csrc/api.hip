@@ -218,6 +218,7 @@ int check_backward_job(const ExaRasterBackwardJob& j) {
         return fail(EXA_RASTER_E_WORKSPACE, "workspace / radii is NULL");
     if (j.capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
     if (!j.dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
+    if (j.grad_first < 0 || j.grad_first > j.P) return fail(EXA_RASTER_E_INVALID, "grad_first must be in 0..P");
     return 0;
 }
 
@@ -228,7 +229,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipS
     int n = 0;
     for (int k = 0; k < K; ++k) {
         const ExaRasterBackwardJob& j = jobs[k];
-        if (j.P == 0) continue;                                   // nothing to differentiate
+        if (j.P == 0 || j.grad_first == j.P) continue;            // nothing to differentiate
         const ExaRasterSettings* s = j.settings;
         const Grid g = make_grid(s->image_width, s->image_height);
         RenderBwdArgs& r = ra[n];
@@ -237,6 +238,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipS
         r.bw = carve_bin_ws(const_cast<void*>(j.bin_ws), j.capacity);
         r.bg = s->bg; r.dL_dcolor = j.dL_dcolor; r.dL_ddepth = j.dL_ddepth; r.dL_dalpha = j.dL_dalpha;
         r.partials = carve_grad_ws(j.grad_ws, j.capacity);
+        r.grad_first = j.grad_first;
         PreprocessBwdArgs& b = pa[n];
         b.P = j.P; b.sh_M = j.sh_M; b.sh_degree = s->sh_degree; b.grid = g;
         b.tanfovx = s->tanfovx; b.tanfovy = s->tanfovy;
@@ -251,6 +253,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipS
         b.dL_dopacity = j.dL_dopacity; b.dL_dscales = j.dL_dscales; b.dL_drotations = j.dL_drotations;
         b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;
         b.dens_accum = j.densify_grad_accum; b.dens_cnt = j.densify_track_cnt; b.dens_rmax = j.densify_radius_max;
+        b.grad_first = j.grad_first;
         ++n;
     }
     if (n == 0) return 0;
@@ -319,6 +322,7 @@ int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32
         if (rc) return rc;
         if (sum_shared) {
             const ExaRasterBackwardJob &a = jobs[0], &b = jobs[k];
+            if (b.grad_first != 0) return fail(EXA_RASTER_E_INVALID, "sum_shared and grad_first cannot be combined");
             if (a.P != b.P || a.sh_M != b.sh_M || a.means3D != b.means3D || a.shs != b.shs || a.opacities != b.opacities ||
                 a.colors_precomp != b.colors_precomp || a.scales != b.scales || a.rotations != b.rotations ||
                 a.cov3D_precomp != b.cov3D_precomp || a.settings->sh_degree != b.settings->sh_degree ||
@@ -393,6 +397,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     j.dL_dmeans2D = dL_dmeans2D; j.dL_dmeans3D = dL_dmeans3D; j.dL_dcolors = dL_dcolors; j.dL_dopacity = dL_dopacity;
     j.dL_dscales = dL_dscales; j.dL_drotations = dL_drotations; j.dL_dsh = dL_dsh; j.dL_dcov3D = dL_dcov3D;
     j.densify_grad_accum = nullptr; j.densify_track_cnt = nullptr; j.densify_radius_max = nullptr;
+    j.grad_first = 0;
     return exa_raster_backward_batch(&j, 1, 0, stream);
 }
 

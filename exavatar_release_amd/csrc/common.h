@@ -276,6 +276,7 @@ struct RenderBwdArgs {
     const Splat* splats; TileWs tw; BinWs bw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
     PartialWs partials;
+    int grad_first;        // Gaussians below this index are constants (ExaRasterBackwardJob.grad_first)
 };
 hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s);
 
@@ -291,6 +292,7 @@ struct PreprocessBwdArgs {
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
     float* dens_accum; float* dens_cnt; float* dens_rmax;       // optional fused densification statistics (per view)
+    int grad_first;        // Gaussians below this index are constants: no work, no output rows (output row = idx - grad_first)
 };
 // sum_shared != 0: the K jobs are K views of the SAME Gaussians (identical input pointers and P): one thread
 // per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).

@@ -24,19 +24,27 @@ namespace exa {
 // paid 3 K dependent memory round trips.  VW = 1 (the SH path, whose 48-float dL_dsh rows are accumulated in
 // global memory by their single owner): one thread walks all views.  SH = false compiles the SH backward out (the
 // colours-precomp path of ExAvatar's renderer, module.py:632-640): fewer registers, more waves per SIMD.
-template <bool SUM, int VW, bool SH>
+// PREFIX = true: the job may have a constant prefix (grad_first > 0); its own instantiation so that the plain kernels
+// carry none of it.
+template <bool SUM, int VW, bool SH, bool PREFIX>
 __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K) {
     static_assert(VW == 1 || (SUM && VW == BLOCK / 64), "views are split over the waves of a workgroup in SUM mode only");
     __shared__ float s_red[VW > 1 ? 20 * BLOCK : 1];
     const PreprocessBwdArgs& out = batch.v[SUM ? 0 : blockIdx.y];
     constexpr int GPB = BLOCK / VW;                             // Gaussians per workgroup
     if ((int)(blockIdx.x * GPB) >= out.P) return;               // workgroup-uniform
+    // constant prefix (ExaRasterBackwardJob.grad_first): Gaussians below gf are inputs only -- no chain rule, no output
+    // row (row = idx - gf).  A workgroup of constants leaves at once; in the boundary workgroup they stay in the wave
+    // for the cooperative gather below but are neither `vis` nor `valid`.
+    const int gf = PREFIX ? out.grad_first : 0;
+    if (PREFIX && (int)((blockIdx.x + 1) * GPB) <= gf) return;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int idx = VW == 1 ? blockIdx.x * BLOCK + threadIdx.x : blockIdx.x * 64 + lane;
     // NO per-lane early exit: the wave-cooperative gather below needs all 64 lanes, also in the last, partly filled
     // wave (Gaussians appended by densification sit exactly there)
-    const bool valid = idx < out.P;
-    const int idc = valid ? idx : out.P - 1;                    // clamped index for loads
+    const bool valid = idx < out.P && idx >= gf;
+    const int idc = idx < out.P ? idx : out.P - 1;              // clamped index for loads
+    const int row = idx - gf;                                   // output row
     float in_s[3] = {0.f, 0.f, 0.f};
     float4 in_q = make_float4(1.f, 0.f, 0.f, 0.f);
     float in_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             }
             const int ncoef = (deg + 1) * (deg + 1);
             const float* sh = a.shs + (size_t)idc * a.sh_M * 3;
-            float* dsh = out.dL_dsh ? out.dL_dsh + (size_t)idc * a.sh_M * 3 : nullptr;
+            float* dsh = (out.dL_dsh && valid) ? out.dL_dsh + (size_t)row * a.sh_M * 3 : nullptr;
             float ddirx = 0.f, ddiry = 0.f, ddirz = 0.f;
             for (int k = 0; k < a.sh_M; ++k) {
                 const bool on = k < ncoef && k < 16;
@@ -349,14 +357,14 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         }
         }
         if (valid && a.dL_dmeans2D) {
-            a.dL_dmeans2D[idx * 3 + 0] = vm2[0]; a.dL_dmeans2D[idx * 3 + 1] = vm2[1]; a.dL_dmeans2D[idx * 3 + 2] = 0.f;
+            a.dL_dmeans2D[row * 3 + 0] = vm2[0]; a.dL_dmeans2D[row * 3 + 1] = vm2[1]; a.dL_dmeans2D[row * 3 + 2] = 0.f;
         }
         // fused densification statistics of this view (reference avatar/main/model.py:279-285 + module.py:155-157): the
         // screen-space gradient is in registers here, no separate pass over the Gaussians
         if (vis) {
-            if (a.dens_accum) a.dens_accum[idx] += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
-            if (a.dens_cnt) a.dens_cnt[idx] += 1.0f;
-            if (a.dens_rmax) a.dens_rmax[idx] = fmaxf(a.dens_rmax[idx], (float)a.radii[idc]);
+            if (a.dens_accum) a.dens_accum[row] += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
+            if (a.dens_cnt) a.dens_cnt[row] += 1.0f;
+            if (a.dens_rmax) a.dens_rmax[row] = fmaxf(a.dens_rmax[row], (float)a.radii[idc]);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { dmean[i] += vmean[i]; dscale[i] += vscale[i]; dcol[i] += vcol[i]; }
@@ -391,18 +399,18 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
     }
     if (!valid) return;
     if (SH && !sh_init && out.shs && out.dL_dsh) {                    // never visible: the SH block above did not run
-        float* dsh = out.dL_dsh + (size_t)idx * out.sh_M * 3;
+        float* dsh = out.dL_dsh + (size_t)row * out.sh_M * 3;
         for (int k = 0; k < out.sh_M * 3; ++k) dsh[k] = 0.f;
     }
 
-    if (out.dL_dmeans3D) { out.dL_dmeans3D[idx * 3 + 0] = dmean[0]; out.dL_dmeans3D[idx * 3 + 1] = dmean[1]; out.dL_dmeans3D[idx * 3 + 2] = dmean[2]; }
-    if (out.dL_dopacity) out.dL_dopacity[idx] = dop;
-    if (out.dL_dcolors) { out.dL_dcolors[idx * 3 + 0] = dcol[0]; out.dL_dcolors[idx * 3 + 1] = dcol[1]; out.dL_dcolors[idx * 3 + 2] = dcol[2]; }
-    if (out.dL_dscales) { out.dL_dscales[idx * 3 + 0] = dscale[0]; out.dL_dscales[idx * 3 + 1] = dscale[1]; out.dL_dscales[idx * 3 + 2] = dscale[2]; }
-    if (out.dL_drotations) reinterpret_cast<float4*>(out.dL_drotations)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    if (out.dL_dmeans3D) { out.dL_dmeans3D[row * 3 + 0] = dmean[0]; out.dL_dmeans3D[row * 3 + 1] = dmean[1]; out.dL_dmeans3D[row * 3 + 2] = dmean[2]; }
+    if (out.dL_dopacity) out.dL_dopacity[row] = dop;
+    if (out.dL_dcolors) { out.dL_dcolors[row * 3 + 0] = dcol[0]; out.dL_dcolors[row * 3 + 1] = dcol[1]; out.dL_dcolors[row * 3 + 2] = dcol[2]; }
+    if (out.dL_dscales) { out.dL_dscales[row * 3 + 0] = dscale[0]; out.dL_dscales[row * 3 + 1] = dscale[1]; out.dL_dscales[row * 3 + 2] = dscale[2]; }
+    if (out.dL_drotations) reinterpret_cast<float4*>(out.dL_drotations)[row] = make_float4(dq[0], dq[1], dq[2], dq[3]);
     if (out.dL_dcov3D) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) out.dL_dcov3D[idx * 6 + i] = dcov[i];
+        for (int i = 0; i < 6; ++i) out.dL_dcov3D[row * 6 + i] = dcov[i];
     }
 }
 
@@ -435,16 +443,21 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shar
     for (int k = 0; k < K; ++k) P = max(P, a[k].P);
     if (P == 0) return hipSuccess;
     bool sh = false;
-    for (int k = 0; k < K; ++k) sh = sh || a[k].shs != nullptr;
+    bool prefix = false;
+    for (int k = 0; k < K; ++k) { sh = sh || a[k].shs != nullptr; prefix = prefix || a[k].grad_first > 0; }
     const dim3 grid256((P + BLOCK - 1) / BLOCK, sum_shared ? 1 : K);
     if (sum_shared && !sh)
-        preprocess_bwd_kernel<true, BLOCK / 64, false><<<dim3((P + 63) / 64, 1), BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<true, BLOCK / 64, false, false><<<dim3((P + 63) / 64, 1), BLOCK, 0, s>>>(make_batch(a, K), K);
     else if (sum_shared)
-        preprocess_bwd_kernel<true, 1, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<true, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+    else if (sh && prefix)
+        preprocess_bwd_kernel<false, 1, true, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
     else if (sh)
-        preprocess_bwd_kernel<false, 1, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+    else if (prefix)
+        preprocess_bwd_kernel<false, 1, false, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
     else
-        preprocess_bwd_kernel<false, 1, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, false, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
     return hipGetLastError();
 }
 

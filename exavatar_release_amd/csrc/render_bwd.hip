@@ -42,6 +42,16 @@
 // min(0.99, .).  The screen-space gradients are emitted as five moments of s = dL/dG * G
 // (sum s dx, s dy, s dx^2, s dx dy, s dy^2); preprocess_bwd.hip turns them into d/d(mean2D, conic).
 //
+// CONSTANT PREFIX (PREFIX = true; ExaRasterBackwardJob.grad_first > 0): ExAvatar's composite renders blend the detached
+// scene under the human (torch.cat((scene.detach(), human)), reference avatar/main/model.py:119-126).  Gaussians below
+// `grad_first` get no gradient: a batch whose blended entries are all constants exits after its header (most of the
+// image in a scene + human render), inside a live batch a chunk of 16 constants skips phase B, and no partial record is
+// written for a constant entry.  The arithmetic of the trainable entries is the same source, but it is compiled as its
+// own instantiation: folded into the one kernel -- even behind scalar branches on grad_first -- the extra tests cost
+// the all-trainable path 2.5-3 us of 55 on C3 (A/B on one box), so that path carries none of them.  Between the two
+// instantiations the compiler may contract multiply-adds differently: the trainable gradients agree to rounding
+// (~1e-7 relative), not bit for bit.
+//
 // Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered (blended) splat, 12 (+8) B/pixel of
 // incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 49 B per blended instance.
 #include <stdlib.h>
@@ -78,7 +88,9 @@ struct BwdPay {
     float gr, gg, gb, gd, ga;
 };
 
-template <bool HAS_DEPTH, int GC, int SPW>
+constexpr uint32_t NO_SLOT = 0xffffffffu;         // s_pslot of a constant (frozen) entry: nothing to write
+
+template <bool HAS_DEPTH, int GC, int SPW, bool PREFIX>
 __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
     constexpr int XROW = XLayout<GC>::ROW, XGROUP = XLayout<GC>::GROUP;
     __shared__ BatchLds s_b;
@@ -106,9 +118,14 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         }
         return h;
     };
+    const uint32_t grad_first = PREFIX ? (uint32_t)a.grad_first : 0u;
     auto is_active = [&](const BwdHdr& h) -> bool {              // wave-uniform
-        return __builtin_amdgcn_readfirstlane(h.st1) != 0u &&
-               (__builtin_amdgcn_readfirstlane(h.bm_lo) | __builtin_amdgcn_readfirstlane(h.bm_hi)) != 0u;
+        uint32_t lo = __builtin_amdgcn_readfirstlane(h.bm_lo), hi = __builtin_amdgcn_readfirstlane(h.bm_hi);
+        if (PREFIX) {                                            // blended AND trainable (lanes past the list end hold
+            const unsigned long long tr = __ballot(h.id >= grad_first);     // garbage ids, but their mask bits are clear)
+            lo &= (uint32_t)tr; hi &= (uint32_t)(tr >> 32);
+        }
+        return __builtin_amdgcn_readfirstlane(h.st1) != 0u && (lo | hi) != 0u;
     };
     auto load_pay = [&](const BwdHdr& h, uint32_t slot) -> BwdPay {
         BwdPay p;
@@ -130,6 +147,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
             const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
             p.pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
+            if (PREFIX && h.id < grad_first) p.pslot = NO_SLOT;
         }
         // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
         const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;
@@ -198,6 +216,8 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     float R = (p0.cf1 - sr) * gr + (p0.cf2 - sg) * gg + (p0.cf3 - sb) * gb - tail;
     if (HAS_DEPTH) R = fmaf(p0.cf4 - sd, gd, R);
     wave_lds_fence();
+    // staged entries (compacted order) that are trainable; a chunk without any skips phase B
+    const unsigned long long need = PREFIX ? __ballot(lane < cnt && s_pslot[lane] != NO_SLOT) : ~0ull;
 
     const int g = lane % GC, h = lane / GC;                     // phase B role: splat g of the chunk, pixel group h
     float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane / GC) * XGROUP + 2 * (lane % GC));    // phase A: my column
@@ -239,7 +259,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         }
         wave_lds_fence();
         // ---- phase B: lane = (splat g of the chunk, pixel group h = pixel rows 2h, 2h + 1) -------------------
-        {
+        if (!PREFIX || ((need >> c0) & ((1ull << GC) - 1ull)) != 0ull) {
             const int kk = c0 + g;                              // rows >= cend hold stale data: never stored
             float S0 = 0.f, Sx = 0.f, Sxx = 0.f, Sy = 0.f, Sxy = 0.f, dr = 0.f, dg = 0.f, db = 0.f, dz = 0.f;
 #pragma unroll
@@ -282,11 +302,13 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             if (h == 0 && kk < cend) {
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
                 const uint32_t ps = s_pslot[kk];
-                float4* dst = prec + (size_t)ps * 3;
-                dst[0] = make_float4(o * mx, o * my, o * mxx, o * mxy);
-                dst[1] = make_float4(o * myy, dop, dr, dg);
-                dst[2] = make_float4(db, dz, 0.f, 0.f);
-                touched[ps] = (uint8_t)1;
+                if (!PREFIX || ps != NO_SLOT) {
+                    float4* dst = prec + (size_t)ps * 3;
+                    dst[0] = make_float4(o * mx, o * my, o * mxx, o * mxy);
+                    dst[1] = make_float4(o * myy, dop, dr, dg);
+                    dst[2] = make_float4(db, dz, 0.f, 0.f);
+                    touched[ps] = (uint8_t)1;
+                }
             }
         }
         wave_lds_fence();                                       // the next chunk / batch overwrites the LDS buffers
@@ -298,17 +320,21 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
 
 hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
     uint64_t slots = 0;
-    bool depth = false;
+    bool depth = false, prefix = false;
     for (int k = 0; k < K; ++k) {
         slots = a[k].capacity / BATCH > slots ? a[k].capacity / BATCH : slots;
         depth = depth || a[k].dL_ddepth != nullptr;
+        prefix = prefix || a[k].grad_first > 0;
     }
     if (slots == 0) return hipSuccess;
     static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();     // developer knobs
     static const int spw = [] { const char* e = getenv("EXA_BWD_SPW"); return e ? atoi(e) : 1; }();
     const Batch<RenderBwdArgs> b = make_batch(a, K);
-#define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, 0, s>>>(b)
-    if (gc == 8) {
+#define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S, false><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, 0, s>>>(b)
+    if (prefix) {
+        if (depth) render_bwd_kernel<true, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(b);
+        else render_bwd_kernel<false, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(b);
+    } else if (gc == 8) {
         if (depth) EXA_LAUNCH_BWD(true, 8, 1); else EXA_LAUNCH_BWD(false, 8, 1);
     } else if (spw == 2) {
         if (depth) EXA_LAUNCH_BWD(true, 16, 2); else EXA_LAUNCH_BWD(false, 16, 2);

@@ -183,7 +183,7 @@ def _sizes(P, W, H, capacity):
 
 class _Job:
     """Host-side record of one render of a batch."""
-    __slots__ = ('rs', 'P', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
+    __slots__ = ('rs', 'P', 'nF', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
                  'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
                  'gb', 'tb')
 
@@ -192,12 +192,16 @@ N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, 
 
 
 class _Rasterize(torch.autograd.Function):
-    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, densify, *tensors[8 K]).
+    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, densify, frozen, *tensors[8 K]).
     ``densify``: None or a K-list of None / (xyz_grad_accum, track_cnt, radius_max) tensors updated IN PLACE by that
-    render's backward (fused densification statistics, include/exa_raster.h)."""
+    render's backward (fused densification statistics, include/exa_raster.h).
+    ``frozen``: None or a K-list of None / 8-tuples in the order of ``_IN_NAMES``: a CONSTANT prefix of Gaussians that
+    render k blends in front of / behind its own (the detached scene of ExAvatar's composite renders,
+    ``avatar/main/model.py:119-126``).  The render sees ``cat(prefix, own)``; the backward returns gradients for the own
+    rows only and skips all work on the prefix (``ExaRasterBackwardJob.grad_first``)."""
 
     @staticmethod
-    def forward(ctx, K, settings, grad_enabled, shared, densify, *tensors):
+    def forward(ctx, K, settings, grad_enabled, shared, densify, frozen, *tensors):
         lib = _lib.load()
         device = tensors[0].device
         if device.type != 'cuda':
@@ -212,14 +216,29 @@ class _Rasterize(torch.autograd.Function):
             j = _Job()
             j.rs = settings[k]
             j.H, j.W = int(j.rs.image_height), int(j.rs.image_width)
-            j.P = int(m3.shape[0])
-            j.means3D = _f32c(m3, 'means3D', device)
-            j.sh = _f32c(sh, 'shs', device)
-            j.colors = _f32c(col, 'colors_precomp', device)
-            j.opac = _f32c(op, 'opacities', device)
-            j.scales = _f32c(sc, 'scales', device)
-            j.rot = _f32c(rot, 'rotations', device)
-            j.cov = _f32c(cov, 'cov3D_precomp', device)
+            fz = frozen[k] if frozen is not None else None
+            j.nF = int(fz[0].shape[0]) if fz is not None else 0
+
+            def inp(t, i, name):
+                t = _f32c(t, name, device)
+                if fz is None:
+                    return t
+                f = _f32c(fz[i], name + ' (constant prefix)', device)
+                if (t is None) != (f is None):
+                    raise ValueError('%s: the constant prefix must provide the same inputs as the render' % name)
+                if t is None:
+                    return None
+                if f.shape[0] != j.nF or f.shape[1:] != t.shape[1:]:
+                    raise ValueError('%s: constant prefix of shape %s does not fit %s' % (name, tuple(f.shape), tuple(t.shape)))
+                return torch.cat((f, t))          # no autograd inside Function.forward: a plain copy kernel
+            j.means3D = inp(m3, 0, 'means3D')
+            j.P = int(j.means3D.shape[0])
+            j.sh = inp(sh, 2, 'shs')
+            j.colors = inp(col, 3, 'colors_precomp')
+            j.opac = inp(op, 4, 'opacities')
+            j.scales = inp(sc, 5, 'scales')
+            j.rot = inp(rot, 6, 'rotations')
+            j.cov = inp(cov, 7, 'cov3D_precomp')
             j.sh_M = int(j.sh.shape[1]) if j.sh is not None else 0
             j.key = (device.index, j.P, j.H, j.W)
             jobs.append(j)
@@ -313,7 +332,7 @@ class _Rasterize(torch.autograd.Function):
             ctx.shared = bool(shared) and K > 1
             ctx.hdr_check = hdr_check
             ctx.meta = [(j.rs, j.P, j.H, j.W, j.sh_M, j.capacity, j.gb, j.tb, j.settings, j.keep, j.ws, j.bins,
-                         tuple(t is not None for t in (j.sh, j.colors, j.scales, j.rot, j.cov))) for j in jobs]
+                         tuple(t is not None for t in (j.sh, j.colors, j.scales, j.rot, j.cov)), j.nF) for j in jobs]
             saved = []
             empty = None
             for j in jobs:
@@ -340,12 +359,13 @@ class _Rasterize(torch.autograd.Function):
         saved = ctx.saved_tensors
         device = saved[0].device
         f32 = dict(dtype=torch.float32, device=device)
-        need = ctx.needs_input_grad[5:]
+        need = ctx.needs_input_grad[6:]
         arr = (_lib.ExaRasterBackwardJob * K)()
-        keep, ret = [], [None, None, None, None, None]
+        keep, ret = [], [None, None, None, None, None, None]
         with torch.cuda.device(device):
             for k in range(K):
-                rs, P, H, W, sh_M, cap, gb, tb, st, _skeep, ws, bins, has = ctx.meta[k]
+                rs, P, H, W, sh_M, cap, gb, tb, st, _skeep, ws, bins, has, nF = ctx.meta[k]
+                Pg = P - nF                               # rows of every gradient array (constant prefix excluded)
                 has_sh, has_col, has_sc, has_rot, has_cov = has
                 means3D, sh, col, opac, scales, rot, cov, radii = saved[8 * k: 8 * k + 8]
                 g_color, g_depth, g_alpha = grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]
@@ -364,14 +384,14 @@ class _Rasterize(torch.autograd.Function):
                 own = (not ctx.shared) or k == 0          # shared: job 0's outputs receive the sum over the K views
                 # separate tensors on purpose: AccumulateGrad adopts a whole tensor as `.grad` without a copy, a view
                 # of a shared buffer would be cloned
-                d_means3D = torch.empty((P, 3), **f32) if own and nd[0] else None
-                d_means2D = torch.empty((P, 3), **f32) if nd[1] else None
-                d_sh = torch.empty((P, sh_M, 3), **f32) if own and has_sh and nd[2] else None
-                d_colors = torch.empty((P, 3), **f32) if own and has_col and nd[3] else None
-                d_opac = torch.empty((P, 1), **f32) if own and nd[4] else None
-                d_scales = torch.empty((P, 3), **f32) if own and has_sc and nd[5] else None
-                d_rot = torch.empty((P, 4), **f32) if own and has_rot and nd[6] else None
-                d_cov = torch.empty((P, 6), **f32) if own and has_cov and nd[7] else None
+                d_means3D = torch.empty((Pg, 3), **f32) if own and nd[0] else None
+                d_means2D = torch.empty((Pg, 3), **f32) if nd[1] else None
+                d_sh = torch.empty((Pg, sh_M, 3), **f32) if own and has_sh and nd[2] else None
+                d_colors = torch.empty((Pg, 3), **f32) if own and has_col and nd[3] else None
+                d_opac = torch.empty((Pg, 1), **f32) if own and nd[4] else None
+                d_scales = torch.empty((Pg, 3), **f32) if own and has_sc and nd[5] else None
+                d_rot = torch.empty((Pg, 4), **f32) if own and has_rot and nd[6] else None
+                d_cov = torch.empty((Pg, 6), **f32) if own and has_cov and nd[7] else None
                 grad_ws = torch.empty(int(_sizes(P, W, H, cap).grad_bytes), dtype=torch.uint8, device=device)
                 keep += [g_color, g_depth, g_alpha, grad_ws]
                 a = arr[k]
@@ -397,10 +417,11 @@ class _Rasterize(torch.autograd.Function):
                 dens = ctx.densify[k] if ctx.densify is not None else None
                 if dens is not None:
                     if d_means2D is None:          # the statistics need the screen-space gradient: compute it anyway
-                        d_tmp = torch.empty((P, 3), **f32)
+                        d_tmp = torch.empty((Pg, 3), **f32)
                         keep.append(d_tmp)
                         a.dL_dmeans2D = d_tmp.data_ptr()
                     a.densify_grad_accum, a.densify_track_cnt, a.densify_radius_max = [_addr(t) for t in dens]
+                a.grad_first = nF
                 ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
             _lib.check(lib.exa_raster_backward_batch(arr, K, int(ctx.shared), _stream_ptr(device)))
         if ctx.hdr_check is not None:
@@ -434,7 +455,7 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """``densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` float32 tensors of P elements that THIS
     render's backward updates in place (fused densification statistics, see ``densify.track_densify_stats``)."""
     dens = None if densify_stats is None else [_check_densify(densify_stats, int(means3D.shape[0]), means3D.device)]
-    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, dens, means3D, means2D, sh,
+    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, dens, None, means3D, means2D, sh,
                             colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
 
 
@@ -445,7 +466,10 @@ def rasterize_gaussians_batch(jobs):
     """K renders in one launch per pipeline stage.
 
     ``jobs``: sequence of dicts with the keyword arguments of ``GaussianRasterizer.forward`` plus
-    ``raster_settings`` (and optionally ``densify_stats``, see :func:`rasterize_gaussians`).  Returns a list of ``(color, radii, depth, alpha)`` tuples, bit-identical to K single
+    ``raster_settings`` (and optionally ``densify_stats``, see :func:`rasterize_gaussians`, and ``frozen``: a dict with
+    the same tensor keywords holding a CONSTANT prefix of Gaussians -- the render blends ``cat(prefix, own)``, ``radii``
+    covers both, gradients / ``means2D`` / ``densify_stats`` cover the job's own Gaussians only and the backward does
+    no work for the prefix).  Returns a list of ``(color, radii, depth, alpha)`` tuples, bit-identical to K single
     calls.  When every job passes the SAME tensor objects for the Gaussians (K views of one model), the backward
     sums the K views' gradients inside the per-Gaussian kernel (one thread walks the K views) instead of letting
     autograd add K gradient tensors.
@@ -455,16 +479,28 @@ def rasterize_gaussians_batch(jobs):
     if K == 0:
         return []
     flat = []
+    frozen = None
     for j in jobs:
         _check_combo(j.get('shs'), j.get('colors_precomp'), j.get('scales'), j.get('rotations'), j.get('cov3D_precomp'))
         flat += [j.get(n) for n in _IN_NAMES]
-    shared = K > 1 and all(all(jobs[k].get(n) is jobs[0].get(n) for n in _IN_NAMES if n != 'means2D') for k in range(1, K))
+    if any(j.get('frozen') is not None for j in jobs):
+        frozen = []
+        for j in jobs:
+            fz = j.get('frozen')
+            if fz is not None:
+                if fz.get('means3D') is None:
+                    raise ValueError('frozen: the constant prefix needs means3D')
+                fz = tuple(None if n == 'means2D' or fz.get(n) is None else fz[n].detach() for n in _IN_NAMES)
+            frozen.append(fz)
+    shared = K > 1 and frozen is None and \
+        all(all(jobs[k].get(n) is jobs[0].get(n) for n in _IN_NAMES if n != 'means2D') for k in range(1, K))
     if shared and K > 8:
         shared = False
     dens = None
     if any(j.get('densify_stats') is not None for j in jobs):
         dens = [_check_densify(j.get('densify_stats'), int(j['means3D'].shape[0]), j['means3D'].device) for j in jobs]
-    outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, dens, *flat)
+    outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, dens, frozen,
+                            *flat)
     return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
 
 

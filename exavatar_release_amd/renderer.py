@@ -53,8 +53,9 @@ def _camera_block(cam_param, img_shape, device):
     return res
 
 
-def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None):
-    """Settings tuple + rasterizer keyword arguments of one render, built exactly as module.py:594-640 does."""
+def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, frozen_assets=None):
+    """Settings tuple + rasterizer keyword arguments of one render, built exactly as module.py:594-640 does.
+    ``frozen_assets``: constant Gaussians blended together with ``gaussian_assets`` (render_many / render_iteration)."""
     mean_3d = gaussian_assets['mean_3d']
     device = mean_3d.device
     if bg is None:
@@ -80,10 +81,15 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None):
     mean_2d = torch.zeros((point_num, 3), dtype=torch.float32, device=device)
     mean_2d.requires_grad = True
     mean_2d.retain_grad()
+    frozen = None
+    if frozen_assets is not None:
+        frozen = dict(means3D=frozen_assets['mean_3d'], colors_precomp=frozen_assets['rgb'],
+                      opacities=frozen_assets['opacity'], scales=frozen_assets['scale'],
+                      rotations=frozen_assets['rotation'])
     return dict(raster_settings=raster_settings, means3D=mean_3d, means2D=mean_2d, shs=None,
                 colors_precomp=gaussian_assets['rgb'], opacities=gaussian_assets['opacity'],
                 scales=gaussian_assets['scale'], rotations=gaussian_assets['rotation'], cov3D_precomp=None,
-                densify_stats=densify_stats)
+                densify_stats=densify_stats, frozen=frozen)
 
 
 def _output_dict(job, outs):
@@ -133,8 +139,12 @@ def render_many(renderer, jobs):
     instead of 2 K in the backward, one autograd node, and the renders' workgroups fill the chip together.  Results
     are bit-identical to sequential calls (the pipeline has no atomics).
 
-    ``jobs``: sequence of ``(gaussian_assets, img_shape, cam_param, bg[, densify_stats])`` tuples (``bg`` may be ``None``).
-    Returns the list of output dicts of ``renderer.forward``.
+    ``jobs``: sequence of ``(gaussian_assets, img_shape, cam_param, bg[, densify_stats[, frozen_assets]])`` tuples
+    (``bg`` may be ``None``).  ``frozen_assets``: a second asset dict of CONSTANT Gaussians rendered together with
+    ``gaussian_assets`` -- what the reference writes as ``torch.cat((scene_asset[key].detach(), human_asset[key]))``
+    (``model.py:119-126``), without the five concatenations in the autograd graph and without any backward work for the
+    constant part; the render's ``radius`` / ``is_vis`` cover ``cat(frozen, own)``, its ``mean_2d`` probe only the own
+    Gaussians.  Returns the list of output dicts of ``renderer.forward``.
     """
     jobs = list(jobs)
     if not jobs:
@@ -142,7 +152,8 @@ def render_many(renderer, jobs):
     device = jobs[0][0]['mean_3d'].device
     if device.type != 'cuda':
         raise RuntimeError('exavatar_release_amd: render_many runs on a ROCm device only')
-    rj = [_raster_job(j[0], j[1], j[2], j[3] if len(j) > 3 else None, j[4] if len(j) > 4 else None) for j in jobs]
+    rj = [_raster_job(j[0], j[1], j[2], j[3] if len(j) > 3 else None, j[4] if len(j) > 4 else None,
+                      j[5] if len(j) > 5 else None) for j in jobs]
     outs = rasterize_gaussians_batch(rj)
     return [_output_dict(j, o) for j, o in zip(rj, outs)]
 
@@ -153,3 +164,36 @@ def render_views(renderer, gaussian_assets, img_shape, cam_params, bg=None):
     the SUM of the K views' gradients for the shared tensors (summed inside the per-Gaussian kernel), and one
     ``mean_2d`` probe per view.  Returns the list of K output dicts."""
     return render_many(renderer, [(gaussian_assets, img_shape, cp, bg) for cp in cam_params])
+
+
+ITERATION_RENDERS = ('scene', 'human', 'scene_human', 'human_refined', 'scene_human_refined')
+
+
+def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, img_shape, cam_param, bg,
+                     scene_densify_stats=None):
+    """The five same-camera renders of one ExAvatar training sample (``avatar/main/model.py:119-167``) as ONE batched
+    call with the Gaussian SETS shared between them:
+
+    ===================== ===================================== ==========================================
+    render                reference                             here
+    ===================== ===================================== ==========================================
+    ``scene``             ``renderer(scene_asset, ...)``        job 0: scene, white background
+    ``human``             ``renderer(human_asset, ..., bg)``    job 1: human, ``bg``
+    ``scene_human``       ``cat(scene.detach(), human)``        job 2: human + CONSTANT scene prefix
+    ``human_refined``     ``renderer(human_asset_refined, bg)`` job 3
+    ``scene_human_refined`` ``cat(scene.detach(), refined)``    job 4: refined human + CONSTANT scene prefix
+    ===================== ===================================== ==========================================
+
+    The scene tensors enter the composite renders as constants: no ``torch.cat`` / ``CatBackward`` nodes, and the
+    backward of jobs 2 and 4 skips every 64-entry batch that blended no human Gaussian (most of the image), writes no
+    partial sums and runs no chain rule for the scene (``ExaRasterBackwardJob.grad_first``).  Images are bit-identical
+    to the reference's formulation through :func:`render_many`; the human gradients too.
+    ``scene_densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` updated by the scene render's backward
+    (``model.py:279-285``).  Returns a dict of the five output dicts keyed by :data:`ITERATION_RENDERS`.
+    """
+    jobs = [(scene_asset, img_shape, cam_param, None, scene_densify_stats),
+            (human_asset, img_shape, cam_param, bg),
+            (human_asset, img_shape, cam_param, None, None, scene_asset),
+            (human_asset_refined, img_shape, cam_param, bg),
+            (human_asset_refined, img_shape, cam_param, None, None, scene_asset)]
+    return dict(zip(ITERATION_RENDERS, render_many(renderer, jobs)))

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 110          /* 0.1.1: batched entry points, img workspace removed */
+#define EXA_RASTER_VERSION 120          /* 0.1.2: ExaRasterBackwardJob.grad_first (constant leading Gaussians) */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
 #define EXA_RASTER_E_INVALID (-1)
@@ -185,6 +185,13 @@ typedef struct ExaRasterBackwardJob {
     /* optional fused densification statistics (all three NULL = off): updated in place by the per-Gaussian backward
      * kernel exactly as exa_raster_densify_stats would do it with this job's dL_dmeans2D and radii -- no extra pass */
     float* densify_grad_accum; float* densify_track_cnt; float* densify_radius_max;
+    /* Constant prefix: Gaussians 0 .. grad_first - 1 are inputs only, they get no gradient.  This is the scene under
+     * the human in ExAvatar's composite renders (torch.cat((scene.detach(), human)), avatar/main/model.py:119-126): the
+     * backward skips every 64-entry batch that blended no trainable Gaussian, writes no partial record for a constant one
+     * and runs no per-Gaussian chain rule for it.  With grad_first > 0 EVERY gradient array above (dL_dmeans2D ...
+     * dL_dcov3D, densify_*) holds P - grad_first rows: row r belongs to Gaussian grad_first + r.  0 = all trainable.
+     * Not combinable with sum_shared. */
+    int32_t grad_first;
 } ExaRasterBackwardJob;
 
 int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream);

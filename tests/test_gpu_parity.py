@@ -504,6 +504,109 @@ def test_render_many_is_bit_identical_to_sequential_renders(dev):
         assert torch.equal(x, y)
 
 
+def _frozen_case(dev, nS, nH, H, W, f, seed, big_at=()):
+    """scene (constant) + human (trainable) through the constant-prefix path, the plain composite and the oracle."""
+    scene = scenes.dist_a_random(nS, H, W, seed=seed, focal=f)
+    human = scenes.dist_a_random(nH, H, W, seed=seed + 1, focal=f, z_range=(2.0, 4.0))
+    for which, i in big_at:              # splats of >= 64 sub-tiles at chosen indices (wave-cooperative gather)
+        t = scene if which == 's' else human
+        t['scale'][i] = torch.tensor([0.45, 0.40, 0.35])
+        t['mean_3d'][i] = torch.tensor([0.05 * (1 + i % 3), -0.03, 3.0 if which == 's' else 2.9])
+        t['opacity'][i] = 0.35
+    cam = scenes.neutral_camera(H, W, focal=f)
+    cam_d = {k: t.to(dev) for k, t in cam.items()}
+    g = torch.Generator().manual_seed(seed + 2)
+    G, bg = torch.randn(3, H, W, generator=g), torch.rand(3, generator=g)
+    rend = exa.GaussianRenderer()
+    # (1) constant-prefix path
+    s1, h1 = _to(scene, dev), _to(human, dev)
+    o1 = exa.render_many(rend, [(h1, (H, W), cam_d, bg.to(dev), None, s1)])[0]
+    ((o1['img'] * G.to(dev)).sum() + o1['mask'].sum()).backward()
+    # (2) the reference's formulation: torch.cat((scene.detach(), human)) as ONE Gaussian set
+    s2, h2 = _to(scene, dev), _to(human, dev)
+    o2 = rend({k: torch.cat((s2[k].detach(), h2[k])) for k in KEYS}, (H, W), cam_d, bg.to(dev))
+    ((o2['img'] * G.to(dev)).sum() + o2['mask'].sum()).backward()
+    # (3) oracle on the concatenation
+    s3 = {k: v.clone() for k, v in scene.items()}
+    h3 = {k: v.clone().requires_grad_(True) for k, v in human.items()}
+    ref = ro.render({k: torch.cat((s3[k], h3[k])) for k in KEYS}, (H, W), cam, bg, return_aux=True)
+    ((ref['img'] * G).sum() + ref['mask'].sum()).backward()
+    return (s1, h1, o1), (s2, h2, o2), (h3, ref)
+
+
+def _assert_same_to_rounding(a, b, name):
+    """Two compilations of the same arithmetic: equal up to a few ulp of the tensor's magnitude."""
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-30, '%s: %g vs scale %g' % (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize('nS,nH,big_at', [
+    (3000, 1500, ()),
+    (1000 + 37, 500 + 11, (('s', 1000 + 36), ('h', 0), ('h', 500 + 10))),     # boundary inside a wave / workgroup
+    (256, 700, (('h', 3),)),                                                  # prefix = exactly one workgroup
+    (5, 64, ()),
+])
+def test_constant_prefix_matches_concatenation_and_oracle(dev, nS, nH, big_at):
+    """ExaRasterBackwardJob.grad_first (the detached scene of ExAvatar's composite renders, model.py:119-126): the
+    image equals the plain concatenated render bit for bit, the trainable Gaussians' gradients to rounding (same source,
+    but the prefix-aware backward kernels are their own instantiations: multiply-adds may be contracted differently),
+    the constants get no gradient, and everything agrees with the oracle."""
+    H, W, f = 128, 160, 170.0
+    (s1, h1, o1), (s2, h2, o2), (h3, ref) = _frozen_case(dev, nS, nH, H, W, f, 300 + nS % 97, big_at)
+    assert torch.equal(o1['img'], o2['img']) and torch.equal(o1['mask'], o2['mask'])
+    assert torch.equal(o1['radius'], o2['radius']) and o1['radius'].shape[0] == nS + nH
+    assert o1['mean_2d'].shape == (nH, 3)
+    assert all(s1[k].grad is None for k in KEYS)
+    for k in KEYS:
+        _assert_same_to_rounding(h1[k].grad, h2[k].grad, k)
+    _assert_same_to_rounding(o1['mean_2d'].grad, o2['mean_2d'].grad[nS:], 'mean_2d')
+    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W)
+    assert_image_close(o1['img'], ref['img'], amb, 'img')
+    assert torch.equal(o1['radius'].cpu(), ref['radius'])
+    near = gaussians_near_pixels(ref['aux']['pre'], amb)[nS:]
+    for k in KEYS:
+        assert_grads_close(h1[k].grad, h3[k].grad, k, near,
+                           abs_scale=rotation_grad_scale(h3['scale'], h3['scale'].grad) if k == 'rotation' else 0.0)
+    assert_grads_close(o1['mean_2d'].grad, ref['mean_2d'].grad[nS:], 'mean_2d', near)
+
+
+def test_render_iteration_equals_the_reference_formulation(dev):
+    """render_iteration (scene sets shared by the five renders of model.py:119-167, constant scene prefix in the two
+    composites) against the reference's own formulation -- five sequential renders with torch.cat((scene.detach(),
+    human)): images and radii bit for bit, gradients to rounding (see above)."""
+    H, W, f = 128, 160, 170.0
+    scene = scenes.dist_a_random(3000, H, W, seed=51, focal=f)
+    human = scenes.dist_a_random(1500, H, W, seed=52, focal=f, z_range=(2.0, 4.0))
+    refined = {k: (v + 0.01 * torch.randn(v.shape, generator=torch.Generator().manual_seed(53)) if k == 'mean_3d' else v.clone())
+               for k, v in human.items()}
+    cam = {k: t.to(dev) for k, t in scenes.neutral_camera(H, W, focal=f).items()}
+    bg = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    g = torch.Generator().manual_seed(54)
+    G = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(5)]
+    rend = exa.GaussianRenderer()
+
+    def run(shared_sets):
+        s, h, r = _to(scene, dev), _to(human, dev), _to(refined, dev)
+        if shared_sets:
+            res = exa.render_iteration(rend, s, h, r, (H, W), cam, bg)
+            outs = [res[k] for k in exa.ITERATION_RENDERS]
+        else:
+            cat = lambda a_, b_: {k: torch.cat((a_[k].detach(), b_[k])) for k in KEYS}
+            jobs = [(s, (H, W), cam), (h, (H, W), cam, bg), (cat(s, h), (H, W), cam), (r, (H, W), cam, bg), (cat(s, r), (H, W), cam)]
+            outs = [rend(*j) for j in jobs]
+        sum((o['img'] * Gi).sum() + o['mask'].sum() for o, Gi in zip(outs, G)).backward()
+        torch.cuda.synchronize()
+        grads = [t[k].grad.clone() for t in (s, h, r) for k in KEYS] + [outs[0]['mean_2d'].grad.clone()]
+        return [o['img'].detach().clone() for o in outs] + [o['radius'].clone() for o in outs], grads
+
+    imgs_a, grads_a = run(False)
+    imgs_b, grads_b = run(True)
+    for x, y in zip(imgs_a, imgs_b):
+        assert torch.equal(x, y)
+    for i, (x, y) in enumerate(zip(grads_a, grads_b)):     # all five jobs of the batched call run the prefix-aware kernels
+        _assert_same_to_rounding(y, x, 'grad %d' % i)
+
+
 def test_last_partial_wave_with_large_gaussian(dev):
     """P % 64 != 0 with a splat of >= 64 sub-tiles at index P - 1 (where densification appends): the per-Gaussian
     backward fetches such a splat's partial sums with the WHOLE wave, so the lanes past P must take part."""

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 110
+    assert lib.exa_raster_version() == 120
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
@@ -85,7 +85,8 @@ def test_batch_job_structs_match_c_layout():
     # LP64: pointer, 2 x int32, then 8-byte fields only
     assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8
     assert _lib.ExaRasterForwardJob.capacity.offset == 104 and _lib.ExaRasterForwardJob.out_color.offset == 112
-    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8
+    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8 + 8
+    assert _lib.ExaRasterBackwardJob.grad_first.offset == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8
     assert _lib.ExaRasterBackwardJob.grad_ws.offset == 136
     lib = _lib.load()
     # argument validation of the batched entry points, no GPU touched

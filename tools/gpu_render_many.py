@@ -9,7 +9,10 @@ from oracle import raster_oracle as ro   # densify_stats_reference only (the PyT
 
 dev = torch.device('cuda:0'); H = W = 1024
 KEYS = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
-scene = {k: v.to(dev).requires_grad_(True) for k, v in scenes.dist_b_avatar(100000, seed=1).items()}
+if os.environ.get('EXA_SCENE', 'avatar') == 'scene':      # a real background (Dist-C) instead of a second body
+    scene = {k: v.to(dev).requires_grad_(True) for k, v in scenes.dist_c_scene(100000, H, W, seed=1).items()}
+else:
+    scene = {k: v.to(dev).requires_grad_(True) for k, v in scenes.dist_b_avatar(100000, seed=1).items()}
 human = {k: v.to(dev).requires_grad_(True) for k, v in scenes.dist_b_avatar(50000, seed=2).items()}
 refined = {k: v.detach().clone().requires_grad_(True) for k, v in human.items()}
 cam = {k: t.to(dev) for k, t in scenes.ring_camera(H, W, 7, 200).items()}
@@ -20,9 +23,13 @@ rend = exa.GaussianRenderer()
 
 
 def iteration(concurrent):
-    jobs = [(scene, (H, W), cam), (human, (H, W), cam, bg), (cat(scene, human), (H, W), cam), (refined, (H, W), cam, bg),
-            (cat(scene, refined), (H, W), cam)]
-    outs = exa.render_many(rend, jobs) if concurrent else [rend(*j) for j in jobs]
+    if concurrent == 'sets':          # Gaussian sets shared between the renders, constant scene prefix in the composites
+        res = exa.render_iteration(rend, scene, human, refined, (H, W), cam, bg)
+        outs = [res[k] for k in exa.ITERATION_RENDERS]
+    else:
+        jobs = [(scene, (H, W), cam), (human, (H, W), cam, bg), (cat(scene, human), (H, W), cam), (refined, (H, W), cam, bg),
+                (cat(scene, refined), (H, W), cam)]
+        outs = exa.render_many(rend, jobs) if concurrent else [rend(*j) for j in jobs]
     loss = sum((o['img'] * G).sum() for o in outs)
     for t in (scene, human, refined):
         for v in t.values():
@@ -33,7 +40,7 @@ def iteration(concurrent):
 
 for mode in ('exact', 'auto'):
     exa.config.mode = mode
-    for conc in (False, True):
+    for conc in (False, True, 'sets'):
         for _ in range(60):          # long warm-up: the first phase after a protocol switch measured slow for dozens of iterations
             iteration(conc)
             torch.cuda.synchronize()
@@ -42,7 +49,7 @@ for mode in ('exact', 'auto'):
         for _ in range(n):
             iteration(conc)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-        print('5 renders fwd+bwd, mode %-8s %-10s: %.3f ms / iteration' % (mode, 'batched' if conc else 'sequential', dt * 1e3))
+        print('5 renders fwd+bwd, mode %-8s %-10s: %.3f ms / iteration' % (mode, {False: 'sequential', True: 'batched', 'sets': 'sets'}[conc], dt * 1e3))
 exa.check_overflow()
 
 outs = iteration(False)
