@@ -511,7 +511,47 @@ def rccl_world1_smoke(device):
         return {'ok': False, 'error': str(e)[:200]}
 
 
-def cpu_baseline(cfg_name, assets, shape, train, target_instances=40_000, max_threads=16):
+def cpu_baseline(cfg_name, assets, shape, train, max_threads=64):
+    """CPU baseline (kind "port"): the C restatement of the rasterizer (oracle/c/raster_oracle.c -- sequential per-pixel
+    loops in the shape upstream has them, OpenMP over Gaussians / tiles) on the SAME workload: ring view 0 of the config
+    in full, forward + backward with the same dense dL/dimage (forward only for `--mode forward`), median of three runs
+    after one warm-up, on min(host threads, 64) threads.  Falls back to the (much slower) PyTorch oracle on a bounded
+    sample when the C library cannot be built."""
+    try:
+        from oracle import c_oracle as co
+        co.load()
+    except Exception as e:  # noqa: BLE001 -- no gcc on this host: time the PyTorch oracle instead
+        res = cpu_baseline_torch(cfg_name, assets, shape, train)
+        res['sample'] += ' [C oracle unavailable: %s]' % str(e)[:80]
+        return res
+    from exavatar_release_amd import scenes
+    from oracle import raster_oracle as ro
+    H, W = shape
+    focal = 1500.0 * (H / 1024.0) if cfg_name != 'c2' else 1500.0 * 960 / 1024
+    cam = scenes.neutral_camera(H, W) if cfg_name == 'c1' else scenes.ring_camera(H, W, 0, N_VIEWS, focal=focal)
+    G = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)) if train else None
+    use_sh = 'sh' in assets
+    so = ro.settings_from_camera(cam, shape, torch.ones(3), 3 if use_sh else 0)
+    cores = max(1, min(os.cpu_count() or 1, max_threads))
+    co.set_num_threads(cores)
+
+    def run():
+        t0 = time.perf_counter()
+        r = co.rasterize(assets['mean_3d'], assets['opacity'], shs=assets['sh'] if use_sh else None,
+                         colors_precomp=None if use_sh else assets['rgb'], scales=assets['scale'],
+                         rotations=assets['rotation'], settings=so, dL_dcolor=G)
+        return time.perf_counter() - t0, r['num_rendered']
+    run()
+    times = sorted(run()[0] for _ in range(3))
+    D = run()[1]
+    t_med = times[1]
+    return {'value': 1.0 / t_med, 'unit': 'iters/s', 'cores': cores, 'kind': 'port',
+            'sample': 'C restatement of the rasterizer (oracle/c, gcc -O2 + OpenMP) %s of view 0 in full (%d 16x16-tile '
+                      'instances) on %d of %d host threads: median of 3 runs %.3f s (min %.3f s)'
+                      % ('fwd+bwd' if train else 'forward', D, cores, os.cpu_count() or 1, t_med, times[0])}
+
+
+def cpu_baseline_torch(cfg_name, assets, shape, train, target_instances=40_000, max_threads=16):
     """Times oracle/raster_oracle.py (fwd + autograd bwd, float32; forward only for `--mode forward`) on a bounded
     sample: the full per-Gaussian stage plus the tiles nearest the image centre holding ~``target_instances`` tile
     instances; the per-tile part is scaled by the instance fraction.  Threads are capped at ``max_threads``

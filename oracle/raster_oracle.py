@@ -29,7 +29,7 @@ stop when T (1 - alpha) < 1e-4.  Outputs (step 10): color = C + T bg, depth = su
 alpha = 1 - T, radii.
 
 Backward = torch.autograd of the forward with the rules of SURVEY.md 8(c): discrete decisions are
-constants, ``min(0.99, .)`` is straight-through, the fov clamp zeroes its gradient when active,
+constants, ``min(0.99, .)`` is straight-through, a clamped ``t.x`` / ``t.y`` is a constant (upstream's ``x_grad_mul``),
 the conic's backward carries upstream's ``1 / (det^2 + 1e-7)`` (``_ConicFromCov2D``),
 ``means2D`` is added to the NDC position so its gradient is d L / d pix * (W/2, H/2).
 """
@@ -213,8 +213,15 @@ def preprocess(means3D, means2D, opacities, scales, rotations, cov3D_precomp, s:
     limx = 1.3 * tanx
     limy = 1.3 * tany
     tz = pvz
-    tx = torch.minimum(limx, torch.maximum(-limx, pvx / tz)) * tz
-    ty = torch.minimum(limy, torch.maximum(-limy, pvy / tz)) * tz
+    txtz, tytz = pvx / tz, pvy / tz
+    tx = torch.minimum(limx, torch.maximum(-limx, txtz)) * tz
+    ty = torch.minimum(limy, torch.maximum(-limy, tytz)) * tz
+    # upstream's backward (computeCov2DCUDA) differentiates J with respect to an INDEPENDENT (t.x, t.y, t.z) and
+    # multiplies dL/dt.x (dL/dt.y) by 0 when the clamp is active ("x_grad_mul"): a clamped t.x is a constant, also
+    # with respect to t.z.  Plain autograd of `clamp(t.x / t.z) * t.z` would keep d t.x / d t.z = +-1.3 tanfov.
+    # (Unclamped: d/dt.x = 1 and d/dt.z = 0 either way.)
+    tx = torch.where((txtz < -limx) | (txtz > limx), tx.detach(), tx)
+    ty = torch.where((tytz < -limy) | (tytz > limy), ty.detach(), ty)
     J00 = focal_x / tz
     J02 = -(focal_x * tx) / (tz * tz)
     J11 = focal_y / tz

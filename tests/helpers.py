@@ -125,3 +125,23 @@ def record_stats(tag, stats):
     if os.path.isdir(d):
         with open(os.path.join(d, 'parity_stats.jsonl'), 'a') as f:
             f.write(json.dumps({'tag': tag, **stats}) + '\n')
+
+
+def clamped_scene(H, W, f):
+    """400 random Gaussians, the first 40 large ones 35-65 % outside the frustum: the +-1.3 tanfov clamp is active
+    for them and they still reach into the image (non-zero gradients)."""
+    from exavatar_release_amd import scenes
+    a = scenes.dist_a_random(400, H, W, seed=5, focal=f)
+    g = torch.Generator().manual_seed(9)
+    for i in range(40):
+        z = 3.0 + torch.rand(1, generator=g).item()
+        side = 1 if i % 2 else -1
+        if i % 4 < 2:
+            u = side * (0.5 * W / f) * (1.35 + 0.3 * torch.rand(1, generator=g).item())
+            a['mean_3d'][i] = torch.tensor([u * z, 0.1 * side, z])
+        else:
+            u = side * (0.5 * H / f) * (1.4 + 0.2 * torch.rand(1, generator=g).item())
+            a['mean_3d'][i] = torch.tensor([0.1 * side, u * z, z])
+        a['scale'][i] = torch.tensor([0.5, 0.45, 0.4])
+        a['opacity'][i] = 0.6
+    return a

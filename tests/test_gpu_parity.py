@@ -12,7 +12,8 @@ import exavatar_release_amd as exa
 from exavatar_release_amd import scenes
 from exavatar_release_amd.camera import make_raster_matrices
 from oracle import raster_oracle as ro
-from tests.helpers import assert_grads_close, assert_image_close, gaussians_near_pixels, rotation_grad_scale
+from tests.helpers import (assert_grads_close, assert_image_close, clamped_scene, gaussians_near_pixels,
+                           rotation_grad_scale)
 
 pytestmark = pytest.mark.gpu
 
@@ -111,6 +112,18 @@ def test_large_and_offscreen_gaussians(dev):
     g = torch.Generator().manual_seed(5)
     out, ref = _cmp_render(a, (H, W), cam, torch.rand(3, generator=g), dev, torch.randn(3, H, W, generator=g))
     assert int((out['radius'][40:60] > 0).sum()) == 0
+
+
+def test_clamped_gaussians_follow_upstreams_x_grad_mul(dev):
+    """Large Gaussians 35-65 % outside the frustum: the +-1.3 tanfov clamp of the EWA projection is active and they
+    still reach into the image.  Upstream's backward treats the clamped t.x (t.y) as a constant -- also with respect
+    to t.z -- and so do the kernel and both oracles (tests/test_c_oracle.py); plain autograd of the clamp would move
+    dL/dmean of such a Gaussian by up to 9 %, far outside the per-Gaussian bar checked here."""
+    H, W, f = 96, 128, 150.0
+    a = clamped_scene(H, W, f)
+    g = torch.Generator().manual_seed(9)
+    _cmp_render(a, (H, W), scenes.neutral_camera(H, W, focal=f), torch.rand(3, generator=g), dev,
+                torch.randn(3, H, W, generator=g))
 
 
 @pytest.mark.parametrize('n_deep,o_min', [(1500, 0.004), (2600, 0.008)])
