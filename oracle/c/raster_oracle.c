@@ -379,13 +379,15 @@ static void preprocess_backward_one(const OrcSettings* s, int idx, int sh_M, con
  * Forward (+ backward when dL_dcolor != NULL).  All pointers are host memory, float32 / int32, contiguous, shapes as the
  * reference passes them (module.py:632-640).  Optional (NULL = skip): shs xor colors_precomp, (scales + rotations) xor
  * cov3D_precomp, out_final_T [H*W], out_n_contrib [H*W] (1-based index of the last blended list entry, upstream's
- * n_contrib), dL_ddepth, dL_dalpha, every gradient output.  Returns the number of (Gaussian, 16x16 tile) instances
+ * n_contrib), out_margin [H*W] (relative distance of the pixel's closest discrete decision -- alpha >= 1/255, T < 1e-4,
+ * power > 0 -- to its threshold, the quantity oracle/raster_oracle.py::ambiguous_pixel_mask thresholds at 1e-4: two fp32
+ * implementations may legitimately differ at such a pixel), dL_ddepth, dL_dalpha, every gradient output.  Returns the number of (Gaussian, 16x16 tile) instances
  * (upstream's num_rendered), < 0 on a bad argument / allocation failure.
  */
 long exa_oracle_render(const OrcSettings* s, int32_t P, int32_t sh_M, const float* means3D, const float* shs,
                        const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
                        const float* cov3D_precomp, float* out_color, float* out_depth, float* out_alpha, int32_t* radii,
-                       float* out_final_T, int32_t* out_n_contrib, const float* dL_dcolor, const float* dL_ddepth,
+                       float* out_final_T, int32_t* out_n_contrib, float* out_margin, const float* dL_dcolor, const float* dL_ddepth,
                        const float* dL_dalpha, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dcolors,
                        float* dL_dopacity, float* dL_dscales, float* dL_drotations, float* dL_dsh, float* dL_dcov3D) {
     if (!s || P < 0 || (P > 0 && (!means3D || !opacities))) return -1;
@@ -447,17 +449,20 @@ long exa_oracle_render(const OrcSettings* s, int32_t P, int32_t sh_M, const floa
         const long n = tile_off[t + 1] - tile_off[t];
         for (int j = ty * TILE; j < ty * TILE + TILE && j < H; ++j)
             for (int i = tx * TILE; i < tx * TILE + TILE && i < W; ++i) {
-                float T = 1.0f, C[3] = {0.f, 0.f, 0.f}, Dp = 0.f;
+                float T = 1.0f, C[3] = {0.f, 0.f, 0.f}, Dp = 0.f, margin = INFINITY;
                 int32_t last = 0;
                 const float fx = (float)i, fy = (float)j;
                 for (long k = 0; k < n; ++k) {
                     const Geo* g = &geo[list[k].id];
                     float dx, dy;
                     const float power = gauss_power(g, fx, fy, &dx, &dy);
+                    if (out_margin && fabsf(power) <= 1e-6f) margin = fminf(margin, fabsf(power));
                     if (power > 0.0f) continue;
                     const float alpha = fminf(ALPHA_MAX, g->opacity * expf(power));
+                    if (out_margin) margin = fminf(margin, fabsf(alpha - ALPHA_MIN) * 255.0f);
                     if (alpha < ALPHA_MIN) continue;
                     const float test_T = T * (1.0f - alpha);
+                    if (out_margin) margin = fminf(margin, fabsf(test_T - T_EPS) / T_EPS);
                     if (test_T < T_EPS) break;                   /* this Gaussian is NOT blended */
                     const float w = alpha * T;
                     C[0] += g->col[0] * w; C[1] += g->col[1] * w; C[2] += g->col[2] * w;
@@ -473,6 +478,7 @@ long exa_oracle_render(const OrcSettings* s, int32_t P, int32_t sh_M, const floa
                 out_alpha[pix] = 1.0f - T;
                 final_T[pix] = T;
                 n_contrib[pix] = last;
+                if (out_margin) out_margin[pix] = margin;
             }
     }
 

@@ -46,7 +46,7 @@ def load(build=True):
     lib = ctypes.CDLL(LIB_PATH)
     p = ctypes.c_void_p
     lib.exa_oracle_render.restype = ctypes.c_long
-    lib.exa_oracle_render.argtypes = [ctypes.POINTER(OrcSettings), ctypes.c_int32, ctypes.c_int32] + [p] * 24
+    lib.exa_oracle_render.argtypes = [ctypes.POINTER(OrcSettings), ctypes.c_int32, ctypes.c_int32] + [p] * 25
     lib.exa_oracle_num_threads.restype = ctypes.c_int
     lib.exa_oracle_set_num_threads.argtypes = [ctypes.c_int]
     _lib = lib
@@ -90,7 +90,8 @@ def rasterize(means3D, opacities, shs=None, colors_precomp=None, scales=None, ro
     ``GaussianRasterizationSettings``) with CPU tensors.
 
     Returns a dict: ``color [3,H,W]``, ``depth [1,H,W]``, ``alpha [1,H,W]``, ``radii [P] int32``, ``final_T [H,W]``,
-    ``n_contrib [H,W] int32``, ``num_rendered`` and -- when ``dL_dcolor`` is given -- ``grads``: a dict with
+    ``n_contrib [H,W] int32``, ``pixel_margin [H,W]`` (``ambiguous = pixel_margin < 1e-4``, the mask
+    ``oracle.raster_oracle.ambiguous_pixel_mask`` computes), ``num_rendered`` and -- when ``dL_dcolor`` is given -- ``grads``: a dict with
     ``means2D, means3D, opacities`` and whichever of ``colors_precomp / shs``, ``scales + rotations / cov3D_precomp``
     apply (same shapes as the inputs).
     """
@@ -107,6 +108,7 @@ def rasterize(means3D, opacities, shs=None, colors_precomp=None, scales=None, ro
     radii = np.zeros((P,), np.int32)
     final_T = np.empty((H, W), np.float32)
     n_contrib = np.empty((H, W), np.int32)
+    margin = np.empty((H, W), np.float32)
     gc, gd, ga = _f32(dL_dcolor), _f32(dL_ddepth), _f32(dL_dalpha)
     grads = {}
     if gc is not None:
@@ -124,14 +126,14 @@ def rasterize(means3D, opacities, shs=None, colors_precomp=None, scales=None, ro
     g = grads.get
     D = lib.exa_oracle_render(ctypes.byref(st), P, sh_M, _ptr(m3), _ptr(sh), _ptr(col), _ptr(op), _ptr(sc), _ptr(rot),
                               _ptr(cov), _ptr(color), _ptr(depth), _ptr(alpha), _ptr(radii), _ptr(final_T),
-                              _ptr(n_contrib), _ptr(gc), _ptr(gd), _ptr(ga), _ptr(g('means2D')), _ptr(g('means3D')),
+                              _ptr(n_contrib), _ptr(margin), _ptr(gc), _ptr(gd), _ptr(ga), _ptr(g('means2D')), _ptr(g('means3D')),
                               _ptr(g('colors_precomp')), _ptr(g('opacities')), _ptr(g('scales')), _ptr(g('rotations')),
                               _ptr(g('shs')), _ptr(g('cov3D_precomp')))
     if D < 0:
         raise RuntimeError('exa_oracle_render failed with status %d' % D)
     out = {'color': torch.from_numpy(color), 'depth': torch.from_numpy(depth), 'alpha': torch.from_numpy(alpha),
            'radii': torch.from_numpy(radii), 'final_T': torch.from_numpy(final_T),
-           'n_contrib': torch.from_numpy(n_contrib), 'num_rendered': int(D)}
+           'n_contrib': torch.from_numpy(n_contrib), 'pixel_margin': torch.from_numpy(margin), 'num_rendered': int(D)}
     if gc is not None:
         out['grads'] = {k: torch.from_numpy(v) for k, v in grads.items()}
     return out
@@ -148,7 +150,8 @@ def render(gaussian_assets, img_shape, cam_param, bg=None, dL_dimg=None, dL_ddep
                   scales=gaussian_assets['scale'], rotations=gaussian_assets['rotation'], settings=s,
                   dL_dcolor=dL_dimg, dL_ddepth=dL_ddepth, dL_dalpha=dL_dalpha)
     out = {'img': r['color'], 'depthmap': r['depth'], 'mask': r['alpha'], 'radius': r['radii'], 'is_vis': r['radii'] > 0,
-           'final_T': r['final_T'], 'n_contrib': r['n_contrib'], 'num_rendered': r['num_rendered']}
+           'final_T': r['final_T'], 'n_contrib': r['n_contrib'], 'pixel_margin': r['pixel_margin'],
+           'num_rendered': r['num_rendered']}
     if 'grads' in r:
         gr = r['grads']
         out['grads'] = {'mean_3d': gr['means3D'], 'scale': gr['scales'], 'rotation': gr['rotations'],

@@ -53,6 +53,10 @@ def _assert_agree(t, r, c, H, W, per_gaussian_tol=None):
     differ = c['n_contrib'] != r['aux']['n_contrib']
     assert not bool((differ & ~amb).any())
     assert torch.allclose(c['final_T'][~amb], r['aux']['final_T'][~amb], atol=1e-6)
+    # the ambiguity margins themselves (what the GPU parity tests mask with): the same pixels up to those whose margin
+    # sits within 5 % of the 1e-4 bar in either implementation
+    m_c, m_p = c['pixel_margin'], r['aux']['pixel_margin']
+    assert not bool((((m_c < 1e-4) ^ amb) & ((m_p - 1e-4).abs() > 5e-6)).any())
     for k, rk in (('img', 'img'), ('depthmap', 'depthmap'), ('mask', 'mask')):
         d = (c[k] - r[rk].detach()).abs().amax(0)
         assert float(d[~amb].max()) <= IMG_TOL, k

@@ -11,6 +11,7 @@ import torch
 import exavatar_release_amd as exa
 from exavatar_release_amd import scenes
 from exavatar_release_amd.camera import make_raster_matrices
+from oracle import c_oracle as co
 from oracle import raster_oracle as ro
 from tests.helpers import (assert_grads_close, assert_image_close, gaussians_near_pixels, rotation_grad_scale, grad_stats, image_stats,
                            record_stats)
@@ -76,6 +77,42 @@ def test_c3_full_size_parity_with_oracle(dev, P, view, budget):
     shape = (1024, 1024)
     _full_parity('c3_P%d_view%d' % (P, view), scenes.dist_b_avatar(P, seed=0), shape,
                  scenes.ring_camera(1024, 1024, view, 200), dev, budget)
+
+
+@pytest.mark.parametrize('view', [5, 61, 88, 140, 171, 199])
+def test_c3_ring_views_against_the_c_oracle(dev, view):
+    """The headline workload on six more of the 200 ring views, against the C restatement of the rasterizer
+    (oracle/c: 0.1-0.3 s per fwd+bwd view instead of 3-6 s, so breadth is affordable; tests/test_c_oracle.py holds it
+    against the PyTorch oracle to 1e-6 incl. the ambiguity margins).  Same bars as above."""
+    H = W = 1024
+    assets = scenes.dist_b_avatar(150_000, seed=0)
+    cam = scenes.ring_camera(H, W, view, 200)
+    g = torch.Generator().manual_seed(100 + view)
+    G, bg = torch.randn(3, H, W, generator=g), torch.rand(3, generator=g)
+    a_gpu = {k: v.to(dev).requires_grad_(True) for k, v in assets.items()}
+    out = exa.GaussianRenderer()(a_gpu, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    (out['img'] * G.to(dev)).sum().backward()
+    ref = co.render(assets, (H, W), cam, bg, dL_dimg=G)
+    amb = ref['pixel_margin'] < 1e-4
+    stats = {'P': 150_000, 'H': H, 'W': W}
+    for name, got, want in (('img', out['img'], ref['img']), ('depth', out['depthmap'], ref['depthmap']),
+                            ('alpha', out['mask'], ref['mask'])):
+        stats[name] = image_stats(got, want, amb)
+        assert_image_close(None, None, amb, name, 600, stats=stats[name])
+    stats['radii_equal'] = bool(torch.equal(out['radius'].cpu(), ref['radius']))
+    assert stats['radii_equal'], 'radii differ'
+    with torch.no_grad():
+        so = ro.settings_from_camera(cam, (H, W), bg)
+        pre = ro.preprocess(assets['mean_3d'], None, assets['opacity'], assets['scale'], assets['rotation'], None, so,
+                            torch.float32)
+    near = gaussians_near_pixels(pre, amb)
+    scale_ref = ref['grads']['scale']
+    for k in KEYS + ('mean_2d',):
+        got = a_gpu[k].grad if k != 'mean_2d' else out['mean_2d'].grad
+        st = assert_grads_close(got, ref['grads'][k], k, near,
+                                abs_scale=rotation_grad_scale(assets['scale'], scale_ref) if k == 'rotation' else 0.0)
+        stats['grad_' + k] = st
+    record_stats('c3_view%d_vs_c_oracle' % view, stats)
 
 
 @pytest.mark.parametrize('name,budget', [('c2', 400), ('c2l', 160)])
