@@ -18,7 +18,8 @@ context stored), hipGraph-captured -- the animation / inference use case of avat
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: `roofline` (dominant kernel,
 HIP-event timed inside this script), `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
 workload, rank 0 at N = 1 only), `extra_batched_views` (K views per batched launch, next to -- never instead of --
-the single-view headline) and `extra_views_in_flight` (independent views on separate streams).
+the single-view headline), `extra_views_in_flight` (independent views on separate streams) and `extra_exavatar_iteration`
+(the five same-camera renders of one ExAvatar training sample, eager, three ways).
 """
 import argparse
 import json
@@ -331,6 +332,13 @@ def main():
                 result[name] = {'error': str(e)[:200]}
         exa.check_overflow()
 
+    # ---- extra: one ExAvatar training sample = five same-camera renders fwd + bwd (model.py:119-167), eager ----
+    if rank == 0 and single and not args.no_concurrent and args.config == 'c3' and train:
+        try:
+            result['extra_exavatar_iteration'] = iteration_throughput(device)
+        except Exception as e:  # noqa: BLE001
+            result['extra_exavatar_iteration'] = {'error': str(e)[:200]}
+
     # ---- per-kernel HIP-event timing (eager, on torch's stream = the stream the kernels run on) -----
     if rank == 0 and not args.no_kernel_timing:
         c1 = make_ctx(1)
@@ -428,6 +436,59 @@ def _timed_replays(ctxs, args, set_view, units_per_step):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return n * units_per_step / dt, dt / n * 1e3
+
+
+def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024, iters=30):
+    """The five renders of one ExAvatar training sample -- scene, human, scene + human, refined human, scene + refined
+    human (avatar/main/model.py:119-167; SURVEY.md 8d "ExAvatar-iteration equivalents") -- forward + backward through
+    the drop-in Python surface, EAGER (no hipGraph: the real model's P changes with densification), three ways:
+    five sequential GaussianRenderer calls on torch.cat((scene.detach(), human)) as the reference writes it, the same
+    five as one batched call (render_many), and render_iteration (Gaussian sets shared, detached scene as a constant
+    prefix of the composites).  100 k Dist-C scene + 50 k avatar-like human Gaussians at 1024 x 1024."""
+    import exavatar_release_amd as exa
+    from exavatar_release_amd import scenes
+    keys = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
+    saved = (exa.config.mode, exa.config.fixed_capacity)
+    exa.config.mode, exa.config.fixed_capacity = 'auto', None
+    try:
+        scene = {k: v.to(device).requires_grad_(True) for k, v in scenes.dist_c_scene(n_scene, H, W, seed=1).items()}
+        human = {k: v.to(device).requires_grad_(True) for k, v in scenes.dist_b_avatar(n_human, seed=2).items()}
+        refined = {k: v.detach().clone().requires_grad_(True) for k, v in human.items()}
+        cam = {k: t.to(device) for k, t in scenes.ring_camera(H, W, 7, N_VIEWS).items()}
+        bg = torch.rand(3, device=device)
+        G = torch.randn(3, H, W, device=device)
+        rend = exa.GaussianRenderer()
+        cat = lambda a, b: {k: torch.cat((a[k].detach(), b[k])) for k in keys}      # noqa: E731
+
+        def iteration(how):
+            if how == 'sets':
+                res = exa.render_iteration(rend, scene, human, refined, (H, W), cam, bg)
+                outs = [res[k] for k in exa.ITERATION_RENDERS]
+            else:
+                jobs = [(scene, (H, W), cam), (human, (H, W), cam, bg), (cat(scene, human), (H, W), cam),
+                        (refined, (H, W), cam, bg), (cat(scene, refined), (H, W), cam)]
+                outs = exa.render_many(rend, jobs) if how == 'batched' else [rend(*j) for j in jobs]
+            loss = sum((o['img'] * G).sum() for o in outs)
+            for t in (scene, human, refined):
+                for v in t.values():
+                    v.grad = None
+            loss.backward()
+        out = {'workload': '%d k Dist-C scene + %d k avatar-like human Gaussians, %dx%d, 5 renders fwd+bwd, eager'
+                           % (n_scene // 1000, n_human // 1000, W, H)}
+        for how in ('sequential', 'batched', 'sets'):
+            for _ in range(12):
+                iteration(how)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                iteration(how)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            out[how] = {'ms_per_iteration': ms, 'renders_per_s': 5e3 / ms}
+        exa.check_overflow()
+        return out
+    finally:
+        exa.config.mode, exa.config.fixed_capacity = saved
 
 
 def batched_throughput(K, S, args, make_ctx, set_view, raster_step):
