@@ -13,6 +13,8 @@ for line in open(os.path.join(root, 'gpurun_out', 'parity_stats.jsonl')):
 order = [t for t in ('c3_P150000_view0', 'c3_P150000_view37', 'c3_P167000_view113', 'c2', 'c2l', 'c3s', 'c5_fwd_sh3') if t in rows]
 order += [t for t in rows if t not in order]
 out = ['# %s: HIP path vs CPU oracle at BASELINE.json\'s full sizes (MI355X, `pytest -m gpu tests/test_gpu_fullsize.py`)' % tag, '',
+       'Rows `*_vs_c_oracle` and `c5_fwd_sh3` are checked against the C restatement (oracle/c), the others against the PyTorch oracle; '
+       'the two oracles agree with each other to 1e-6 on these workloads (tests/test_c_oracle.py).', '',
        'Written by the tests themselves (`tests/helpers.record_stats` -> gpurun_out/parity_stats.jsonl, turned into this file by '
        '`tools/make_parity_profile.py`), measured before the asserts.  "ambiguous" = pixels whose alpha >= 1/255, T < 1e-4 or '
        'power > 0 decision lies within 1e-4 (relative) of its threshold in the ORACLE (a property of the scene, identical on any '
