@@ -94,6 +94,7 @@ SIGNATURES = {
     'exa_raster_forward_render_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
     'exa_raster_forward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
     'exa_raster_backward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterBackwardJob), _I32, _I32, c_void_p]),
+    'exa_raster_read_header_async': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),
@@ -129,7 +130,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 120:
+    if lib.exa_raster_version() < 121:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

@@ -401,6 +401,13 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     return exa_raster_backward_batch(&j, 1, 0, stream);
 }
 
+int exa_raster_read_header_async(const void* tile_ws, void* host_dst16, void* stream) {
+    if (!tile_ws || !host_dst16) return fail(EXA_RASTER_E_NULLPTR, "read_header_async: NULL pointer");
+    EXA_HIP(hipMemcpyAsync(host_dst16, tile_ws, 16, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)),
+            "read_header_async");
+    return 0;
+}
+
 int exa_raster_mark_visible(const ExaRasterSettings* s, int32_t P, const float* means3D, uint8_t* present,
                             void* stream) {
     int rc = check_settings(s);

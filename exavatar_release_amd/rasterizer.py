@@ -91,6 +91,23 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CTX = _NoCtx()
+
+
+def _on_device(device):
+    """``torch.cuda.device(device)`` only when it is not the current device already (the context manager costs ~10 us
+    per entry, twice per render, in an eager training loop)."""
+    return _NO_CTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
 def _make_settings(rs, device, keep):
     """ctypes settings struct; tensors it points to are appended to ``keep`` so they stay alive."""
     s = _lib.ExaRasterSettings()
@@ -255,8 +272,9 @@ class _Rasterize(torch.autograd.Function):
                                    'earlier un-captured call of the same shape) before stream capture')
             mode = 'exact'            # first call of this shape: measure D once, like upstream does
 
-        with torch.cuda.device(device):
-            stream = _stream_ptr(device)
+        with _on_device(device):
+            stream_obj = torch.cuda.current_stream(device)
+            stream = ctypes.c_void_p(stream_obj.cuda_stream)
             if mode == 'capacity' and not capturing:
                 _drain_pending()          # event queries are illegal during stream capture
             arr = (_lib.ExaRasterForwardJob * K)()
@@ -310,9 +328,10 @@ class _Rasterize(torch.autograd.Function):
                 _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
                 if not capturing:
                     ev, host = _hdr_slot(K)                      # pinned buffer + event from a small pool
-                    rows = [j.ws[j.gb:j.gb + 16].view(torch.int32) for j in jobs]
-                    host[:K].copy_(rows[0].view(1, 4) if K == 1 else torch.stack(rows), non_blocking=True)
-                    ev.record(torch.cuda.current_stream(device))
+                    hp = host.data_ptr()
+                    for k, j in enumerate(jobs):                 # one runtime call per header: no tensor-library ops
+                        _lib.check(lib.exa_raster_read_header_async(j.tile_ptr, hp + 16 * k, stream))
+                    ev.record(stream_obj)
                     hdr_check = (ev, host, [(j.key, j.capacity) for j in jobs])
                     if not need_ctx:
                         _pending.append(hdr_check)
@@ -362,7 +381,7 @@ class _Rasterize(torch.autograd.Function):
         need = ctx.needs_input_grad[6:]
         arr = (_lib.ExaRasterBackwardJob * K)()
         keep, ret = [], [None, None, None, None, None, None]
-        with torch.cuda.device(device):
+        with _on_device(device):
             for k in range(K):
                 rs, P, H, W, sh_M, cap, gb, tb, st, _skeep, ws, bins, has, nF = ctx.meta[k]
                 Pg = P - nF                               # rows of every gradient array (constant prefix excluded)

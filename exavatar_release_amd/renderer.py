@@ -111,20 +111,11 @@ class GaussianRenderer(nn.Module):
         ``(xyz_grad_accum, track_cnt, radius_max)`` tensors that this render's backward updates in place -- the
         bookkeeping of avatar/main/model.py:279-285 + module.py:155-157 fused into the backward pass."""
         job = _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats)
-        if densify_stats is not None:
-            outs = rasterize_gaussians(job['means3D'], job['means2D'], None, job['colors_precomp'], job['opacities'],
-                                       job['scales'], job['rotations'], None, job['raster_settings'], densify_stats)
-        else:
-            rasterizer = GaussianRasterizer(raster_settings=job['raster_settings'])
-            outs = rasterizer(
-                means3D=job['means3D'],
-                means2D=job['means2D'],
-                shs=None,
-                colors_precomp=job['colors_precomp'],
-                opacities=job['opacities'],
-                scales=job['scales'],
-                rotations=job['rotations'],
-                cov3D_precomp=None)
+        # the reference instantiates GaussianRasterizer(raster_settings) per call (module.py:623) and calls it with
+        # keywords; its forward is exactly this function call (rasterizer.GaussianRasterizer.forward), without building
+        # an nn.Module per render
+        outs = rasterize_gaussians(job['means3D'], job['means2D'], None, job['colors_precomp'], job['opacities'],
+                                   job['scales'], job['rotations'], None, job['raster_settings'], densify_stats)
         return _output_dict(job, outs)
 
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 120          /* 0.1.2: ExaRasterBackwardJob.grad_first (constant leading Gaussians) */
+#define EXA_RASTER_VERSION 121          /* 0.1.2: ExaRasterBackwardJob.grad_first (constant leading Gaussians); .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
 #define EXA_RASTER_E_INVALID (-1)
@@ -198,6 +198,15 @@ int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, voi
 int exa_raster_forward_render_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);
 int exa_raster_forward_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);
 int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32_t sum_shared, void* stream);
+
+/*
+ * Asynchronous read-back of the first 16 bytes of the header (num_rendered, overflow, max_tile_list, num_visible) of a
+ * tile workspace into caller-provided PINNED host memory, enqueued on `stream` behind the forward call: what a binding
+ * does after a fused exa_raster_forward to learn -- later, without a host synchronisation now -- whether the capacity
+ * was enough.  One runtime call instead of a slice + view + copy through the tensor library (~20 us of host time per
+ * render in an eager training loop).  Not capturable in a hipGraph (a memcpy node): callers skip it under capture.
+ */
+int exa_raster_read_header_async(const void* tile_ws, void* host_dst16, void* stream);
 
 /* upstream markVisible: present[i] = (view-space z of means3D[i] > 0.2). */
 int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const float* means3D,

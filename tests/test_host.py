@@ -23,11 +23,11 @@ def _declared_functions():
 def test_library_exports_every_symbol_the_header_declares():
     lib = _lib.load()
     names = _declared_functions()
-    assert len(names) >= 23
+    assert len(names) >= 24
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 120
+    assert lib.exa_raster_version() == 121
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
