@@ -96,6 +96,25 @@ def test_batch_job_structs_match_c_layout():
     assert lib.exa_raster_forward_batch(None, 0, 0, None) == 0
     bj = (_lib.ExaRasterBackwardJob * 1)()
     assert lib.exa_raster_backward_batch(bj, 1, 0, None) == -2
+    # constant prefix: 0 <= grad_first <= P, and never together with sum_shared
+    st = _lib.ExaRasterSettings()
+    st.image_height, st.image_width, st.tanfovx, st.tanfovy = 64, 64, 0.5, 0.5
+    st.bg = st.viewmatrix = st.projmatrix = st.campos = 4096
+    b = bj[0]
+    b.settings = ctypes.pointer(st)
+    b.P = 10
+    for name in ('means3D', 'colors_precomp', 'opacities', 'scales', 'rotations', 'radii', 'geom_ws', 'tile_ws', 'grad_ws',
+                 'dL_dcolor'):
+        setattr(b, name, 4096)
+    b.grad_first = 11
+    assert lib.exa_raster_backward_batch(bj, 1, 0, None) == -1 and b'grad_first' in lib.exa_raster_last_error()
+    b.grad_first = -1
+    assert lib.exa_raster_backward_batch(bj, 1, 0, None) == -1
+    b.grad_first = 3
+    assert lib.exa_raster_backward_batch(bj, 1, 1, None) == -1 and b'sum_shared' in lib.exa_raster_last_error()
+    b.grad_first = 10                     # nothing trainable: a no-op that touches no pointer
+    assert lib.exa_raster_backward_batch(bj, 1, 0, None) == 0
+    assert lib.exa_raster_read_header_async(None, None, None) == -2
 
 
 def test_python_surface_matches_the_reference_plugin():
