@@ -12,8 +12,7 @@ import torch
 import torch.nn as nn
 
 from .camera import make_raster_matrices
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,
-                         rasterize_gaussians_batch)
+from .rasterizer import GaussianRasterizationSettings, rasterize_gaussians, rasterize_gaussians_batch
 
 
 _CAM_KEYS = ('focal', 'princpt', 'R', 't')
@@ -178,7 +177,8 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
     The scene tensors enter the composite renders as constants: no ``torch.cat`` / ``CatBackward`` nodes, and the
     backward of jobs 2 and 4 skips every 64-entry batch that blended no human Gaussian (most of the image), writes no
     partial sums and runs no chain rule for the scene (``ExaRasterBackwardJob.grad_first``).  Images are bit-identical
-    to the reference's formulation through :func:`render_many`; the human gradients too.
+    to the reference's formulation through :func:`render_many`, gradients agree to rounding (the prefix-aware backward
+    kernels are separate instantiations: ~1e-7 relative).
     ``scene_densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` updated by the scene render's backward
     (``model.py:279-285``).  Returns a dict of the five output dicts keyed by :data:`ITERATION_RENDERS`.
     """
