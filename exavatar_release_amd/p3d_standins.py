@@ -10,14 +10,19 @@ non-synthetic configuration from running on MI355X at all.  The reference uses a
   features carried along);
 * ``Meshes(...).verts_normals_packed()`` -- ``module.py:502``, ``smpl_x.py:140``, ``loss.py:156``;
 * ``matrix_to_rotation_6d`` / ``rotation_6d_to_matrix`` / ``matrix_to_quaternion`` / ``quaternion_to_matrix`` /
-  ``axis_angle_to_matrix`` -- ``module.py:4``.
+  ``axis_angle_to_matrix`` / ``matrix_to_axis_angle`` -- ``module.py:4,363-364,680``, ``smpl_x.py:12``;
+* ``look_at_view_transform`` -- the turntable cameras of the forward-only drivers of the renderer
+  (``avatar/main/get_neutral_pose.py:76-82``, ``avatar/main/animate_view_rot.py:93-95``: BASELINE configs[4]'s use case);
+* ``save_obj`` -- ``avatar/main/test.py:11``, ``get_neutral_pose.py:18`` (vertices + faces only).
 
 None of their source is in the reference tree (third-party package, not vendored): the functions below restate the
 PUBLISHED algorithms of pytorch3d (``ops/knn.py``, ``ops/subdivide_meshes.py`` ``subdivide_homogeneous``,
-``structures/meshes.py`` ``_compute_edges_packed`` / ``_compute_vertex_normals``, ``transforms/rotation_conversions.py``)
+``structures/meshes.py`` ``_compute_edges_packed`` / ``_compute_vertex_normals``, ``transforms/rotation_conversions.py``,
+``renderer/cameras.py`` ``look_at_view_transform`` / ``look_at_rotation`` / ``camera_position_from_spherical_angles``)
 with the same argument names, return types and orderings, in plain PyTorch -- they run on ROCm and CPU tensors alike and
 are differentiable wherever pytorch3d's are.  tests/test_standins.py pins them with brute-force and analytic checks.
 """
+import math
 from collections import namedtuple
 from typing import Optional
 
@@ -269,3 +274,104 @@ def rotation_6d_to_matrix(d6):
     b2 = F.normalize(b2, dim=-1)
     b3 = torch.cross(b1, b2, dim=-1)
     return torch.stack((b1, b2, b3), dim=-2)
+
+
+def quaternion_to_axis_angle(quaternions):
+    """Quaternions (w, x, y, z) -> axis-angle vectors (direction = axis, length = angle in radians), with the series
+    expansion of ``sin(angle / 2) / angle`` near zero that pytorch3d uses."""
+    norms = torch.norm(quaternions[..., 1:], p=2, dim=-1, keepdim=True)
+    half_angles = torch.atan2(norms, quaternions[..., :1])
+    angles = 2 * half_angles
+    eps = 1e-6
+    small = angles.abs() < eps
+    sin_half_over_angle = torch.empty_like(angles)
+    sin_half_over_angle[~small] = torch.sin(half_angles[~small]) / angles[~small]
+    sin_half_over_angle[small] = 0.5 - (angles[small] * angles[small]) / 48
+    return quaternions[..., 1:] / sin_half_over_angle
+
+
+def matrix_to_axis_angle(matrix):
+    """Rotation matrices [..., 3, 3] -> axis-angle (reference module.py:363-364,680, smpl_x.py:12)."""
+    return quaternion_to_axis_angle(matrix_to_quaternion(matrix))
+
+
+# ---- cameras (pytorch3d.renderer.cameras): row-vector convention X_cam = X_world @ R + T ---------------------------
+def _rows(x, device, dtype=torch.float32):
+    x = torch.as_tensor(x, dtype=dtype, device=device)
+    return x if x.dim() > 0 else x.view(1)
+
+
+def camera_position_from_spherical_angles(distance, elevation, azimuth, degrees: bool = True, device='cpu'):
+    """Camera centre on a sphere around the origin: +Y up, azimuth measured from +Z towards +X."""
+    dist, elev, azim = (_rows(v, device) for v in (distance, elevation, azimuth))
+    dist, elev, azim = torch.broadcast_tensors(dist.reshape(-1), elev.reshape(-1), azim.reshape(-1))
+    if degrees:
+        elev = math.pi / 180.0 * elev
+        azim = math.pi / 180.0 * azim
+    x = dist * torch.cos(elev) * torch.sin(azim)
+    y = dist * torch.sin(elev)
+    z = dist * torch.cos(elev) * torch.cos(azim)
+    return torch.stack((x, y, z), dim=1)
+
+
+def look_at_rotation(camera_position, at=((0, 0, 0),), up=((0, 1, 0),), device='cpu'):
+    """R [N, 3, 3] whose COLUMNS are the camera's x / y / z axes in world coordinates (z looks from the camera to
+    ``at``; x = up x z; y = z x x; when ``up`` is parallel to z, x is taken as y x z instead, like pytorch3d does)."""
+    cam, at, up = (_rows(v, device) for v in (camera_position, at, up))
+    cam, at, up = torch.broadcast_tensors(cam.reshape(-1, 3), at.reshape(-1, 3), up.reshape(-1, 3))
+    z_axis = F.normalize(at - cam, eps=1e-5)
+    x_axis = F.normalize(torch.cross(up, z_axis, dim=1), eps=1e-5)
+    y_axis = F.normalize(torch.cross(z_axis, x_axis, dim=1), eps=1e-5)
+    is_close = torch.isclose(x_axis, torch.tensor(0.0, device=x_axis.device), atol=5e-3).all(dim=1, keepdim=True)
+    if bool(is_close.any()):
+        replacement = F.normalize(torch.cross(y_axis, z_axis, dim=1), eps=1e-5)
+        x_axis = torch.where(is_close, replacement, x_axis)
+    R = torch.cat((x_axis[:, None, :], y_axis[:, None, :], z_axis[:, None, :]), dim=1)
+    return R.transpose(1, 2)
+
+
+def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, degrees: bool = True, eye=None, at=((0, 0, 0),),
+                           up=((0, 1, 0),), device='cpu'):
+    """``(R [N, 3, 3], T [N, 3])`` of cameras looking at ``at`` from ``eye``, or from the point at distance ``dist``,
+    elevation ``elev`` and azimuth ``azim`` around ``at`` -- pytorch3d's row-vector convention ``X_cam = X_world @ R + T``
+    (so ``T = -R^T C``).  The reference turns it into its column-vector ``cam_param`` with ``R = torch.inverse(R)``
+    (``get_neutral_pose.py:80-82``, ``animate_view_rot.py:93-95``): see :func:`turntable_cam_param`."""
+    if eye is not None:
+        C = _rows(eye, device).reshape(-1, 3)
+        at_t = _rows(at, device).reshape(-1, 3)
+    else:
+        at_t = _rows(at, device).reshape(-1, 3)
+        C = camera_position_from_spherical_angles(dist, elev, azim, degrees=degrees, device=device) + at_t
+    R = look_at_rotation(C, at_t, up, device=device)
+    T = -torch.bmm(R.transpose(1, 2), C.expand(R.shape[0], 3)[:, :, None])[:, :, 0]
+    return R, T
+
+
+def turntable_cam_param(dist, elev, azim, at, focal, princpt, degrees: bool = False):
+    """One ``cam_param`` dict ``{R, t, focal, princpt}`` of the reference's turntable renders, built exactly as
+    ``get_neutral_pose.py:79-82`` does: ``R, t = look_at_view_transform(...); R = torch.inverse(R)``."""
+    at = torch.as_tensor(at, dtype=torch.float32)
+    R, t = look_at_view_transform(dist=dist, elev=elev, azim=azim, degrees=degrees, at=at.reshape(1, 3), up=((0, 1, 0),),
+                                  device=at.device)
+    return {'R': torch.inverse(R)[0], 't': t[0], 'focal': torch.as_tensor(focal, dtype=torch.float32, device=at.device),
+            'princpt': torch.as_tensor(princpt, dtype=torch.float32, device=at.device)}
+
+
+def save_obj(f, verts, faces, decimal_places: Optional[int] = None):
+    """Wavefront OBJ with vertices and (1-based) triangle indices, the subset of ``pytorch3d.io.save_obj`` the
+    reference uses (``avatar/main/test.py``, ``get_neutral_pose.py``): ``save_obj(path, verts [V, 3], faces [F, 3])``."""
+    verts = torch.as_tensor(verts).detach().cpu()
+    faces = torch.as_tensor(faces).detach().cpu()
+    if verts.dim() != 2 or verts.shape[1] != 3:
+        raise ValueError("Argument 'verts' should either be empty or of shape (num_verts, 3).")
+    if faces.numel() and (faces.dim() != 2 or faces.shape[1] != 3):
+        raise ValueError("Argument 'faces' should either be empty or of shape (num_faces, 3).")
+    fmt = '%f' if decimal_places is None else '%%.%df' % decimal_places
+    lines = ['v ' + ' '.join(fmt % float(c) for c in v) for v in verts.tolist()]
+    lines += ['f ' + ' '.join(str(int(i) + 1) for i in tri) for tri in faces.tolist()]
+    text = '\n'.join(lines) + ('\n' if lines else '')
+    if hasattr(f, 'write'):
+        f.write(text)
+    else:
+        with open(f, 'w') as fh:
+            fh.write(text)

@@ -120,3 +120,79 @@ def test_rotation_conversions_round_trip():
     assert d6.shape == (50, 6) and torch.allclose(p3d.rotation_6d_to_matrix(d6), R, atol=1e-5)
     # module.py:90: identity -> 6D (1, 0, 0, 0, 1, 0)
     assert p3d.matrix_to_rotation_6d(torch.eye(3)[None]).tolist() == [[1.0, 0.0, 0.0, 0.0, 1.0, 0.0]]
+
+
+def test_matrix_to_axis_angle_round_trip_and_reference_usage():
+    g = torch.Generator().manual_seed(4)
+    aa = torch.randn(64, 3, generator=g)
+    aa = aa / aa.norm(dim=1, keepdim=True) * (torch.rand(64, 1, generator=g) * 3.0 + 0.01)      # angles in (0, pi)
+    back = p3d.matrix_to_axis_angle(p3d.axis_angle_to_matrix(aa))
+    assert torch.allclose(back, aa, atol=1e-5)
+    # module.py:363-364: the inverse pose = the negated axis-angle
+    inv = p3d.matrix_to_axis_angle(torch.inverse(p3d.axis_angle_to_matrix(aa)))
+    assert torch.allclose(inv, -aa, atol=1e-5)
+    # tiny rotations go through the series branch
+    tiny = torch.tensor([[1e-8, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    assert torch.allclose(p3d.matrix_to_axis_angle(p3d.axis_angle_to_matrix(tiny)), tiny, atol=1e-7)
+    # module.py:680: 6D -> matrix -> axis-angle
+    d6 = p3d.matrix_to_rotation_6d(p3d.axis_angle_to_matrix(aa))
+    assert torch.allclose(p3d.matrix_to_axis_angle(p3d.rotation_6d_to_matrix(d6)), aa, atol=1e-4)
+
+
+def test_look_at_view_transform_turntable_like_the_reference_drivers():
+    """get_neutral_pose.py:76-82 / animate_view_rot.py:93-95: R, t = look_at_view_transform(dist, elev, azim,
+    degrees=False, at=at_point[None], up=((0, 1, 0),)); R = torch.inverse(R) -> cam_param for the renderer."""
+    import math
+    at = torch.tensor([0.1, -0.2, 3.0])
+    dist, elev = 2.5, -math.pi / 6
+    for i in range(8):
+        azim = math.pi + 2 * math.pi * i / 8
+        R, T = p3d.look_at_view_transform(dist=dist, elev=elev, azim=azim, degrees=False, at=at[None, :], up=((0, 1, 0),))
+        assert R.shape == (1, 3, 3) and T.shape == (1, 3)
+        assert torch.allclose(R[0] @ R[0].t(), torch.eye(3), atol=1e-5) and abs(float(torch.linalg.det(R[0])) - 1) < 1e-5
+        # camera centre: the spherical formula around `at`; in pytorch3d's row convention X_cam = X_world R + T
+        C = at + dist * torch.tensor([math.cos(elev) * math.sin(azim), math.sin(elev), math.cos(elev) * math.cos(azim)])
+        assert torch.allclose(C @ R[0] + T[0], torch.zeros(3), atol=1e-5)              # the centre maps to the origin
+        at_cam = at @ R[0] + T[0]
+        assert torch.allclose(at_cam, torch.tensor([0.0, 0.0, dist]), atol=1e-5)        # `at` sits on the optical axis
+        # the reference's column-vector cam_param: x_cam = R_ref x + t with R_ref = inverse(R)
+        cp = p3d.turntable_cam_param(dist, elev, azim, at, (1500.0, 1500.0), (512.0, 512.0))
+        assert torch.allclose(cp['R'], torch.inverse(R[0]), atol=1e-6) and torch.allclose(cp['t'], T[0])
+        assert torch.allclose(cp['R'] @ at + cp['t'], torch.tensor([0.0, 0.0, dist]), atol=1e-5)
+        # "up" stays up: the world's +Y has a positive component along the camera's +Y axis
+        assert float((torch.tensor([0.0, 1.0, 0.0]) @ R[0])[1]) > 0
+    # degrees, eye= and the degenerate up-parallel case
+    R, T = p3d.look_at_view_transform(dist=2.0, elev=0.0, azim=90.0)
+    assert torch.allclose(torch.tensor([2.0, 0.0, 0.0]) @ R[0] + T[0], torch.zeros(3), atol=1e-5)
+    R2, T2 = p3d.look_at_view_transform(eye=((0.0, 0.0, -4.0),), at=((0.0, 0.0, 0.0),))
+    assert torch.allclose(R2[0], torch.eye(3), atol=1e-6) and torch.allclose(T2[0], torch.tensor([0.0, 0.0, 4.0]))
+    R3, _ = p3d.look_at_view_transform(eye=((0.01, 5.0, 0.0),), at=((0.0, 0.0, 0.0),))    # looking (almost) straight down
+    assert torch.isfinite(R3).all() and abs(float(torch.linalg.det(R3[0])) - 1) < 1e-4
+    # up exactly parallel to the viewing direction is degenerate in pytorch3d as well (x = up x z = 0, the fallback
+    # y x z is 0 too): finite, but not a rotation -- the reference never gets there (elev = -pi/6 or |elev| < pi/2)
+    R4, _ = p3d.look_at_view_transform(eye=((0.0, 5.0, 0.0),), at=((0.0, 0.0, 0.0),))
+    assert torch.isfinite(R4).all()
+
+
+def test_turntable_camera_through_the_raster_matrices():
+    """A turntable cam_param built the reference's way goes through make_raster_matrices like any other camera: the
+    look-at point projects to the image centre."""
+    import math
+    from exavatar_release_amd.camera import make_raster_matrices
+    at = torch.tensor([0.0, 0.3, 3.0])
+    cp = p3d.turntable_cam_param(2.0, -math.pi / 6, math.pi + 0.7, at, (1500.0, 1500.0), (512.0, 512.0))
+    tanx, tany, view, proj, campos = make_raster_matrices(cp, (1024, 1024))
+    h = torch.cat((at, torch.ones(1))) @ proj
+    ndc = h[:2] / h[3]
+    assert torch.allclose(ndc, torch.zeros(2), atol=1e-5)
+    assert torch.allclose(campos, -cp['R'].t() @ cp['t'], atol=1e-5)
+
+
+def test_save_obj(tmp_path):
+    v = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.5, -2.0]])
+    f = torch.tensor([[0, 1, 2]])
+    path = tmp_path / 'm.obj'
+    p3d.save_obj(str(path), v, f)
+    lines = path.read_text().strip().splitlines()
+    assert lines[0].startswith('v 0.0') and lines[2].split() == ['v', '0.000000', '1.500000', '-2.000000']
+    assert lines[3] == 'f 1 2 3'
