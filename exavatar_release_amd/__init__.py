@@ -9,9 +9,9 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, chec
                          rasterize_gaussians, rasterize_gaussians_batch)
 from .densify import track_densify_stats
 from .losses import SSIM, PhotometricLoss, RGBLoss
-from .renderer import ITERATION_RENDERS, GaussianRenderer, render_iteration, render_many, render_views
+from .renderer import ITERATION_RENDERS, GaussianRenderer, GraphedRenderer, render_iteration, render_many, render_views
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
            'rasterize_gaussians_batch', 'config', 'check_overflow', 'track_densify_stats', 'render_many', 'render_views',
-           'render_iteration', 'ITERATION_RENDERS',
+           'render_iteration', 'ITERATION_RENDERS', 'GraphedRenderer',
            'SSIM', 'RGBLoss', 'PhotometricLoss']

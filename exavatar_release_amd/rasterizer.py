@@ -160,6 +160,15 @@ def check_overflow():
     _drain_pending(block=True)
 
 
+def check_overflow_quiet():
+    """Drain the outstanding capacity-mode read-backs like :func:`check_overflow`, but only RECORD what they say
+    (the instance counts feed the capacity memo) instead of raising: for callers that handle an overflow themselves."""
+    try:
+        _drain_pending(block=True)
+    except RuntimeError:
+        pass
+
+
 def read_header(tile_ws):
     """(num_rendered, overflow, entries, num_visible, num_instances) of a tile workspace tensor (synchronises)."""
     return tuple(int(v) for v in tile_ws[:20].view(torch.int32).cpu())

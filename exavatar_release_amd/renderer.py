@@ -188,3 +188,125 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
             (human_asset_refined, img_shape, cam_param, bg),
             (human_asset_refined, img_shape, cam_param, None, None, scene_asset)]
     return dict(zip(ITERATION_RENDERS, render_many(renderer, jobs)))
+
+
+class GraphedRenderer:
+    """Forward-only renders of a FIXED number of Gaussians through a captured hipGraph (BASELINE configs[4]).
+
+    The animation / turntable drivers of the reference render the same avatar frame after frame under
+    ``torch.no_grad()`` (``avatar/main/animate.py:64-66``, ``animate_view_rot.py:104``, ``get_neutral_pose.py:86``):
+    ``P`` and the image size never change, only the Gaussians' values and the camera do.  This class captures the ten
+    kernel launches of one forward (no backward context stored) once and replays them per frame: inputs are copied
+    into static tensors, the camera block into one 38-float static tensor, and the frame costs one graph launch
+    instead of ~0.2 ms of host work::
+
+        gr = GraphedRenderer(point_num, (H, W), device)              # sh_degree=3 for SH inputs ('sh' instead of 'rgb')
+        for frame in frames:
+            out = gr(human_asset, cam_param_of(frame), bg)           # dict like GaussianRenderer's, minus 'mean_2d'
+
+    The returned tensors are the graph's static outputs: valid until the next call (clone what must survive).
+    Instance capacity: measured by one eager render of the first frame, times ``capacity_growth``; after every replay
+    the 16-byte header is read back (``check=True``: one host synchronisation per frame, free for drivers that pull the
+    image to the host anyway) and a frame that overflowed is re-rendered after re-capturing with the capacity it needs.
+    The field of view is baked into the kernel arguments: a change of focal length or image size re-captures.
+    """
+
+    _ASSET_KEYS = ('mean_3d', 'scale', 'rotation', 'opacity')
+
+    def __init__(self, point_num, img_shape, device, sh_degree=None, capacity_growth=1.5, check=True, capacity=None):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('exavatar_release_amd: GraphedRenderer runs on a ROCm device only')
+        self.P, self.shape, self.device = int(point_num), (int(img_shape[0]), int(img_shape[1])), device
+        self.sh_degree = sh_degree
+        self.growth, self.check = float(capacity_growth), bool(check)
+        f32 = dict(dtype=torch.float32, device=device)
+        P = self.P
+        self._in = {'mean_3d': torch.zeros((P, 3), **f32), 'scale': torch.zeros((P, 3), **f32),
+                    'rotation': torch.zeros((P, 4), **f32), 'opacity': torch.zeros((P, 1), **f32)}
+        if sh_degree is None:
+            self._in['rgb'] = torch.zeros((P, 3), **f32)
+        else:
+            self._in['sh'] = torch.zeros((P, (int(sh_degree) + 1) ** 2, 3), **f32)
+        self._cam = torch.zeros(38, **f32)                    # viewmatrix 16 | projmatrix 16 | campos 3 | bg 3
+        self._mean_2d = torch.zeros((P, 3), **f32)
+        self._capacity = int(capacity) if capacity is not None else None
+        self._graph, self._tan, self._outs, self._tile = None, None, None, None
+        self.captures = 0
+
+    def _settings(self, tan):
+        c = self._cam
+        return GaussianRasterizationSettings(
+            image_height=self.shape[0], image_width=self.shape[1], tanfovx=tan[0], tanfovy=tan[1], bg=c[35:38],
+            scale_modifier=1.0, viewmatrix=c[0:16].view(4, 4), projmatrix=c[16:32].view(4, 4),
+            sh_degree=0 if self.sh_degree is None else int(self.sh_degree), campos=c[32:35], prefiltered=False, debug=False)
+
+    def _raster(self, tan):
+        i = self._in
+        return rasterize_gaussians(i['mean_3d'], self._mean_2d, i.get('sh'), i.get('rgb'), i['opacity'], i['scale'],
+                                   i['rotation'], None, self._settings(tan))
+
+    def _capture(self, tan):
+        from . import rasterizer as rz
+        saved = (rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug)
+        try:
+            with torch.no_grad():
+                if self._capacity is None:                    # measure this frame once with the two-stage protocol
+                    rz.config.mode, rz.config.fixed_capacity = 'exact', None
+                    rz.config.keep_debug = True
+                    self._raster(tan)
+                    need = rz.read_header(rz._debug_last['tile'])[0]
+                    self._capacity = max(int(need * self.growth), 1 << 16)
+                self._capacity = (self._capacity + 63) // 64 * 64
+                rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug = 'capacity', self._capacity, True
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):                 # warm-up on a side stream, as torch.cuda.graph asks for
+                    self._raster(tan)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+                torch.cuda.synchronize(self.device)
+                rz.check_overflow_quiet()
+                self._graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph):
+                    self._outs = self._raster(tan)
+                self._tile = rz._debug_last['tile']           # the captured call's tile workspace (graph-private pool)
+                rz._debug_last.clear()
+                self._tan = tan
+                self.captures += 1
+        finally:
+            rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug = saved
+
+    def __call__(self, gaussian_assets, cam_param, bg=None):
+        from . import rasterizer as rz
+        dev = self.device
+        if bg is None:
+            bg = torch.ones(3, dtype=torch.float32, device=dev)
+        tanx, tany, view, proj, campos = _camera_block(cam_param, self.shape, dev)
+        with torch.no_grad():
+            for k in self._in:
+                src = gaussian_assets[k]
+                if tuple(src.shape) != tuple(self._in[k].shape):
+                    raise ValueError('GraphedRenderer: %s has shape %s, captured for %s (P is fixed)'
+                                     % (k, tuple(src.shape), tuple(self._in[k].shape)))
+                self._in[k].copy_(src)
+            self._cam[0:16].copy_(view.reshape(-1))
+            self._cam[16:32].copy_(proj.reshape(-1))
+            self._cam[32:35].copy_(campos.reshape(-1))
+            self._cam[35:38].copy_(torch.as_tensor(bg, dtype=torch.float32).reshape(-1))
+        tan = (float(tanx), float(tany))
+        with torch.cuda.device(dev):
+            for _ in range(3):
+                if self._graph is None or self._tan != tan:
+                    self._capture(tan)
+                self._graph.replay()
+                if not self.check:
+                    break
+                need, overflow = rz.read_header(self._tile)[:2]
+                if not overflow:
+                    break
+                self._capacity = int(need * self.growth)      # this frame needs more instances than any before it
+                self._graph = None
+            else:
+                raise RuntimeError('exavatar_release_amd: GraphedRenderer could not size its instance buffer')
+        color, radii, depth, alpha = self._outs
+        return {'img': color, 'depthmap': depth, 'mask': alpha, 'is_vis': radii > 0, 'radius': radii}

@@ -451,6 +451,58 @@ def test_hipgraph_replay_equals_eager(dev):
         exa.config.fixed_capacity = None
 
 
+def test_graphed_renderer_replays_equal_eager_no_grad_renders(dev):
+    """GraphedRenderer (BASELINE configs[4]'s mode as a product class: the forward of a fixed-P avatar captured once in a
+    hipGraph, replayed per animation frame with new Gaussians and a new camera) against plain no_grad renders through
+    GaussianRenderer: images, depth, alpha and radii bit for bit; one capture for a whole turntable; a frame that
+    overflows the instance buffer is re-rendered after a re-capture; a new focal length re-captures; SH inputs."""
+    H, W, P, f = 160, 192, 4000, 200.0
+    base = scenes.dist_a_random(P, H, W, seed=61, focal=f, z_range=(2.5, 5.0))
+    g = torch.Generator().manual_seed(62)
+    frames = []
+    for i in range(4):
+        a = {k: v.clone() for k, v in base.items()}
+        a['mean_3d'] = a['mean_3d'] + 0.02 * i * torch.randn(P, 3, generator=g)
+        a['rgb'] = torch.rand(P, 3, generator=g)
+        frames.append(({k: v.to(dev) for k, v in a.items()},
+                       {k: t.to(dev) for k, t in scenes.ring_camera(H, W, 3 * i, 40, radius=3.5, center=(0.0, 0.0, 3.5), focal=f).items()},
+                       torch.rand(3, generator=g).to(dev)))
+    rend = exa.GaussianRenderer()
+
+    def check(gr, a, cam, bg):
+        out = gr(a, cam, bg)
+        with torch.no_grad():
+            ref = rend(a, (H, W), cam, bg)
+        for k in ('img', 'depthmap', 'mask', 'radius', 'is_vis'):
+            assert torch.equal(out[k], ref[k]), k
+    gr = exa.GraphedRenderer(P, (H, W), dev)
+    for a, cam, bg in frames:
+        check(gr, a, cam, bg)
+    assert gr.captures == 1
+    # a new focal length changes tan(fov), which is baked into the kernel arguments: one more capture
+    cam2 = dict(frames[0][1]); cam2['focal'] = cam2['focal'] * 1.25
+    check(gr, frames[0][0], cam2, frames[0][2])
+    assert gr.captures == 2
+    # an instance buffer that is too small: the overflowed frame is rendered again after a re-capture
+    gr_small = exa.GraphedRenderer(P, (H, W), dev, capacity=64)
+    check(gr_small, *frames[1])
+    assert gr_small.captures == 2
+    check(gr_small, *frames[2])
+    # SH inputs evaluated in the kernel
+    sh = scenes.sh_from_rgb(base['rgb'], 2, seed=7, rest_sigma=0.2).to(dev)
+    gr_sh = exa.GraphedRenderer(P, (H, W), dev, sh_degree=2)
+    a, cam, bg = frames[0]
+    out = gr_sh({**{k: a[k] for k in ('mean_3d', 'scale', 'rotation', 'opacity')}, 'sh': sh}, cam, bg)
+    tanx, tany, view, proj, campos = make_raster_matrices({k: v.cpu() for k, v in cam.items()}, (H, W))
+    st = exa.GaussianRasterizationSettings(H, W, tanx, tany, bg, 1.0, view.to(dev), proj.to(dev), 2, campos.to(dev), False, False)
+    with torch.no_grad():
+        col, rad, dep, alp = exa.GaussianRasterizer(st)(means3D=a['mean_3d'], means2D=torch.zeros(P, 3, device=dev),
+                                                        opacities=a['opacity'], shs=sh, scales=a['scale'], rotations=a['rotation'])
+    assert torch.equal(out['img'], col) and torch.equal(out['radius'], rad)
+    with pytest.raises(ValueError, match='P is fixed'):
+        gr({k: v[:-1] for k, v in a.items()}, cam, bg)
+
+
 def test_fused_densify_stats_match_reference_bookkeeping(dev):
     """one HIP kernel instead of the reference's boolean-mask statements, on a real render's outputs,
     accumulated over three views like a training run does."""
