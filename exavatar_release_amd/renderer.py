@@ -232,7 +232,14 @@ class GraphedRenderer:
         self._mean_2d = torch.zeros((P, 3), **f32)
         self._capacity = int(capacity) if capacity is not None else None
         self._graph, self._tan, self._outs, self._tile = None, None, None, None
+        self._last = {}                                       # key -> (source tensor, its version) of the previous frame
         self.captures = 0
+
+    @property
+    def inputs(self):
+        """The static input tensors the graph reads (``mean_3d, scale, rotation, opacity, rgb | sh``): a producer may
+        write its results straight into them (``out=``) and pass them back in -- no per-frame copy at all."""
+        return self._in
 
     def _settings(self, tan):
         c = self._cam
@@ -288,7 +295,17 @@ class GraphedRenderer:
                 if tuple(src.shape) != tuple(self._in[k].shape):
                     raise ValueError('GraphedRenderer: %s has shape %s, captured for %s (P is fixed)'
                                      % (k, tuple(src.shape), tuple(self._in[k].shape)))
+                # no copy for a tensor the caller wrote straight into ``self.inputs[k]``, nor for the very tensor object
+                # of the previous frame if nothing wrote to it since (opacity / rotation / SH rest coefficients of an
+                # animated avatar: 58 MB per frame for 300 k Gaussians at degree 3)
+                if src is self._in[k]:
+                    self._last.pop(k, None)                   # the static tensor no longer mirrors the previous source
+                    continue
+                last = self._last.get(k)
+                if last is not None and last[0] is src and last[1] == src._version:
+                    continue
                 self._in[k].copy_(src)
+                self._last[k] = (src, src._version)
             self._cam[0:16].copy_(view.reshape(-1))
             self._cam[16:32].copy_(proj.reshape(-1))
             self._cam[32:35].copy_(campos.reshape(-1))

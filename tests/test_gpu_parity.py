@@ -479,6 +479,14 @@ def test_graphed_renderer_replays_equal_eager_no_grad_renders(dev):
     for a, cam, bg in frames:
         check(gr, a, cam, bg)
     assert gr.captures == 1
+    # unchanged tensor objects are not copied again, an in-place update is picked up, gr.inputs can be written directly
+    a0, cam0, bg0 = frames[0]
+    check(gr, a0, cam0, bg0)
+    a0['mean_3d'].add_(0.01)
+    check(gr, a0, cam0, bg0)
+    gr.inputs['rgb'].mul_(0.5)
+    check(gr, dict(a0, rgb=gr.inputs['rgb']), cam0, bg0)
+    assert gr.captures == 1
     # a new focal length changes tan(fov), which is baked into the kernel arguments: one more capture
     cam2 = dict(frames[0][1]); cam2['focal'] = cam2['focal'] * 1.25
     check(gr, frames[0][0], cam2, frames[0][2])
