@@ -52,11 +52,28 @@ def _camera_block(cam_param, img_shape, device):
     return res
 
 
+def _sh_degree(gaussian_assets):
+    """``None`` for the reference's assets (precomputed ``rgb``); for assets that carry spherical-harmonics
+    coefficients ``sh`` [P, M, 3] instead, the degree to evaluate: ``sh_degree`` if given, else the largest one M holds."""
+    if 'sh' not in gaussian_assets or gaussian_assets.get('rgb') is not None:
+        return None
+    if gaussian_assets.get('sh_degree') is not None:
+        return int(gaussian_assets['sh_degree'])
+    M = int(gaussian_assets['sh'].shape[1])
+    deg = int(round(M ** 0.5)) - 1
+    if (deg + 1) ** 2 != M or not 0 <= deg <= 3:
+        raise ValueError('gaussian_assets["sh"] must hold 1, 4, 9 or 16 coefficients per colour channel (or pass sh_degree)')
+    return deg
+
+
 def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, frozen_assets=None):
     """Settings tuple + rasterizer keyword arguments of one render, built exactly as module.py:594-640 does.
-    ``frozen_assets``: constant Gaussians blended together with ``gaussian_assets`` (render_many / render_iteration)."""
+    ``frozen_assets``: constant Gaussians blended together with ``gaussian_assets`` (render_many / render_iteration).
+    Beyond the reference: assets with ``sh`` [P, M, 3] (and no ``rgb``) are coloured IN the rasterizer -- the reference
+    evaluates ``clamp_min(eval_sh(...) + 0.5, 0)`` in PyTorch first (module.py:258-266) and passes ``rgb``."""
     mean_3d = gaussian_assets['mean_3d']
     device = mean_3d.device
+    sh_degree = _sh_degree(gaussian_assets)
     if bg is None:
         bg = torch.ones((3), dtype=torch.float32, device=device)
 
@@ -70,7 +87,7 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
         scale_modifier=1.0,
         viewmatrix=view_matrix,
         projmatrix=full_proj_matrix,
-        sh_degree=0,  # dummy: rgb is already computed (module.py:618)
+        sh_degree=0 if sh_degree is None else sh_degree,  # 0 = dummy: rgb is already computed (module.py:618)
         campos=cam_pos,
         prefiltered=False,
         debug=False,
@@ -82,11 +99,15 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
     mean_2d.retain_grad()
     frozen = None
     if frozen_assets is not None:
-        frozen = dict(means3D=frozen_assets['mean_3d'], colors_precomp=frozen_assets['rgb'],
+        if (_sh_degree(frozen_assets) is None) != (sh_degree is None):
+            raise ValueError('frozen_assets must carry the same colour input (rgb or sh) as gaussian_assets')
+        frozen = dict(means3D=frozen_assets['mean_3d'], colors_precomp=frozen_assets['rgb'] if sh_degree is None else None,
+                      shs=None if sh_degree is None else frozen_assets['sh'],
                       opacities=frozen_assets['opacity'], scales=frozen_assets['scale'],
                       rotations=frozen_assets['rotation'])
-    return dict(raster_settings=raster_settings, means3D=mean_3d, means2D=mean_2d, shs=None,
-                colors_precomp=gaussian_assets['rgb'], opacities=gaussian_assets['opacity'],
+    return dict(raster_settings=raster_settings, means3D=mean_3d, means2D=mean_2d,
+                shs=None if sh_degree is None else gaussian_assets['sh'],
+                colors_precomp=gaussian_assets['rgb'] if sh_degree is None else None, opacities=gaussian_assets['opacity'],
                 scales=gaussian_assets['scale'], rotations=gaussian_assets['rotation'], cov3D_precomp=None,
                 densify_stats=densify_stats, frozen=frozen)
 
@@ -113,7 +134,7 @@ class GaussianRenderer(nn.Module):
         # the reference instantiates GaussianRasterizer(raster_settings) per call (module.py:623) and calls it with
         # keywords; its forward is exactly this function call (rasterizer.GaussianRasterizer.forward), without building
         # an nn.Module per render
-        outs = rasterize_gaussians(job['means3D'], job['means2D'], None, job['colors_precomp'], job['opacities'],
+        outs = rasterize_gaussians(job['means3D'], job['means2D'], job['shs'], job['colors_precomp'], job['opacities'],
                                    job['scales'], job['rotations'], None, job['raster_settings'], densify_stats)
         return _output_dict(job, outs)
 

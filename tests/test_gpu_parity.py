@@ -246,6 +246,15 @@ def test_in_kernel_sh_colour(dev, deg):
     assert_grads_close(shg.grad, shc.grad, 'shs')
     for k in ('mean_3d', 'scale', 'rotation', 'opacity'):
         assert_grads_close(ag[k].grad, ac[k].grad, k)
+    # the same render through the plugin surface: assets that carry `sh` instead of `rgb` take the in-kernel path
+    a2 = {k: v.detach().clone().requires_grad_(True) for k, v in ag.items() if k != 'rgb'}
+    a2['sh'] = shg.detach().clone().requires_grad_(True)
+    a2['sh_degree'] = deg
+    out = exa.GaussianRenderer()(a2, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    (out['img'] * G.to(dev)).sum().backward()
+    assert torch.equal(out['img'], col) and torch.equal(out['radius'], rad)
+    assert torch.equal(a2['sh'].grad, shg.grad) and torch.equal(a2['mean_3d'].grad, ag['mean_3d'].grad)
+    assert torch.equal(out['mean_2d'].grad, m2.grad)
 
 
 def test_cov3d_precomp_path(dev):

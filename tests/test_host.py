@@ -192,3 +192,40 @@ def test_dev_layout_helper_matches_library():
     spec.loader.exec_module(lay)
     for P, W, H in ((150000, 1024, 1024), (1000, 540, 960), (0, 64, 64), (70001, 1920, 1080)):
         assert lay.tile_offsets(P, W, H)['total'] == int(_lib.workspace_sizes(P, W, H, 0).tile_bytes)
+
+
+def test_renderer_plumbing_of_sh_assets(monkeypatch):
+    """GaussianRenderer with assets that carry SH coefficients instead of rgb: the shs path of the rasterizer with the
+    right degree, the reference's call otherwise (module.py:609-640) -- checked on the arguments, no GPU needed."""
+    from exavatar_release_amd import renderer as rn
+    seen = {}
+
+    def fake(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+             densify_stats=None):
+        seen.update(sh=sh, col=colors_precomp, deg=raster_settings.sh_degree, m2=means2D, cov=cov3Ds_precomp,
+                    op=opacities, sc=scales, rot=rotations, m3=means3D)
+        H, W = raster_settings.image_height, raster_settings.image_width
+        return torch.zeros(3, H, W), torch.ones(means3D.shape[0], dtype=torch.int32), torch.zeros(1, H, W), torch.zeros(1, H, W)
+    monkeypatch.setattr(rn, 'rasterize_gaussians', fake)
+    a = scenes.dist_a_random(50, 32, 32, seed=1)
+    cam = scenes.neutral_camera(32, 32)
+    out = rn.GaussianRenderer()(a, (32, 32), cam)
+    assert seen['sh'] is None and seen['col'] is a['rgb'] and seen['deg'] == 0 and seen['cov'] is None
+    assert seen['m3'] is a['mean_3d'] and seen['op'] is a['opacity'] and seen['sc'] is a['scale'] and seen['rot'] is a['rotation']
+    assert out['mean_2d'] is seen['m2'] and out['mean_2d'].requires_grad and out['mean_2d'].shape == (50, 3)
+    assert set(out) == {'img', 'depthmap', 'mask', 'mean_2d', 'is_vis', 'radius'} and bool(out['is_vis'].all())
+    sh = scenes.sh_from_rgb(a['rgb'], 2)
+    b = {k: v for k, v in a.items() if k != 'rgb'}
+    b['sh'] = sh
+    rn.GaussianRenderer()(b, (32, 32), cam)
+    assert seen['sh'] is sh and seen['col'] is None and seen['deg'] == 2
+    b['sh_degree'] = 1                         # evaluate fewer bands than stored
+    rn.GaussianRenderer()(b, (32, 32), cam)
+    assert seen['deg'] == 1
+    with pytest.raises(ValueError):
+        rn.GaussianRenderer()({**{k: v for k, v in a.items() if k != 'rgb'}, 'sh': sh[:, :5]}, (32, 32), cam)
+    # the constant prefix must carry the same kind of colour input
+    with pytest.raises(ValueError, match='same colour input'):
+        rn._raster_job(b, (32, 32), cam, None, None, a)
+    j = rn._raster_job(b, (32, 32), cam, None, None, b)
+    assert j['frozen']['shs'] is sh and j['frozen']['colors_precomp'] is None
