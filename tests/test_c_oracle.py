@@ -250,3 +250,14 @@ def test_quad_stream_schedule_model_renders_the_oracles_image(mode):
     assert float((dep - ref['depthmap']).abs()[0][~amb].max()) <= 1e-5 and float((alp - ref['mask']).abs()[0][~amb].max()) <= IMG_TOL
     assert st['trips_quad_exact'] <= st['trips_quad_box'] <= st['trips_today']
     assert st['entries_walked_today'] <= st['list_entries']
+
+
+def test_bench_cpu_baseline_runs_on_the_c_restatement():
+    """bench.py's cpu_baseline leg (kind "port"): the C restatement on the bench workload's own view, here C1."""
+    import bench
+    assets, shape, workload = bench.build_scene('c1')
+    res = bench.cpu_baseline('c1', assets, shape, True, max_threads=4)
+    assert res['kind'] == 'port' and res['unit'] == 'iters/s' and res['value'] > 0 and 1 <= res['cores'] <= 4
+    assert 'C restatement' in res['sample'] and 'fwd+bwd' in res['sample']
+    fwd = bench.cpu_baseline('c1', assets, shape, False, max_threads=2)
+    assert 'forward' in fwd['sample'] and fwd['value'] > 0
