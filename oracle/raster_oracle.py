@@ -148,6 +148,24 @@ class _ConicFromCov2D(torch.autograd.Function):
         return da, db, dc
 
 
+class _ZeroGradOfCulled(torch.autograd.Function):
+    """Identity whose backward zeroes the rows of culled Gaussians (radius == 0).  Upstream's backward kernels return
+    at once for them (``if (!(radii[idx] > 0)) return;``): their gradients are exactly zero.  Autograd would also give
+    zero -- nothing downstream uses them -- except where the forward of such a Gaussian is not finite (a centre exactly
+    on the camera plane: 1 / t.z = inf, and 0 * inf = NaN in the chain rule).  ``holder`` is filled with the visibility
+    mask once ``preprocess`` has run; the backward pass reads it."""
+
+    @staticmethod
+    def forward(ctx, x, holder):
+        ctx.holder = holder
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        vis = ctx.holder[0].view([-1] + [1] * (g.dim() - 1))
+        return torch.where(vis, g, torch.zeros_like(g)), None
+
+
 def preprocess(means3D, means2D, opacities, scales, rotations, cov3D_precomp, s: OracleSettings, dtype):
     """Steps 1-7. Returns a dict of per-Gaussian tensors (differentiable where it must be).
 
@@ -342,7 +360,13 @@ def rasterize(means3D, means2D, opacities, shs=None, colors_precomp=None, scales
     H, W = int(s.image_height), int(s.image_width)
     P = means3D.shape[0]
     bg = s.bg.to(dtype)
+    vis_holder = []
+    if torch.is_grad_enabled():             # culled Gaussians get exactly zero gradients, like upstream (see the class)
+        wrap = lambda t_: _ZeroGradOfCulled.apply(t_, vis_holder) if (t_ is not None and t_.requires_grad) else t_   # noqa: E731
+        means3D, means2D, opacities, scales = wrap(means3D), wrap(means2D), wrap(opacities), wrap(scales)
+        rotations, cov3D_precomp, shs, colors_precomp = wrap(rotations), wrap(cov3D_precomp), wrap(shs), wrap(colors_precomp)
     pre = preprocess(means3D, means2D, opacities, scales, rotations, cov3D_precomp, s, dtype)
+    vis_holder.append(pre['visible'])
     if shs is not None:
         colors = eval_sh_color(int(s.sh_degree), shs.to(dtype), means3D.to(dtype), s.campos.to(dtype))
     else:

@@ -261,3 +261,58 @@ def test_bench_cpu_baseline_runs_on_the_c_restatement():
     assert 'C restatement' in res['sample'] and 'fwd+bwd' in res['sample']
     fwd = bench.cpu_baseline('c1', assets, shape, False, max_threads=2)
     assert 'forward' in fwd['sample'] and fwd['value'] > 0
+
+
+@pytest.mark.parametrize('trial', range(16))
+def test_edge_case_fuzz_agrees_between_the_two_restatements(trial):
+    """Seeded random scenes salted with edge cases -- opacity 0 / 1 / at the 1/255 bar, scales x1e-4 .. x300, centres at,
+    just beyond, before and behind the 0.2 near plane and exactly ON the camera plane, unnormalised quaternions, ragged image
+    sizes, all three image gradients -- through both restatements: same radii, same n_contrib, finite results, same
+    gradients.  (Found this way: autograd returned NaN instead of 0 for a culled Gaussian on the camera plane.)"""
+    g = torch.Generator().manual_seed(1000 + trial)
+    H, W = int(torch.randint(9, 70, (1,), generator=g)), int(torch.randint(9, 90, (1,), generator=g))
+    P = int(torch.randint(8, 300, (1,), generator=g))
+    f = float(torch.rand(1, generator=g) * 150 + 20)
+    a = scenes.dist_a_random(P, H, W, seed=trial, focal=f, z_range=(0.1, 8.0))
+    n = max(1, P // 8)
+    idx = torch.randperm(P, generator=g)
+    pick = lambda vals, m: torch.tensor(vals)[torch.randint(0, len(vals), (m,), generator=g)]      # noqa: E731
+    a['opacity'][idx[:n]] = pick([0.0, 1.0, 1 / 255.0, 0.0039, 0.0040], n).view(-1, 1)
+    a['scale'][idx[n:2 * n]] *= pick([1e-4, 1e-2, 30.0, 300.0], n).view(-1, 1)
+    a['mean_3d'][idx[2 * n:3 * n], 2] = pick([0.2, 0.2000001, 0.19, -1.0, 0.0], n)
+    a['rotation'][idx[3 * n:4 * n]] *= 3.0
+    cam = scenes.ring_camera(H, W, trial % 7, 7, radius=3.0, center=(0.0, 0.0, 3.0), focal=f) if trial % 2 else \
+        scenes.neutral_camera(H, W, focal=f)
+    G, Gd, Ga = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    bg = torch.rand(3, generator=g)
+    t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+    r = ro.render(t, (H, W), cam, bg, return_aux=True)
+    ((r['img'] * G).sum() + (r['depthmap'] * Gd).sum() + (r['mask'] * Ga).sum()).backward()
+    c = co.render(a, (H, W), cam, bg, dL_dimg=G, dL_ddepth=Gd, dL_dalpha=Ga)
+    amb = ro.ambiguous_pixel_mask(r['aux'], H, W)
+    assert torch.equal(c['radius'], r['radius'])
+    assert torch.isfinite(c['img']).all() and torch.isfinite(r['img']).all()
+    differ = c['n_contrib'] != r['aux']['n_contrib']
+    assert not bool((differ & ~amb).any())
+    if (~amb).any():
+        assert float((c['img'] - r['img'].detach()).abs().amax(0)[~amb].max()) <= 5e-6 * (1.0 + float(r['img'].detach().abs().max()))
+    culled = r['radius'] == 0
+    for k in KEYS:
+        gp, gc = t[k].grad, c['grads'][k]
+        assert torch.isfinite(gp).all() and torch.isfinite(gc).all(), k
+        assert not bool(gp[culled].any()) and not bool(gc[culled].any()), k         # culled Gaussians: exactly zero
+    # gradients: float32 autograd carries its own rounding (up to ~3e-4 of the tensor's max-norm on ill-conditioned
+    # splats), the C restatement accumulates in double; the float64 run of the PyTorch oracle arbitrates
+    t64 = {k: v.clone().double().requires_grad_(True) for k, v in a.items()}
+    r64 = ro.render(t64, (H, W), cam, bg, dtype=torch.float64, return_aux=True)
+    ((r64['img'] * G.double()).sum() + (r64['depthmap'] * Gd.double()).sum() + (r64['mask'] * Ga.double()).sum()).backward()
+    same = (not bool(differ.any()) and bool((r64['aux']['n_contrib'] == r['aux']['n_contrib']).all())
+            and bool((r64['radius'] == r['radius']).all()))
+    if same:                  # (a decision that flips between float32 and float64 legitimately changes gradients)
+        for k in KEYS:
+            ref = t64[k].grad.float()
+            scale = float(ref.abs().max()) + 1e-12
+            if k == 'rotation':
+                scale = max(scale, float(t['scale'].grad.abs().max() * t['scale'].detach().abs().max()))
+            assert float((c['grads'][k] - ref).abs().max()) / scale <= 1e-4, k          # C (double backward) vs float64
+            assert float((t[k].grad - ref).abs().max()) / scale <= 1e-3, k              # float32 autograd vs float64
