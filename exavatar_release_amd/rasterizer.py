@@ -131,6 +131,8 @@ def _make_settings(rs, device, keep):
 
 
 def _note_header(key, cap, D, overflow):
+    if len(_seen_D) > 4096 and key not in _seen_D:      # P changes with every densification step: keep the memo bounded
+        _seen_D.clear()
     _seen_D[key] = max(_seen_D.get(key, 0), D)
     if overflow:
         raise RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); the outputs '
