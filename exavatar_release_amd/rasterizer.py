@@ -131,8 +131,6 @@ def _make_settings(rs, device, keep):
 
 
 def _note_header(key, cap, D, overflow):
-    if len(_seen_D) > 4096 and key not in _seen_D:      # P changes with every densification step: keep the memo bounded
-        _seen_D.clear()
     _seen_D[key] = max(_seen_D.get(key, 0), D)
     if overflow:
         raise RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); the outputs '
@@ -271,6 +269,8 @@ class _Rasterize(torch.autograd.Function):
             j.key = (device.index, j.P, j.H, j.W)
             jobs.append(j)
 
+        if len(_seen_D) > 4096:       # P changes with every densification step: keep the capacity memo bounded
+            _seen_D.clear()             # (here, before any key of this call is looked up; cleared shapes re-measure once)
         mode = config.mode
         capturing = torch.cuda.is_current_stream_capturing()
         if mode == 'auto':
