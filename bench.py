@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_VIEWS = 200
-PROFILE_PREFIX = 'r02'          # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic
+PROFILE_PREFIXES = ('r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
 
 
 def parse():
@@ -53,6 +53,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-concurrent', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the extra_c5_forward / extra_c2 child runs')
     return ap.parse_args()
 
 
@@ -85,14 +86,25 @@ def view_settings(k, shape, cfg_name):
 
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: become the torch.distributed.run launch of N ranks (one per GPU, RCCL over
+        # xGMI; EXA_BENCH_BACKEND=gloo lets several ranks share one GPU for the smoke test of this very path)
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and os.environ.get('EXA_BENCH_BACKEND', 'nccl') == 'nccl':
+            print('bench.py: --gpus %d but only %d device(s) visible (RCCL needs one GPU per rank)' % (args.gpus, n_dev),
+                  file=sys.stderr)
+            sys.exit(2)
+        port = os.environ.get('MASTER_PORT') or str(29500 + os.getpid() % 2000)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print('bench.py: --gpus %d needs a torch.distributed.run launch with that many ranks' % args.gpus,
-                  file=sys.stderr)
-            sys.exit(2)
+        print('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
@@ -207,7 +219,7 @@ def main():
     geom = torch.empty(int(sz.geom_bytes), dtype=torch.uint8, device=device)
     tile = torch.empty(int(sz.tile_bytes), dtype=torch.uint8, device=device)
     radii = torch.empty(P, dtype=torch.int32, device=device)
-    D_list, V_list, I_list = [], [], []
+    D_list, V_list, I_list, T_list = [], [], [], []
     c0 = ctxs[0]
     for i in range(len(my_views)):        # every view of the shard: the capacity below provably covers them
         c0['cam'][0].copy_(cam_tab[i])
@@ -220,9 +232,11 @@ def main():
         hdr = read_header(tile)
         D_list.append(hdr[0])        # capacity this view needs (64 * batch slots)
         V_list.append(hdr[3])
-        I_list.append(hdr[4])        # sub-tile instances actually emitted
+        I_list.append(hdr[4])        # 8x8 sub-tile instances (rect count, before the exact footprint test)
+        T_list.append(hdr[6])        # 16x16 tile instances = upstream's num_rendered = the D of SURVEY.md 8(d)
     del geom, tile
-    D_max, D_mean, V_mean = max(D_list), sum(I_list) / len(I_list), sum(V_list) / len(V_list)
+    D_max, I_mean, V_mean = max(D_list), sum(I_list) / len(I_list), sum(V_list) / len(V_list)
+    D_mean = sum(T_list) / len(T_list)
     exa.config.mode = 'capacity'
     exa.config.fixed_capacity = int(D_max) + 64      # every view of the shard was probed: D_max is exact (overflow is checked)
 
@@ -317,7 +331,9 @@ def main():
                        'views_in_flight_per_gpu': S, 'views_per_launch': KV,
                        'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads (dist.FlatGradAllReducer)'
                                       % (world, n_float * 4),
-                       'mean_instances_D': D_mean, 'mean_visible_V': V_mean},
+                       'mean_instances_D': D_mean, 'mean_subtile_instances': I_mean, 'mean_visible_V': V_mean},
+            'rccl': {'world_size': dist.get_world_size() if world > 1 else 1,
+                     'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if world > 1 else None},
         }
 
     single = S == 1 and KV == 1 and world == 1
@@ -378,13 +394,34 @@ def main():
         total_bytes = (128 * P + 252 * V + 44 * D + 56 * WH) if train else fwd_bytes
         result['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': pmc_traffic(dom) if args.config == 'c3' and train else None,
+            'frac': achieved / HBM_PEAK_GBS,
             'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
+            'byte_model': 'SURVEY.md 8(d) with the run\'s own P, V and D = 16x16 tile instances (header.num_tile_instances)',
             'kernel_avg_us': avg_us,
             'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),
                      'achieved_GBs_at_measured_step': total_bytes * KV / (ms_per_step * 1e-3) / 1e9,
                      'frac_at_measured_step': total_bytes * KV / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
+        tr, src = pmc_traffic(dom) if args.config == 'c3' and train else (None, None)
+        result['roofline']['traffic'] = tr
+        result['roofline']['traffic_source'] = src
+        eb = result.get('extra_batched_views')
+        if isinstance(eb, dict) and 'ms_per_launch' in eb:
+            kb = eb['views_per_launch']
+            gbs = total_bytes * kb / (eb['ms_per_launch'] * 1e-3) / 1e9
+            result['roofline_batched'] = {'views_per_launch': kb, 'algorithmic_bytes': total_bytes * kb,
+                                          'ms_per_launch': eb['ms_per_launch'], 'achieved_GBs': gbs,
+                                          'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm'}
+
+    # ---- other BASELINE configs as driver-visible lines: C5 (configs[4], forward only, hipGraph) and C2 ----------
+    if rank == 0 and single and not args.no_concurrent and args.config == 'c3' and train and not args.no_other_configs:
+        # free this process's graphs / workspaces first: the child runs on the same GPU
+        for c in ctxs:
+            c['graph'] = None
+        ctxs.clear()
+        torch.cuda.empty_cache()
+        result['extra_c5_forward'] = other_config('c5', args)
+        result['extra_c2'] = other_config('c2', args)
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1) ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -402,16 +439,38 @@ def main():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>_hbm_traffic.json: FETCH_SIZE
-    and WRITE_SIZE collected in separate rocprofv3 --pmc runs of the same C3 workload); None if not available."""
+    """(HBM bytes per launch of `kernel`, where the number comes from).  NOT measured in this run: read from the committed
+    PMC passes (profiles/<round>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs
+    of the same C3 workload by the builder); (None, None) if not available."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for prefix in (PROFILE_PREFIX,):
+    for prefix in PROFILE_PREFIXES:
         try:
-            with open(os.path.join(here, 'profiles', prefix + '_hbm_traffic.json')) as f:
-                return float(json.load(f)['kernels'][kernel]['hbm_bytes'])
+            name = prefix + '_hbm_traffic.json'
+            with open(os.path.join(here, 'profiles', name)) as f:
+                d = json.load(f)
+            return float(d['kernels'][kernel]['hbm_bytes']), \
+                'profiles/%s (builder-side rocprofv3 --pmc passes, %s; not collected in this run)' % (name, d.get('what', 'C3 view 0, exact mode'))
         except Exception:  # noqa: BLE001
             pass
-    return None
+    return None, None
+
+
+def other_config(cfg, args):
+    """The headline step of another BASELINE config (c5: 300 k Gaussians, SH 3, 2048^2, forward only, hipGraph = configs[4];
+    c2: 120 k, 540x960, fwd+bwd) in a child process on the same GPU, so that the driver's one default run sees them."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', cfg, '--steps', str(max(20, min(args.steps, 200))),
+           '--warmup', str(max(5, min(args.warmup, 20))), '--no-cpu-baseline', '--no-concurrent', '--no-kernel-timing',
+           '--no-other-configs']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return {'error': (r.stderr or r.stdout)[-300:]}
+        d = json.loads(lines[-1])
+        return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config')}
+    except Exception as e:  # noqa: BLE001
+        return {'error': str(e)[:200]}
 
 
 def _timed_replays(ctxs, args, set_view, units_per_step):

@@ -40,6 +40,12 @@ class ExaRasterWorkspaceSizes(ctypes.Structure):
     ]
 
 
+class ExaRasterHeader(ctypes.Structure):
+    _fields_ = [('num_rendered', ctypes.c_uint32), ('overflow', ctypes.c_uint32), ('max_tile_list', ctypes.c_uint32),
+                ('num_visible', ctypes.c_uint32), ('num_instances', ctypes.c_uint32), ('active_cells', ctypes.c_uint32),
+                ('num_tile_instances', ctypes.c_uint32)]
+
+
 class ExaRasterForwardJob(ctypes.Structure):
     """One render of a batched forward call (include/exa_raster.h)."""
     _fields_ = [
@@ -51,6 +57,7 @@ class ExaRasterForwardJob(ctypes.Structure):
         ('geom_ws', c_void_p), ('tile_ws', c_void_p),
         ('bin_ws', c_void_p), ('capacity', ctypes.c_uint64),
         ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
+        ('host_header', c_void_p), ('header_tag', ctypes.c_uint32),
     ]
 
 
@@ -95,6 +102,11 @@ SIGNATURES = {
     'exa_raster_forward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
     'exa_raster_backward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterBackwardJob), _I32, _I32, c_void_p]),
     'exa_raster_read_header_async': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    'exa_raster_read_header_full_async': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    'exa_raster_host_device_pointer': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    'exa_raster_header_status': (ctypes.c_int, [ctypes.POINTER(ExaRasterHeader)]),
+    'exa_raster_camera_block': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_float), c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),
@@ -130,7 +142,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 121:
+    if lib.exa_raster_version() < 130:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

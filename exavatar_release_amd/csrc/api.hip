@@ -135,6 +135,7 @@ BinArgs bin_args(const ExaRasterForwardJob& j) {
     b.tw = carve_tile_ws(j.tile_ws, b.grid.cells, b.chunks);
     b.bw = carve_bin_ws(j.bin_ws, j.capacity);
     b.capacity = j.capacity;
+    b.host_hdr = static_cast<uint32_t*>(j.host_header); b.hdr_tag = j.header_tag;
     return b;
 }
 
@@ -222,7 +223,7 @@ int check_backward_job(const ExaRasterBackwardJob& j) {
     return 0;
 }
 
-int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipStream_t st) {
+int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int dens_shared, hipStream_t st) {
     RenderBwdArgs ra[MAX_BATCH];
     PreprocessBwdArgs pa[MAX_BATCH];
     const ExaRasterSettings* s0 = jobs[0].settings;
@@ -260,7 +261,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, hipS
     int rc;
     EXA_TIMED(K_RENDER_BWD, launch_render_bwd(ra, n, st), "render_bwd");
     if ((rc = debug_sync(s0, st, "render_bwd"))) return rc;
-    EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(pa, n, sum_shared, st), "preprocess_bwd");
+    EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(pa, n, sum_shared, dens_shared, st), "preprocess_bwd");
     if ((rc = debug_sync(s0, st, "preprocess_bwd"))) return rc;
     return 0;
 }
@@ -331,9 +332,36 @@ int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32
         }
     }
     if (sum_shared && K > MAX_BATCH) return fail(EXA_RASTER_E_INVALID, "sum_shared supports at most 8 views per call");
+    // Densification statistics are plain read-modify-writes per job: two jobs of one call must not update the same
+    // array (their workgroups run concurrently).  The one supported form of sharing: sum_shared with ALL K views
+    // accumulating into the same three arrays (K views of one model -> one set of statistics), summed inside the kernel.
+    int dens_shared = 0;
+    {
+        int n_dens = 0, n_same = 0;
+        for (int k = 0; k < K; ++k) {
+            const ExaRasterBackwardJob& b = jobs[k];
+            if (!b.densify_grad_accum && !b.densify_track_cnt && !b.densify_radius_max) continue;
+            ++n_dens;
+            if (b.densify_grad_accum == jobs[0].densify_grad_accum && b.densify_track_cnt == jobs[0].densify_track_cnt &&
+                b.densify_radius_max == jobs[0].densify_radius_max) ++n_same;
+        }
+        if (sum_shared && K > 1 && n_dens == K && n_same == K) dens_shared = 1;
+        else if (n_dens > 1) {
+            for (int i = 0; i < K; ++i)
+                for (int j = i + 1; j < K; ++j) {
+                    const float* pi[3] = {jobs[i].densify_grad_accum, jobs[i].densify_track_cnt, jobs[i].densify_radius_max};
+                    const float* pj[3] = {jobs[j].densify_grad_accum, jobs[j].densify_track_cnt, jobs[j].densify_radius_max};
+                    for (int u = 0; u < 3; ++u)
+                        for (int v = 0; v < 3; ++v)
+                            if (pi[u] && pi[u] == pj[v])
+                                return fail(EXA_RASTER_E_ALIAS, "two jobs of one batch update the same densification-statistics "
+                                            "array (supported only as sum_shared with the same three arrays in every job)");
+                }
+        }
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
-        const int rc = backward_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, sum_shared, st);
+        const int rc = backward_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, sum_shared, dens_shared, st);
         if (rc) return rc;
     }
     return 0;
@@ -350,6 +378,7 @@ static ExaRasterForwardJob one_job(const ExaRasterSettings* s, int32_t P, int32_
     j.opacities = opacities; j.scales = scales; j.rotations = rotations; j.cov3D_precomp = cov3D_precomp;
     j.radii = radii; j.geom_ws = geom_ws; j.tile_ws = tile_ws; j.bin_ws = bin_ws; j.capacity = capacity;
     j.out_color = out_color; j.out_depth = out_depth; j.out_alpha = out_alpha;
+    j.host_header = nullptr; j.header_tag = 0u;
     return j;
 }
 
@@ -405,6 +434,39 @@ int exa_raster_read_header_async(const void* tile_ws, void* host_dst16, void* st
     if (!tile_ws || !host_dst16) return fail(EXA_RASTER_E_NULLPTR, "read_header_async: NULL pointer");
     EXA_HIP(hipMemcpyAsync(host_dst16, tile_ws, 16, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)),
             "read_header_async");
+    return 0;
+}
+
+int exa_raster_header_status(const ExaRasterHeader* h) {
+    if (!h) return fail(EXA_RASTER_E_NULLPTR, "header is NULL");
+    if (h->overflow) {
+        snprintf(g_err, sizeof(g_err), "exa_raster: instance-buffer overflow (the call needs capacity %u)", h->num_rendered);
+        return EXA_RASTER_E_OVERFLOW;
+    }
+    return 0;
+}
+
+int exa_raster_camera_block(const float* R, const float* t, const float* proj16_host, float* viewmatrix_out,
+                            float* projmatrix_out, float* campos_out, void* stream) {
+    if (!R || !t || !proj16_host || !viewmatrix_out || !projmatrix_out || !campos_out)
+        return fail(EXA_RASTER_E_NULLPTR, "camera_block: NULL pointer");
+    Proj16 p;
+    memcpy(p.m, proj16_host, sizeof(p.m));
+    EXA_HIP(launch_camera_block(R, t, p, viewmatrix_out, projmatrix_out, campos_out, static_cast<hipStream_t>(stream)),
+            "camera_block");
+    return 0;
+}
+
+int exa_raster_host_device_pointer(void* host_ptr, void** device_ptr_out) {
+    if (!host_ptr || !device_ptr_out) return fail(EXA_RASTER_E_NULLPTR, "host_device_pointer: NULL pointer");
+    EXA_HIP(hipHostGetDevicePointer(device_ptr_out, host_ptr, 0), "hipHostGetDevicePointer");
+    return 0;
+}
+
+int exa_raster_read_header_full_async(const void* tile_ws, void* host_dst32, void* stream) {
+    if (!tile_ws || !host_dst32) return fail(EXA_RASTER_E_NULLPTR, "read_header_full_async: NULL pointer");
+    EXA_HIP(hipMemcpyAsync(host_dst32, tile_ws, sizeof(ExaRasterHeader), hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)),
+            "read_header_full_async");
     return 0;
 }
 

@@ -192,6 +192,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
     }
     unsigned long long ti_tot;
     block_excl_scan64((unsigned long long)true_inst, s_tmp, ti_tot);
+    unsigned long long tiles_tot;                                // 16x16 tile instances (upstream's num_rendered)
+    {
+        unsigned long long tl = 0ull;
+        for (int c = tid; c < chunks; c += SCAN_THREADS) tl += w.chunk_tiles[c];
+        block_excl_scan64(tl, s_tmp, tiles_tot);
+    }
     if (tid == 0) {
         w.cell_off[cells] = make_uint2((uint32_t)carry, (uint32_t)(carry >> 32));
         w.header->num_rendered = (uint32_t)(carry >> 32);
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
         w.header->max_tile_list = (uint32_t)carry;     // reused slot: number of (Gaussian, cell) entries
         w.header->num_visible = (uint32_t)totals;
         w.header->num_instances = (uint32_t)ti_tot;
+        w.header->num_tile_instances = (uint32_t)tiles_tot;
     }
     if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
     __syncthreads();                                             // cell_off (all of it) visible to the whole workgroup
@@ -252,6 +259,14 @@ __device__ __forceinline__ bool footprint_row(const Footprint& f, float yl, floa
 // every cell comes from the scanned count matrix, ranks inside it from LDS atomics, (c) clears this
 // workgroup's slice of the batch-owner array.
 constexpr int SC_BLOCK = CHUNK;        // one Gaussian per thread
+// Zero-copy header report (ExaRasterForwardJob.host_header): four system-scope dword stores into host-coherent pinned
+// memory, the tag behind a system-scope release fence so that a host that sees the tag sees the values.
+__device__ __forceinline__ void report_header(uint32_t* host_hdr, uint32_t need, uint32_t overflow, uint32_t vis, uint32_t tag) {
+    __hip_atomic_store(host_hdr + 0, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_hdr + 1, overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_hdr + 2, vis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_hdr + 3, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> batch) {
     // base[cells] | cnt2[cells] (u32)  [ | tot[cells] | bef[cells] (u64) when the scans are merged into this kernel ]
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -282,7 +297,11 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
             if (tid == 0) {
                 w.header->num_rendered = 0u; w.header->overflow = 0u; w.header->max_tile_list = 0u;
                 w.header->num_visible = 0u; w.header->num_instances = 0u; w.header->active_cells = 0u;
+                w.header->num_tile_instances = 0u;
+                if (a.host_hdr) report_header(a.host_hdr, 0u, 0u, 0u, a.hdr_tag);
             }
+        } else if (!a.merged && a.chunks == 0 && blockIdx.x == 0 && tid == 0 && a.host_hdr) {
+            report_header(a.host_hdr, w.header->num_rendered, 0u, 0u, a.hdr_tag);     // (cell_scan wrote the header)
         }
         return;
     }
@@ -327,8 +346,9 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
         if (tid == (int)blockIdx.x) s_bcast[0] = cx;
         if (blockIdx.x == 0) {
             if (tid < cells) w.cell_off[tid] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
-            uint32_t vis_total;
-            block_excl_scan(tid < a.chunks ? w.chunk_vis[tid] : 0u, s_tmp, vis_total);
+            unsigned long long vt;                               // tiles << 32 | visible (both sums stay < 2^32)
+            block_excl_scan64(tid < a.chunks ? ((unsigned long long)w.chunk_tiles[tid] << 32) | w.chunk_vis[tid] : 0ull, s_tmp64, vt);
+            const uint32_t vis_total = (uint32_t)vt;
             if (tid == 0) {
                 w.cell_off[cells] = make_uint2((uint32_t)tot_all, (uint32_t)(tot_all >> 32));
                 w.header->num_rendered = D;
@@ -336,6 +356,8 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                 w.header->max_tile_list = (uint32_t)tot_all;     // reused slot: number of (Gaussian, cell) entries
                 w.header->num_visible = vis_total;
                 w.header->num_instances = inst_total;
+                w.header->num_tile_instances = (uint32_t)(vt >> 32);
+                if (a.host_hdr) report_header(a.host_hdr, D, (uint64_t)D > capacity ? 1u : 0u, vis_total, a.hdr_tag);
             }
             if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
             __syncthreads();                                     // cell_off (all of it) visible to the whole workgroup
@@ -347,6 +369,8 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
         for (int c = tid; c < cells; c += SC_BLOCK) s_cnt2[c] = 0u;
     } else {
         D = w.header->num_rendered;
+        if (a.host_hdr && blockIdx.x == 0 && threadIdx.x == 0)
+            report_header(a.host_hdr, D, (uint64_t)D > capacity ? 1u : 0u, w.header->num_visible, a.hdr_tag);
         if ((uint64_t)D > capacity) {
             if (blockIdx.x == 0 && threadIdx.x == 0) w.header->overflow = 1u;
             return;

@@ -107,6 +107,8 @@ struct TileWs {
     uint2* cell_off;                  // [cells + 1]  exclusive prefix (entries, instances)
     uint32_t* chunk_inst;             // [chunks]     instances emitted by each chunk
     uint32_t* chunk_vis;              // [chunks]     Gaussians of the chunk that passed the culls
+    uint32_t* chunk_tiles;            // [chunks]     16x16 tiles of the rects of the chunk's visible Gaussians (upstream's
+                                      //              tiles_touched, summed: header.num_tile_instances)
     uint32_t* chunk_off;              // [chunks]     exclusive prefix of chunk_inst
     uint4* cell_desc;                 // [cells]      cells by descending instance count (heavy work first):
                                       //              {cell, first entry, end entry, first instance slot * 64} -- ONE load
@@ -120,7 +122,7 @@ struct TileWs {
 };
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return HEADER_BYTES + align256(uint64_t(chunks) * cells * 8) + align256(uint64_t(cells) * 8) +
-           align256(uint64_t(cells + 1) * 8) + 3 * align256(uint64_t(chunks + 1) * 4) +
+           align256(uint64_t(cells + 1) * 8) + 4 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4) + align256(uint64_t(cells) * 4);
@@ -136,6 +138,7 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.cell_off = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells + 1) * 8);
     w.chunk_inst = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.chunk_vis = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
+    w.chunk_tiles = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.chunk_off = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(chunks + 1) * 4);
     w.cell_desc = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * 16);
     w.ranges = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
@@ -248,6 +251,9 @@ struct PreprocessArgs {
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+struct Proj16 { float m[16]; };
+hipError_t launch_camera_block(const float* R, const float* t, const Proj16& proj, float* view_out, float* proj_out,
+                               float* campos_out, hipStream_t s);
 
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
 
@@ -258,6 +264,7 @@ struct BinArgs {           // one job of the binning stages (binning.hip)
     int P, chunks, merged;
     Grid grid;
     Splat* splats; TileWs tw; BinWs bw; uint64_t capacity;
+    uint32_t* host_hdr; uint32_t hdr_tag;        // ExaRasterForwardJob.host_header / header_tag (NULL = off)
 };
 hipError_t launch_cell_scan(const BinArgs* a, int K, hipStream_t s);
 hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s);
@@ -296,7 +303,8 @@ struct PreprocessBwdArgs {
 };
 // sum_shared != 0: the K jobs are K views of the SAME Gaussians (identical input pointers and P): one thread
 // per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).
-hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, hipStream_t s);
+// dens_shared != 0 (with sum_shared): the K views accumulate into job 0's densification statistics (one write per Gaussian).
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, int dens_shared, hipStream_t s);
 hipError_t launch_ssim_fwd(int N, int H, int W, const float* img1, const float* img2, float* map, float* dm_dmu1,
                            float* dm_dE11, float* dm_dE12, hipStream_t s);
 hipError_t launch_ssim_bwd(int N, int H, int W, const float* img1, const float* img2, const float* dL_dmap,

@@ -26,10 +26,14 @@ namespace exa {
 // colours-precomp path of ExAvatar's renderer, module.py:632-640): fewer registers, more waves per SIMD.
 // PREFIX = true: the job may have a constant prefix (grad_first > 0); its own instantiation so that the plain kernels
 // carry none of it.
+// dens_shared != 0 (SUM mode only): all K views update the SAME densification-statistics arrays (K views of one model
+// accumulated into one set of statistics): the per-view norms / counts / radii are summed in registers, across the
+// waves through LDS, and written by ONE thread per Gaussian -- the per-view read-modify-write below would race between
+// the waves of a workgroup.  (Distinct arrays per view need no such care; partial aliasing is rejected by the C ABI.)
 template <bool SUM, int VW, bool SH, bool PREFIX>
-__global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K) {
+__global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K, int dens_shared) {
     static_assert(VW == 1 || (SUM && VW == BLOCK / 64), "views are split over the waves of a workgroup in SUM mode only");
-    __shared__ float s_red[VW > 1 ? 20 * BLOCK : 1];
+    __shared__ float s_red[VW > 1 ? 23 * BLOCK : 1];
     const PreprocessBwdArgs& out = batch.v[SUM ? 0 : blockIdx.y];
     constexpr int GPB = BLOCK / VW;                             // Gaussians per workgroup
     if ((int)(blockIdx.x * GPB) >= out.P) return;               // workgroup-uniform
@@ -61,6 +65,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
     bool sh_init = false;                                       // dL_dsh of this Gaussian already holds an earlier view's values
+    float dn_acc = 0.f, dn_cnt = 0.f, dn_rmax = 0.f;            // dens_shared: this thread's share of the K views' statistics
 
     const int n_views = SUM ? K : 1;
     for (int view = VW == 1 ? 0 : wave; view < n_views; view += VW) {
@@ -362,9 +367,15 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         // fused densification statistics of this view (reference avatar/main/model.py:279-285 + module.py:155-157): the
         // screen-space gradient is in registers here, no separate pass over the Gaussians
         if (vis) {
-            if (a.dens_accum) a.dens_accum[row] += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
-            if (a.dens_cnt) a.dens_cnt[row] += 1.0f;
-            if (a.dens_rmax) a.dens_rmax[row] = fmaxf(a.dens_rmax[row], (float)a.radii[idc]);
+            if (SUM && dens_shared) {
+                dn_acc += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
+                dn_cnt += 1.0f;
+                dn_rmax = fmaxf(dn_rmax, (float)a.radii[idc]);
+            } else {
+                if (a.dens_accum) a.dens_accum[row] += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
+                if (a.dens_cnt) a.dens_cnt[row] += 1.0f;
+                if (a.dens_rmax) a.dens_rmax[row] = fmaxf(a.dens_rmax[row], (float)a.radii[idc]);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) { dmean[i] += vmean[i]; dscale[i] += vscale[i]; dcol[i] += vcol[i]; }
@@ -383,6 +394,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
 #pragma unroll
         for (int i = 0; i < 6; ++i) r[(10 + i) * BLOCK] = dcov[i];
         r[16 * BLOCK] = dop;
+        r[20 * BLOCK] = dn_acc; r[21 * BLOCK] = dn_cnt; r[22 * BLOCK] = dn_rmax;
         __syncthreads();
         if (wave != 0) return;
         auto total = [&](int f) {
@@ -396,8 +408,18 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
 #pragma unroll
         for (int i = 0; i < 6; ++i) dcov[i] = total(10 + i);
         dop = total(16);
+        dn_acc = total(20); dn_cnt = total(21);
+        {
+            const float* q = s_red + 22 * BLOCK + lane;
+            dn_rmax = fmaxf(fmaxf(q[0], q[64]), fmaxf(q[128], q[192]));
+        }
     }
     if (!valid) return;
+    if (SUM && dens_shared && dn_cnt > 0.f) {                   // one read-modify-write per Gaussian for all K views
+        if (out.dens_accum) out.dens_accum[row] += dn_acc;
+        if (out.dens_cnt) out.dens_cnt[row] += dn_cnt;
+        if (out.dens_rmax) out.dens_rmax[row] = fmaxf(out.dens_rmax[row], dn_rmax);
+    }
     if (SH && !sh_init && out.shs && out.dL_dsh) {                    // never visible: the SH block above did not run
         float* dsh = out.dL_dsh + (size_t)row * out.sh_M * 3;
         for (int k = 0; k < out.sh_M * 3; ++k) dsh[k] = 0.f;
@@ -438,7 +460,7 @@ hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, f
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, hipStream_t s) {
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, int dens_shared, hipStream_t s) {
     int P = 0;
     for (int k = 0; k < K; ++k) P = max(P, a[k].P);
     if (P == 0) return hipSuccess;
@@ -447,17 +469,17 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shar
     for (int k = 0; k < K; ++k) { sh = sh || a[k].shs != nullptr; prefix = prefix || a[k].grad_first > 0; }
     const dim3 grid256((P + BLOCK - 1) / BLOCK, sum_shared ? 1 : K);
     if (sum_shared && !sh)
-        preprocess_bwd_kernel<true, BLOCK / 64, false, false><<<dim3((P + 63) / 64, 1), BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<true, BLOCK / 64, false, false><<<dim3((P + 63) / 64, 1), BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     else if (sum_shared)
-        preprocess_bwd_kernel<true, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<true, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     else if (sh && prefix)
-        preprocess_bwd_kernel<false, 1, true, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, true, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     else if (sh)
-        preprocess_bwd_kernel<false, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     else if (prefix)
-        preprocess_bwd_kernel<false, 1, false, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, false, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     else
-        preprocess_bwd_kernel<false, 1, false, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K);
+        preprocess_bwd_kernel<false, 1, false, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     return hipGetLastError();
 }
 

@@ -66,7 +66,8 @@ __device__ __forceinline__ ShColour sh_colour(const PreprocessArgs& a, const flo
 }
 
 __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int idx, int sxy[4], bool& visible,
-                                                   const ShColour& shc) {
+                                                   const ShColour& shc, uint32_t& tiles16) {
+    tiles16 = 0u;
     const float* __restrict__ v = a.viewmatrix;
     const float* __restrict__ p = a.projmatrix;
     const float x = a.means3D[idx * 3 + 0], y = a.means3D[idx * 3 + 1], z = a.means3D[idx * 3 + 2];
@@ -182,6 +183,7 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
         return 0;
     }
     a.radii[idx] = radius;
+    tiles16 = (uint32_t)((x1 - x0) * (y1 - y0));               // upstream's tiles_touched
     // colour: precomputed, or SH evaluated here (reference module.py:258-266 semantics)
     float cr, cg, cbl;
     uint32_t flags = 0;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
     for (int c = tid; c < a.grid.cells; c += PBLOCK) s_cell[c] = 0ull;
     __syncthreads();
     uint32_t inst_sum = 0;
-    uint32_t nvis = 0;
+    uint32_t nvis = 0, ntiles = 0;
 #pragma unroll 1
     for (int it = 0; it < CHUNK / PBLOCK; ++it) {
         const int idx = blockIdx.x * CHUNK + it * PBLOCK + tid;
@@ -315,8 +317,10 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
         if (idx < a.P) {
             int sxy[4];
             bool vis;
-            const uint32_t n = preprocess_one(a, idx, sxy, vis, shc);
+            uint32_t t16;
+            const uint32_t n = preprocess_one(a, idx, sxy, vis, shc, t16);
             nvis += vis ? 1u : 0u;
+            ntiles += t16;
             if (n) {
                 inst_sum += n;
                 const int cx0 = sxy[0] >> 3, cx1 = (sxy[1] - 1) >> 3, cy0 = sxy[2] >> 3, cy1 = (sxy[3] - 1) >> 3;
@@ -337,13 +341,15 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
     for (int d = 32; d > 0; d >>= 1) {
         inst_sum += __shfl_xor(inst_sum, d, 64);
         nvis += __shfl_xor(nvis, d, 64);
+        ntiles += __shfl_xor(ntiles, d, 64);
     }
-    __shared__ uint32_t s_vis[PBLOCK / 64];
-    if ((tid & 63) == 0) { s_red[tid >> 6] = inst_sum; s_vis[tid >> 6] = nvis; }
+    __shared__ uint32_t s_vis[PBLOCK / 64], s_til[PBLOCK / 64];
+    if ((tid & 63) == 0) { s_red[tid >> 6] = inst_sum; s_vis[tid >> 6] = nvis; s_til[tid >> 6] = ntiles; }
     __syncthreads();
     if (tid == 0) {
         { uint32_t t = 0; for (int i = 0; i < PBLOCK / 64; ++i) t += s_red[i]; a.tw.chunk_inst[blockIdx.x] = t; }
         { uint32_t t = 0; for (int i = 0; i < PBLOCK / 64; ++i) t += s_vis[i]; a.tw.chunk_vis[blockIdx.x] = t; }
+        { uint32_t t = 0; for (int i = 0; i < PBLOCK / 64; ++i) t += s_til[i]; a.tw.chunk_tiles[blockIdx.x] = t; }
     }
     // this chunk's row of the (chunk, cell) count matrix: plain coalesced stores, zeros included
     unsigned long long* row = a.tw.chunk_cell + (size_t)blockIdx.x * a.grid.cells;
@@ -357,6 +363,38 @@ __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float*
     const float x = means3D[idx * 3 + 0], y = means3D[idx * 3 + 1], z = means3D[idx * 3 + 2];
     const float pvz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
     present[idx] = pvz > NEAR_CULL ? 1 : 0;
+}
+
+// Camera block of GaussianRenderer.forward (reference avatar/common/nets/module.py:604-608) from DEVICE-resident R, t:
+//   viewmatrix = [[R, t], [0, 0, 0, 1]]^T,  projmatrix = viewmatrix @ proj^T,  campos = -R^T t (= inverse(viewmatrix)[3, :3])
+// One 64-lane launch instead of ~25 tiny tensor ops (or a read-back + host math + upload) per new camera.  `proj` is
+// get_proj_matrix's [4, 4] (transforms.py:43-64; depends on focal and image size only), row-major, passed by value.
+// The sums run k = 0..3 left to right (this file is compiled with -ffp-contract=off); the columns the kernels read
+// (0, 1, 3) have a single non-zero term each, so they equal what any matmul computes.
+__global__ __launch_bounds__(64) void camera_block_kernel(const float* __restrict__ R, const float* __restrict__ t, Proj16 proj,
+                                                          float* __restrict__ view_out, float* __restrict__ proj_out,
+                                                          float* __restrict__ campos_out) {
+    const int l = threadIdx.x;
+    if (l < 16) {
+        const int i = l >> 2, j = l & 3;                        // row i, column j of the TRANSPOSED view matrix
+        auto vt = [&](int r, int c) -> float {                  // view^T[r][c] = view[c][r]
+            return c < 3 ? (r < 3 ? R[c * 3 + r] : t[c]) : (r < 3 ? 0.0f : 1.0f);
+        };
+        view_out[l] = vt(i, j);
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = acc + vt(i, k) * proj.m[j * 4 + k];     // proj^T[k][j] = proj[j][k]
+        proj_out[l] = acc;
+    } else if (l < 19) {
+        const int j = l - 16;
+        campos_out[j] = -((R[0 * 3 + j] * t[0] + R[1 * 3 + j] * t[1]) + R[2 * 3 + j] * t[2]);
+    }
+}
+
+hipError_t launch_camera_block(const float* R, const float* t, const Proj16& proj, float* view_out, float* proj_out,
+                               float* campos_out, hipStream_t s) {
+    camera_block_kernel<<<1, 64, 0, s>>>(R, t, proj, view_out, proj_out, campos_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s) {

@@ -39,7 +39,8 @@ def shard_views(n_views: int, rank: int, world_size: int, epoch: int = 0, shuffl
     else:
         order = list(range(n_views))
     if pad and n_views > 0 and n_views % world_size:
-        order = order + order[:world_size - n_views % world_size]
+        total = -(-n_views // world_size) * world_size            # repeat the permutation as DistributedSampler does, so
+        order = (order * (-(-total // n_views)))[:total]          # that even n_views < world_size leaves no rank empty
     return order[rank::world_size]
 
 

@@ -70,8 +70,9 @@ def knn_points(p1, p2, lengths1=None, lengths2=None, norm: int = 2, K: int = 1, 
                 ci_sorted = torch.gather(c1, 1, o2)
                 idx[n, s:s + block] = ci_sorted[:, :K]
     # differentiable outputs are recomputed from the indices (gradients flow to both point sets, like pytorch3d)
-    nn_pts = torch.gather(p2[:, None, :, :].expand(N, P1, P2, D), 2, idx[..., None].expand(N, P1, K, D)) if P2 > 0 else \
-        p1.new_empty((N, P1, 0, D))
+    # (advanced indexing per batch element: its backward is an index_add over [P1 * K, D] rows -- a gather from p2
+    #  expanded to [N, P1, P2, D] would make autograd allocate zeros of that expanded shape, terabytes at 150 k x 150 k)
+    nn_pts = torch.stack([p2[n][idx[n]] for n in range(N)]) if P2 > 0 and N > 0 else p1.new_empty((N, P1, 0 if P2 == 0 else K, D))
     dists = ((p1[:, :, None, :] - nn_pts) ** 2).sum(3)
     return _KNN(dists=dists, idx=idx, knn=nn_pts if return_nn else None)
 

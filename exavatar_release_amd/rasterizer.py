@@ -20,15 +20,35 @@ after the binning stage.  Policies (``config.mode``):
   allocate exactly, stage 2.
 * ``'capacity'``: one fused call with a buffer sized from the D of earlier calls of the same shape
   (x ``config.capacity_growth``; the first call of a shape runs in exact mode to measure D), or from
-  ``config.fixed_capacity``; no host sync and hipGraph-capturable.  An overflow is latched on
-  the device: the forward outputs of that call are invalid and its backward writes zero gradients.  It
-  is surfaced (``RuntimeError``) by the render's own ``backward`` before any gradient is returned, by
-  :func:`check_overflow`, and at the start of every later call once the asynchronous read-back has landed.
-* ``'auto'`` (default): ``'capacity'`` for renders that will be differentiated (the training loop: the
-  overflow check sits in ``backward``, so an optimizer step never sees gradients of an overflowed render)
-  and under stream capture, ``'exact'`` for ``torch.no_grad()`` renders.
+  ``config.fixed_capacity``; no host sync and hipGraph-capturable.  Whether the buffer was large enough
+  comes back through a ZERO-COPY header report: the scatter stage stores ``{needed, overflow, visible, tag}``
+  into 16 bytes of pinned host memory (``ExaRasterForwardJob.host_header``) ~35 us into the forward,
+  and the host only looks at that word -- no runtime call, no copy, no synchronisation.
+* ``'auto'`` (default): ``'capacity'`` for renders that will be differentiated and under stream
+  capture, ``'exact'`` for ``torch.no_grad()`` renders.
+
+Overflow (a render needed more instances than its buffer held; upstream cannot overflow because it
+always takes the ``'exact'`` round trip).  The kernels latch it on the device: the render draws the
+background only and its backward writes zero gradients.  ``config.on_overflow``:
+
+* ``'retry'`` (default): the render's own ``backward`` -- which looks at the report BEFORE returning
+  gradients -- re-runs the forward with the capacity the report names (into the SAME output tensors,
+  so ``img`` is corrected in place for whatever reads it later in stream order) and then runs the
+  backward on the repaired context: gradients are those of the complete render for the incoming
+  dL/dimage.  What cannot be repaired is work that already consumed the incomplete image (the loss
+  value of that one step); a ``RuntimeWarning`` says so.  ``no_grad`` / never-differentiated renders
+  are re-rendered when their report is drained (next call or :func:`check_overflow`).
+* ``'raise'``: ``RuntimeError`` instead (from ``backward``, :func:`check_overflow` or a later call).
+
+``config.overflow_check`` decides whether ``backward`` WAITS for a report that has not landed yet:
+``'always'`` does; ``'adaptive'`` (default) waits during the first ``config.verify_calls`` calls of a
+shape and whenever the last known D filled more than ``config.danger_fill`` of the buffer, and
+otherwise leaves the report to be drained later (an overflow found after its backward has returned
+can only be recorded -- the capacity memo grows -- and warned about).
 """
 import ctypes
+import time
+import warnings
 from typing import NamedTuple
 
 import torch
@@ -48,7 +68,7 @@ class GaussianRasterizationSettings(NamedTuple):
     projmatrix: torch.Tensor
     sh_degree: int
     campos: torch.Tensor
-    prefiltered: bool
+    prefiltered: bool          # accepted and ignored (include/exa_raster.h): the library always culls itself
     debug: bool
 
 
@@ -58,13 +78,22 @@ class _Config:
     min_capacity = 1 << 16
     fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up)
     keep_debug = False        # developer probes: keep the workspaces of the most recent forward reachable
+    on_overflow = 'retry'     # 'retry' | 'raise'
+    overflow_check = 'adaptive'   # 'adaptive' | 'always': does backward wait for a header report that has not landed?
+    verify_calls = 4          # adaptive: the first calls of a shape wait for their report
+    danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
+    upstream_scale_grad = False   # True: dL/dscale as upstream returns it (w.r.t. scale_modifier * scale, i.e. divided
+    #                               by scale_modifier); identical for the reference, which passes 1.0 (module.py:615)
 
 
 config = _Config()
 
 _debug_last = {}  # only filled when config.keep_debug (tools/): workspaces of the most recent forward
 _seen_D = {}      # (device index, P, H, W) -> largest instance capacity a call of that shape needed
-_pending = []     # capacity-mode calls without a backward: (event, pinned header rows, [(key, capacity)])
+_verified = {}    # same key -> number of calls whose report was looked at before their backward returned
+_pending = []     # header reports nobody has consumed yet: _Pending records
+overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
+_capture_report = None   # (slot, tag): header-report slot baked into the call being CAPTURED (set by GraphedRenderer)
 
 
 def _ptr(t):
@@ -75,16 +104,28 @@ def _addr(t):
     return t.data_ptr() if t is not None else None
 
 
-def _f32c(t, name, device):
+def _f32c(t, name, device, memo=None):
+    """float32, contiguous, on ``device``.  ``memo`` (id -> converted tensor) makes K jobs that pass the SAME tensor
+    object share one converted copy -- so that a batch of K views of one model still presents identical pointers to
+    ``exa_raster_backward_batch(sum_shared)`` when the caller's tensors needed a ``.contiguous()`` / ``.float()``."""
     if t is None:
         return None
+    if memo is not None:
+        hit = memo.get(id(t))
+        if hit is not None and hit[0] is t:
+            return hit[1]
     if not isinstance(t, torch.Tensor):
         raise TypeError('%s must be a tensor' % name)
     if t.device != device:
         raise ValueError('%s is on %s, expected %s' % (name, t.device, device))
-    if t.dtype != torch.float32:
-        t = t.float()
-    return t if t.is_contiguous() else t.contiguous()
+    c = t
+    if c.dtype != torch.float32:
+        c = c.float()
+    if not c.is_contiguous():
+        c = c.contiguous()
+    if memo is not None:
+        memo[id(t)] = (t, c)
+    return c
 
 
 def _stream_ptr(device):
@@ -108,8 +149,21 @@ def _on_device(device):
     return _NO_CTX if torch.cuda.current_device() == device.index else torch.cuda.device(device)
 
 
+_settings_cache = []      # most recent first: (key, struct, keep); the keep list pins the tensors the key's ids name
+
+
 def _make_settings(rs, device, keep):
-    """ctypes settings struct; tensors it points to are appended to ``keep`` so they stay alive."""
+    """ctypes settings struct; tensors it points to are appended to ``keep`` so they stay alive.  Memoised on the
+    identity of the four tensors + the scalars: the five renders of an iteration (and every render of a fixed camera)
+    reuse one struct instead of refilling twelve fields."""
+    key = (id(rs.bg), id(rs.viewmatrix), id(rs.projmatrix), id(rs.campos), rs.image_height, rs.image_width, rs.tanfovx,
+           rs.tanfovy, rs.scale_modifier, rs.sh_degree, rs.prefiltered, rs.debug, device.index)
+    for i, (k, s, kp) in enumerate(_settings_cache):
+        if k == key and s.bg == kp[0].data_ptr() and s.viewmatrix == kp[1].data_ptr():
+            if i:
+                _settings_cache.insert(0, _settings_cache.pop(i))
+            keep.extend(kp)
+            return s
     s = _lib.ExaRasterSettings()
     s.image_height = int(rs.image_height)
     s.image_width = int(rs.image_width)
@@ -119,78 +173,230 @@ def _make_settings(rs, device, keep):
     s.sh_degree = int(rs.sh_degree)
     s.prefiltered = int(bool(rs.prefiltered))
     s.debug = int(bool(rs.debug))
+    kp = []
+    cacheable = True
     for name in ('bg', 'viewmatrix', 'projmatrix', 'campos'):
         t = getattr(rs, name)
         if not (isinstance(t, torch.Tensor) and t.device == device and t.dtype == torch.float32 and t.is_contiguous()):
             if not isinstance(t, torch.Tensor):
                 t = torch.as_tensor(t, dtype=torch.float32)
             t = t.to(device=device, dtype=torch.float32).contiguous()
-        keep.append(t)
+            cacheable = False               # the converted copy is ours: its id says nothing about the caller's object
+        kp.append(t)
         setattr(s, name, t.data_ptr())
+    keep.extend(kp)
+    if cacheable:
+        _settings_cache.insert(0, (key, s, kp))
+        del _settings_cache[8:]
     return s
 
 
-def _note_header(key, cap, D, overflow):
-    _seen_D[key] = max(_seen_D.get(key, 0), D)
-    if overflow:
-        raise RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); the outputs '
-                           'of that render are invalid and its gradients are zero. Use config.mode="exact" or raise '
-                           'config.capacity_growth.' % (D, cap))
+# ---- zero-copy header reports ------------------------------------------------------------------------------------
+class _HdrPool:
+    """Ring of 16-byte slots in pinned host memory the scatter kernel writes its header report into."""
+    N = 2048
+
+    def __init__(self):
+        self.buf = torch.zeros((self.N, 4), dtype=torch.int32, pin_memory=True)
+        dp = ctypes.c_void_p()
+        _lib.check(_lib.load().exa_raster_host_device_pointer(ctypes.c_void_p(self.buf.data_ptr()), ctypes.byref(dp)))
+        self.dev_base = int(dp.value)
+        self.words = (ctypes.c_uint32 * (4 * self.N)).from_address(self.buf.data_ptr())
+        self.next = 0
+        self.tag = 1
+
+    def take(self):
+        """(slot, tag, device address)."""
+        i = self.next
+        self.next = (i + 1) % self.N
+        tag = self.tag
+        self.tag = tag + 1 if tag < 0x7ffffff0 else 1
+        return i, tag, self.dev_base + 16 * i
+
+
+_hdr_pool = None
+_hdr_pool_failed = False
+
+
+def _pool():
+    """The pool, or None when pinned host memory cannot be mapped for the device (then reports fall back to an
+    asynchronous 16-byte read-back + event per call)."""
+    global _hdr_pool, _hdr_pool_failed
+    if _hdr_pool is None and not _hdr_pool_failed:
+        try:
+            _hdr_pool = _HdrPool()
+        except Exception:  # noqa: BLE001
+            _hdr_pool_failed = True
+    return _hdr_pool
+
+
+class _Report:
+    """Header report of one job of a capacity-mode call."""
+    __slots__ = ('slot', 'tag', 'event', 'host', 'row', 'stream', 'tile_ptr')
+
+    def ready(self):
+        if self.event is not None:
+            return self.event.query()
+        return _hdr_pool.words[4 * self.slot + 3] == self.tag
+
+    def wait(self):
+        if self.event is not None:
+            self.event.synchronize()
+            return
+        w = _hdr_pool.words
+        i, tag = 4 * self.slot + 3, self.tag
+        t_end = time.perf_counter() + 2e-3
+        while w[i] != tag and time.perf_counter() < t_end:
+            pass
+        if w[i] != tag:
+            self.stream.synchronize()       # far behind: let the stream reach the scatter stage
+
+    def values(self):
+        """(needed capacity, overflow flag); call after ready() / wait()."""
+        if self.event is not None:
+            r = self.host[self.row].tolist()
+            return int(r[0]), int(r[1])
+        w = _hdr_pool.words
+        b = 4 * self.slot
+        if w[b + 3] != self.tag:            # slot recycled by a much later call (> N renders in flight): read the device
+            h = torch.empty(4, dtype=torch.int32)
+            _lib.check(_lib.load().exa_raster_read_header_async(self.tile_ptr, h.data_ptr(), ctypes.c_void_p(self.stream.cuda_stream)))
+            self.stream.synchronize()
+            r = h.tolist()
+            return int(r[0]), int(r[1])
+        return int(w[b]), int(w[b + 1])
+
+
+class _Pending:
+    """One capacity-mode call whose reports have not all been consumed: enough to re-render an overflowed job."""
+    __slots__ = ('jobs', 'reports', 'store_ctx', 'device', 'done', 'backward_done')
+
+
+def _record_overflow(key, need, cap, how):
+    overflow_events.append((key, need, cap, how))
+    del overflow_events[:-64]
+
+
+def _note(key, need):
+    if need > _seen_D.get(key, 0):
+        _seen_D[key] = need
+
+
+def _overflow_error(need, cap):
+    return RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); the outputs '
+                        'of that render are invalid and its gradients are zero. Use config.on_overflow="retry", '
+                        'config.mode="exact" or raise config.capacity_growth.' % (need, cap))
+
+
+def _rerender(j, need, store_ctx, device):
+    """Run job ``j``'s forward again with room for ``need`` instances, into the same output tensors."""
+    lib = _lib.load()
+    cap = (max(int(need * 1.0), 64) + 63) // 64 * 64
+    j.capacity = cap
+    j.ws = torch.empty(j.gb + j.tb + int(_sizes(j.P, j.W, j.H, cap).bin_bytes), dtype=torch.uint8, device=device)
+    j.bins = None
+    j.geom_ptr = j.ws.data_ptr()
+    j.tile_ptr = j.geom_ptr + j.gb
+    j.bin_ptr = j.tile_ptr + j.tb
+    arr = (_lib.ExaRasterForwardJob * 1)()
+    _fill_forward_job(arr[0], j)
+    with _on_device(device):
+        _lib.check(lib.exa_raster_forward_batch(arr, 1, int(store_ctx), _stream_ptr(device)))
+
+
+def _consume(rec, block, from_backward=False):
+    """Look at the reports of ``rec``; handle overflows.  Returns True when every report was consumed.
+    ``from_backward``: the caller is the render's own backward (it may still repair the context)."""
+    all_done = True
+    msgs = []
+    for k, (j, rep) in enumerate(zip(rec.jobs, rec.reports)):
+        if rep is None:
+            continue
+        if not rep.ready():
+            if not block:
+                all_done = False
+                continue
+            rep.wait()
+        need, overflow = rep.values()
+        rec.reports[k] = None
+        _note(j.key, need)
+        if not overflow:
+            continue
+        if config.on_overflow == 'raise':
+            _record_overflow(j.key, need, j.capacity, 'raised')
+            msgs.append(_overflow_error(need, j.capacity))
+            continue
+        if rec.backward_done and not from_backward:
+            # found after its backward returned zeros: nothing left to repair but the memo (already grown above)
+            _record_overflow(j.key, need, j.capacity, 'late')
+            warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d; this was '
+                          'found after its backward had returned zero gradients (config.overflow_check="adaptive"). '
+                          'The capacity memo has grown; set config.overflow_check="always" to wait for every report.'
+                          % (need, j.capacity), RuntimeWarning)
+            continue
+        old = j.capacity
+        _rerender(j, need, rec.store_ctx, rec.device)
+        _record_overflow(j.key, need, old, 'retried')
+        warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d: re-rendered with '
+                      'enough room (outputs corrected in place; work that already read the incomplete image -- the loss '
+                      'value of this step -- is not).' % (need, old), RuntimeWarning)
+    if all_done:
+        rec.done = True
+    if msgs:
+        raise msgs[0]
+    return all_done
 
 
 def _drain_pending(block=False):
-    """Process finished asynchronous header read-backs of capacity-mode calls."""
+    """Process the header reports that have landed (all of them with ``block``).  Every completed record is processed
+    before anything is raised (``config.on_overflow == 'raise'``), so no report is lost to an earlier one's error."""
     global _pending
-    rest, todo = [], []
-    for item in _pending:
-        ev = item[0]
-        if block:
-            ev.synchronize()
-        (todo if ev.query() else rest).append(item)
+    if not _pending:
+        return
+    rest, err = [], None
+    for rec in _pending:
+        if rec.done:
+            continue
+        try:
+            if not _consume(rec, block):
+                rest.append(rec)
+        except RuntimeError as e:
+            err = err or e
+            if not rec.done and any(r is not None for r in rec.reports):
+                rest.append(rec)
     _pending = rest
-    for ev, host, jobs in todo:
-        vals = host[:len(jobs)].tolist()
-        _hdr_release(ev, host)
-        for (key, cap), row in zip(jobs, vals):
-            _note_header(key, cap, row[0], row[1])
+    if err is not None:
+        raise err
 
 
 def check_overflow():
-    """Wait for all outstanding capacity-mode calls and raise if any overflowed its buffer."""
+    """Wait for all outstanding capacity-mode calls; re-render (``config.on_overflow == 'retry'``) or raise for any
+    that overflowed its buffer."""
     _drain_pending(block=True)
 
 
 def check_overflow_quiet():
-    """Drain the outstanding capacity-mode read-backs like :func:`check_overflow`, but only RECORD what they say
-    (the instance counts feed the capacity memo) instead of raising: for callers that handle an overflow themselves."""
+    """Drain the outstanding reports like :func:`check_overflow` but never raise (``on_overflow == 'raise'`` callers that
+    handle an overflow themselves); the instance counts still feed the capacity memo."""
     try:
         _drain_pending(block=True)
     except RuntimeError:
         pass
 
 
+HEADER_FIELDS = ('num_rendered', 'overflow', 'max_tile_list', 'num_visible', 'num_instances', 'active_cells',
+                 'num_tile_instances')
+
+
 def read_header(tile_ws):
-    """(num_rendered, overflow, entries, num_visible, num_instances) of a tile workspace tensor (synchronises)."""
-    return tuple(int(v) for v in tile_ws[:20].view(torch.int32).cpu())
+    """(num_rendered, overflow, entries, num_visible, num_instances, active_cells, num_tile_instances) of a tile
+    workspace tensor (synchronises).  ``num_tile_instances`` = upstream's num_rendered (16x16 tile instances)."""
+    return tuple(int(v) for v in tile_ws[:28].view(torch.int32).cpu())
 
 
 def last_header():
     """Header of the most recent forward; needs ``config.keep_debug = True`` (developer probes only)."""
     return read_header(_debug_last['tile'])
-
-
-_hdr_pool = []    # recycled (event, pinned [8, 4] int32 buffer) pairs of completed header read-backs
-
-
-def _hdr_slot(K):
-    if K <= 8 and _hdr_pool:
-        return _hdr_pool.pop()
-    return torch.cuda.Event(), torch.empty((max(K, 8), 4), dtype=torch.int32, pin_memory=True)
-
-
-def _hdr_release(ev, host):
-    if len(_hdr_pool) < 64 and host.shape[0] == 8:
-        _hdr_pool.append((ev, host))
 
 
 _size_cache = {}
@@ -214,7 +420,24 @@ class _Job:
                  'gb', 'tb')
 
 
+def _fill_forward_job(a, j, report=None):
+    a.settings = ctypes.pointer(j.settings)
+    a.P, a.sh_M = j.P, j.sh_M
+    a.means3D, a.shs, a.colors_precomp = _addr(j.means3D), _addr(j.sh), _addr(j.colors)
+    a.opacities, a.scales, a.rotations = _addr(j.opac), _addr(j.scales), _addr(j.rot)
+    a.cov3D_precomp = _addr(j.cov)
+    a.radii = j.radii.data_ptr()
+    a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = j.geom_ptr, j.tile_ptr, j.bin_ptr, j.capacity
+    base = j.planes.data_ptr()
+    a.out_color, a.out_depth, a.out_alpha = base, base + 12 * j.H * j.W, base + 16 * j.H * j.W
+    if report is not None and report.event is None:
+        a.host_header, a.header_tag = _hdr_pool.dev_base + 16 * report.slot, report.tag
+    else:
+        a.host_header, a.header_tag = None, 0
+
+
 N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D
+_F32 = torch.float32
 
 
 class _Rasterize(torch.autograd.Function):
@@ -236,6 +459,7 @@ class _Rasterize(torch.autograd.Function):
         # autograd is off inside forward(): the caller samples torch.is_grad_enabled() (a render under no_grad must
         # not pay for the backward context although GaussianRenderer's mean_2d probe requires grad)
         need_ctx = bool(grad_enabled) and any(ctx.needs_input_grad)
+        memo = {} if K > 1 else None
         jobs = []
         for k in range(K):
             m3, _m2, sh, col, op, sc, rot, cov = tensors[N_IN * k: N_IN * (k + 1)]
@@ -246,10 +470,10 @@ class _Rasterize(torch.autograd.Function):
             j.nF = int(fz[0].shape[0]) if fz is not None else 0
 
             def inp(t, i, name):
-                t = _f32c(t, name, device)
+                t = _f32c(t, name, device, memo)
                 if fz is None:
                     return t
-                f = _f32c(fz[i], name + ' (constant prefix)', device)
+                f = _f32c(fz[i], name + ' (constant prefix)', device, memo)
                 if (t is None) != (f is None):
                     raise ValueError('%s: the constant prefix must provide the same inputs as the render' % name)
                 if t is None:
@@ -268,9 +492,16 @@ class _Rasterize(torch.autograd.Function):
             j.sh_M = int(j.sh.shape[1]) if j.sh is not None else 0
             j.key = (device.index, j.P, j.H, j.W)
             jobs.append(j)
+        if shared and K > 1:
+            # "K views of the same Gaussians" is decided on what the kernels will see: the converted tensors
+            j0 = jobs[0]
+            shared = all(jk.P == j0.P and all(_addr(getattr(jk, n)) == _addr(getattr(j0, n))
+                                              for n in ('means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov'))
+                         for jk in jobs[1:])
 
         if len(_seen_D) > 4096:       # P changes with every densification step: keep the capacity memo bounded
             _seen_D.clear()             # (here, before any key of this call is looked up; cleared shapes re-measure once)
+            _verified.clear()
         mode = config.mode
         capturing = torch.cuda.is_current_stream_capturing()
         if mode == 'auto':
@@ -283,16 +514,34 @@ class _Rasterize(torch.autograd.Function):
                                    'earlier un-captured call of the same shape) before stream capture')
             mode = 'exact'            # first call of this shape: measure D once, like upstream does
 
+        rec = None
         with _on_device(device):
             stream_obj = torch.cuda.current_stream(device)
             stream = ctypes.c_void_p(stream_obj.cuda_stream)
-            if mode == 'capacity' and not capturing:
-                _drain_pending()          # event queries are illegal during stream capture
+            if mode == 'capacity' and not capturing and _pending:
+                _drain_pending()          # (reads host memory / queries events: not legal during stream capture)
             arr = (_lib.ExaRasterForwardJob * K)()
+            reports = None
+            if mode == 'capacity' and not capturing:
+                pool = _pool()
+                reports = []
+                ev_host = None
+                for k in range(K):
+                    r = _Report()
+                    r.stream = stream_obj
+                    if pool is not None:
+                        r.slot, r.tag, _dev = pool.take()
+                        r.event = r.host = r.row = None
+                    else:
+                        if ev_host is None:
+                            ev_host = (torch.cuda.Event(), torch.empty((K, 4), dtype=torch.int32, pin_memory=True))
+                        r.slot = r.tag = None
+                        r.event, r.host, r.row = ev_host[0], ev_host[1], k
+                    reports.append(r)
             for k, j in enumerate(jobs):
                 j.keep = []
                 j.settings = _make_settings(j.rs, device, j.keep)
-                j.planes = torch.empty((5, j.H, j.W), dtype=torch.float32, device=device)   # colour | depth | alpha
+                j.planes = torch.empty((5, j.H, j.W), dtype=_F32, device=device)   # colour | depth | alpha
                 j.radii = torch.empty((j.P,), dtype=torch.int32, device=device)
                 sz = _sizes(j.P, j.W, j.H, 0)
                 j.gb, j.tb = int(sz.geom_bytes), int(sz.tile_bytes)
@@ -313,39 +562,38 @@ class _Rasterize(torch.autograd.Function):
                     j.bin_ptr = None
                 j.geom_ptr = j.ws.data_ptr()
                 j.tile_ptr = j.geom_ptr + j.gb
-                a = arr[k]
-                a.settings = ctypes.pointer(j.settings)
-                a.P, a.sh_M = j.P, j.sh_M
-                a.means3D, a.shs, a.colors_precomp = _addr(j.means3D), _addr(j.sh), _addr(j.colors)
-                a.opacities, a.scales, a.rotations = _addr(j.opac), _addr(j.scales), _addr(j.rot)
-                a.cov3D_precomp = _addr(j.cov)
-                a.radii = j.radii.data_ptr()
-                a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = j.geom_ptr, j.tile_ptr, j.bin_ptr, j.capacity
-                base = j.planes.data_ptr()
-                a.out_color, a.out_depth, a.out_alpha = base, base + 12 * j.H * j.W, base + 16 * j.H * j.W
+                _fill_forward_job(arr[k], j, reports[k] if reports is not None else None)
+                if capturing and _capture_report is not None and K == 1:
+                    arr[k].host_header = _hdr_pool.dev_base + 16 * _capture_report[0]
+                    arr[k].header_tag = _capture_report[1]
 
-            hdr_check = None
             if mode == 'exact':
                 _lib.check(lib.exa_raster_forward_bin_batch(arr, K, stream))
                 rows = [j.ws[j.gb:j.gb + 16].view(torch.int32) for j in jobs]
                 hdr = (rows[0] if K == 1 else torch.stack(rows)).cpu().view(K, 4)        # D2H + sync, as upstream does
                 for k, j in enumerate(jobs):
                     j.capacity = max(int(hdr[k, 0]), 64)          # header reports whole 64-instance batch slots
-                    _seen_D[j.key] = max(_seen_D.get(j.key, 0), int(hdr[k, 0]))
+                    _note(j.key, int(hdr[k, 0]))
                     j.bins = torch.empty(int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes), dtype=torch.uint8, device=device)
-                    arr[k].bin_ws, arr[k].capacity = j.bins.data_ptr(), j.capacity
+                    j.bin_ptr = j.bins.data_ptr()
+                    arr[k].bin_ws, arr[k].capacity = j.bin_ptr, j.capacity
                 _lib.check(lib.exa_raster_forward_render_batch(arr, K, int(need_ctx), stream))
             else:
                 _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
-                if not capturing:
-                    ev, host = _hdr_slot(K)                      # pinned buffer + event from a small pool
-                    hp = host.data_ptr()
-                    for k, j in enumerate(jobs):                 # one runtime call per header: no tensor-library ops
-                        _lib.check(lib.exa_raster_read_header_async(j.tile_ptr, hp + 16 * k, stream))
-                    ev.record(stream_obj)
-                    hdr_check = (ev, host, [(j.key, j.capacity) for j in jobs])
-                    if not need_ctx:
-                        _pending.append(hdr_check)
+                if reports is not None:
+                    if reports[0].event is not None:             # fallback: 16-byte read-backs + one event
+                        hp = reports[0].host.data_ptr()
+                        for k, j in enumerate(jobs):
+                            _lib.check(lib.exa_raster_read_header_async(j.tile_ptr, hp + 16 * k, stream))
+                        reports[0].event.record(stream_obj)
+                    for r, j in zip(reports, jobs):
+                        r.tile_ptr = j.tile_ptr
+                    # every capacity-mode call is on the pending list until its reports are consumed -- by its own
+                    # backward, or by a later drain when no backward ever runs (no_grad, a skipped step, an unused output)
+                    rec = _Pending()
+                    rec.jobs, rec.reports, rec.store_ctx, rec.device = jobs, reports, need_ctx, device
+                    rec.done = rec.backward_done = False
+                    _pending.append(rec)
 
         if config.keep_debug:
             j = jobs[-1]
@@ -355,14 +603,15 @@ class _Rasterize(torch.autograd.Function):
         ctx.need_ctx = need_ctx
         outs = []
         for j in jobs:
-            outs += [j.planes[0:3], j.radii, j.planes[3:4], j.planes[4:5]]
+            c, d, a = j.planes.split((3, 1, 1))
+            outs += [c, j.radii, d, a]
         if need_ctx:
             ctx.K = K
             ctx.densify = densify
             ctx.shared = bool(shared) and K > 1
-            ctx.hdr_check = hdr_check
-            ctx.meta = [(j.rs, j.P, j.H, j.W, j.sh_M, j.capacity, j.gb, j.tb, j.settings, j.keep, j.ws, j.bins,
-                         tuple(t is not None for t in (j.sh, j.colors, j.scales, j.rot, j.cov)), j.nF) for j in jobs]
+            ctx.rec = rec
+            ctx.jobs = jobs
+            ctx.has = [tuple(t is not None for t in (j.sh, j.colors, j.scales, j.rot, j.cov)) for j in jobs]
             saved = []
             empty = None
             for j in jobs:
@@ -388,44 +637,67 @@ class _Rasterize(torch.autograd.Function):
         K = ctx.K
         saved = ctx.saved_tensors
         device = saved[0].device
-        f32 = dict(dtype=torch.float32, device=device)
         need = ctx.needs_input_grad[6:]
         arr = (_lib.ExaRasterBackwardJob * K)()
         keep, ret = [], [None, None, None, None, None, None]
+        rec = ctx.rec
         with _on_device(device):
+            if rec is not None and not rec.done:
+                # Capacity mode: did this render's forward have room?  Its report was written ~35 us into the forward, so
+                # it has normally landed by now; if not, wait for it or leave it to a later drain (config.overflow_check).
+                # An overflowed job is re-rendered HERE, before the backward kernels are queued on the repaired context.
+                block = config.overflow_check == 'always' or config.fixed_capacity is not None
+                if not block:
+                    for j in rec.jobs:
+                        if _verified.get(j.key, 0) < config.verify_calls or \
+                                _seen_D.get(j.key, 0) > config.danger_fill * j.capacity:
+                            block = True
+                            break
+                if _consume(rec, block, from_backward=True):
+                    for j in rec.jobs:
+                        _verified[j.key] = _verified.get(j.key, 0) + 1
+                    try:
+                        _pending.remove(rec)       # consumed: release its references now, not at the next drain
+                    except ValueError:
+                        pass
+                rec.backward_done = True
             for k in range(K):
-                rs, P, H, W, sh_M, cap, gb, tb, st, _skeep, ws, bins, has, nF = ctx.meta[k]
+                j = ctx.jobs[k]
+                P, H, W, sh_M, nF = j.P, j.H, j.W, j.sh_M, j.nF
                 Pg = P - nF                               # rows of every gradient array (constant prefix excluded)
-                has_sh, has_col, has_sc, has_rot, has_cov = has
+                has_sh, has_col, has_sc, has_rot, has_cov = ctx.has[k]
                 means3D, sh, col, opac, scales, rot, cov, radii = saved[8 * k: 8 * k + 8]
                 g_color, g_depth, g_alpha = grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]
 
                 def grad_in(g, shape):
                     if g is None:
                         return None
-                    g = g.to(**f32).expand(shape)
+                    if g.dtype is _F32 and g.shape == shape and g.is_contiguous():
+                        return g
+                    g = g.to(dtype=_F32, device=device).expand(shape)
                     return g if g.is_contiguous() else g.contiguous()
                 g_color = grad_in(g_color, (3, H, W))
                 if g_color is None:
-                    g_color = torch.zeros((3, H, W), **f32)
+                    g_color = torch.zeros((3, H, W), dtype=_F32, device=device)
                 g_depth = grad_in(g_depth, (1, H, W))
                 g_alpha = grad_in(g_alpha, (1, H, W))
                 nd = need[N_IN * k: N_IN * (k + 1)]
                 own = (not ctx.shared) or k == 0          # shared: job 0's outputs receive the sum over the K views
-                # separate tensors on purpose: AccumulateGrad adopts a whole tensor as `.grad` without a copy, a view
-                # of a shared buffer would be cloned
-                d_means3D = torch.empty((Pg, 3), **f32) if own and nd[0] else None
-                d_means2D = torch.empty((Pg, 3), **f32) if nd[1] else None
-                d_sh = torch.empty((Pg, sh_M, 3), **f32) if own and has_sh and nd[2] else None
-                d_colors = torch.empty((Pg, 3), **f32) if own and has_col and nd[3] else None
-                d_opac = torch.empty((Pg, 1), **f32) if own and nd[4] else None
-                d_scales = torch.empty((Pg, 3), **f32) if own and has_sc and nd[5] else None
-                d_rot = torch.empty((Pg, 4), **f32) if own and has_rot and nd[6] else None
-                d_cov = torch.empty((Pg, 6), **f32) if own and has_cov and nd[7] else None
-                grad_ws = torch.empty(int(_sizes(P, W, H, cap).grad_bytes), dtype=torch.uint8, device=device)
+                # ONE arena for the small per-Gaussian gradients of this job (3 + 3 + 3 + 1 + 3 + 4 + 6 floats per row at
+                # most) instead of up to seven allocator calls; dL/dsh (up to 48 floats per row) stays its own tensor.
+                # AccumulateGrad adopts a contiguous view as `.grad` like any other tensor.
+                want = ((own and nd[0], 3), (nd[1], 3), (own and has_col and nd[3], 3), (own and nd[4], 1),
+                        (own and has_sc and nd[5], 3), (own and has_rot and nd[6], 4), (own and has_cov and nd[7], 6))
+                widths = [w for on, w in want if on]
+                pieces = iter(torch.empty(Pg * sum(widths), dtype=_F32, device=device).split([Pg * w for w in widths])) \
+                    if widths else iter(())
+                d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
+                    [next(pieces).view(Pg, w) if on else None for on, w in want]
+                d_sh = torch.empty((Pg, sh_M, 3), dtype=_F32, device=device) if own and has_sh and nd[2] else None
+                grad_ws = torch.empty(int(_sizes(P, W, H, j.capacity).grad_bytes), dtype=torch.uint8, device=device)
                 keep += [g_color, g_depth, g_alpha, grad_ws]
                 a = arr[k]
-                a.settings = ctypes.pointer(st)           # built in forward; its tensors are kept alive by ctx.meta
+                a.settings = ctypes.pointer(j.settings)   # built in forward; its tensors are kept alive by j.keep
                 a.P, a.sh_M = P, sh_M
                 a.means3D = means3D.data_ptr()
                 a.shs = sh.data_ptr() if has_sh else None
@@ -435,10 +707,8 @@ class _Rasterize(torch.autograd.Function):
                 a.rotations = rot.data_ptr() if has_rot else None
                 a.cov3D_precomp = cov.data_ptr() if has_cov else None
                 a.radii = radii.data_ptr()
-                a.geom_ws = ws.data_ptr()
-                a.tile_ws = ws.data_ptr() + gb
-                a.bin_ws = bins.data_ptr() if bins is not None else ws.data_ptr() + gb + tb
-                a.capacity = cap
+                a.geom_ws, a.tile_ws, a.bin_ws = j.geom_ptr, j.tile_ptr, j.bin_ptr
+                a.capacity = j.capacity
                 a.dL_dcolor, a.dL_ddepth, a.dL_dalpha = g_color.data_ptr(), _addr(g_depth), _addr(g_alpha)
                 a.grad_ws = grad_ws.data_ptr()
                 a.dL_dmeans2D, a.dL_dmeans3D, a.dL_dcolors = _addr(d_means2D), _addr(d_means3D), _addr(d_colors)
@@ -447,24 +717,18 @@ class _Rasterize(torch.autograd.Function):
                 dens = ctx.densify[k] if ctx.densify is not None else None
                 if dens is not None:
                     if d_means2D is None:          # the statistics need the screen-space gradient: compute it anyway
-                        d_tmp = torch.empty((Pg, 3), **f32)
+                        d_tmp = torch.empty((Pg, 3), dtype=_F32, device=device)
                         keep.append(d_tmp)
                         a.dL_dmeans2D = d_tmp.data_ptr()
                     a.densify_grad_accum, a.densify_track_cnt, a.densify_radius_max = [_addr(t) for t in dens]
                 a.grad_first = nF
+                if config.upstream_scale_grad and d_scales is not None and float(j.rs.scale_modifier) != 1.0:
+                    keep.append((d_scales, float(j.rs.scale_modifier)))
                 ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
             _lib.check(lib.exa_raster_backward_batch(arr, K, int(ctx.shared), _stream_ptr(device)))
-        if ctx.hdr_check is not None:
-            # capacity mode: make sure this render's forward did not overflow BEFORE handing gradients to the optimizer
-            # (an overflowed forward gets zero gradients from the kernels above).  The backward kernels are already
-            # queued, so waiting for the forward's 16-byte header read-back does not idle the GPU.
-            ev, host, jobs = ctx.hdr_check
-            ctx.hdr_check = None
-            ev.synchronize()
-            vals = host[:len(jobs)].tolist()
-            _hdr_release(ev, host)
-            for (key, cap), row in zip(jobs, vals):
-                _note_header(key, cap, row[0], row[1])
+            for item in keep:
+                if isinstance(item, tuple):        # upstream's dL/dscale quirk: gradient w.r.t. (modifier * scale)
+                    item[0].div_(item[1])
         return tuple(ret)
 
 
@@ -478,6 +742,28 @@ def _check_densify(dens, P, device):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != P or t.device != device):
             raise ValueError('%s must be a contiguous float32 tensor with %d elements on %s' % (name, P, device))
     return dens
+
+
+def _check_densify_aliasing(dens, shared):
+    """Two jobs of one batch must not update the same statistics array (plain read-modify-writes by concurrently running
+    workgroups) -- except K views of the SAME Gaussians that all name the same three arrays: the kernel then sums the K
+    views' statistics and writes once per Gaussian (``exa_raster_backward_batch``, ``sum_shared``)."""
+    live = [d for d in dens if d is not None and any(t is not None for t in d)]
+    if len(live) < 2:
+        return
+    ptrs = [tuple(_addr(t) for t in d) for d in live]
+    if shared and len(live) == len(dens) and all(p == ptrs[0] for p in ptrs):
+        return
+    seen = set()
+    for p in ptrs:
+        for a in p:
+            if a is None:
+                continue
+            if a in seen:
+                raise ValueError('densify_stats: two renders of one batch update the same tensor; give every render its '
+                                 'own statistics, or -- for K views of the same Gaussians -- pass the same three tensors '
+                                 'to all of them')
+        seen.update(a for a in p if a is not None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -502,7 +788,7 @@ def rasterize_gaussians_batch(jobs):
     no work for the prefix).  Returns a list of ``(color, radii, depth, alpha)`` tuples, bit-identical to K single
     calls.  When every job passes the SAME tensor objects for the Gaussians (K views of one model), the backward
     sums the K views' gradients inside the per-Gaussian kernel (one thread walks the K views) instead of letting
-    autograd add K gradient tensors.
+    autograd add K gradient tensors; such a batch may also share ONE set of ``densify_stats`` tensors.
     """
     jobs = list(jobs)
     K = len(jobs)
@@ -529,6 +815,7 @@ def rasterize_gaussians_batch(jobs):
     dens = None
     if any(j.get('densify_stats') is not None for j in jobs):
         dens = [_check_densify(j.get('densify_stats'), int(j['means3D'].shape[0]), j['means3D'].device) for j in jobs]
+        _check_densify_aliasing(dens, shared)
     outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, dens, frozen,
                             *flat)
     return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]

@@ -8,6 +8,9 @@ hard-coded ``.cuda()``, the default background is created per call (the referenc
 ``torch.ones(3).cuda()`` at import time, module.py:592), and the 4x4 camera matrices are computed on the host
 from one read-back of the camera tensors (same formulas, see ``forward``).
 """
+import ctypes
+import time
+
 import torch
 import torch.nn as nn
 
@@ -50,6 +53,55 @@ def _camera_block(cam_param, img_shape, device):
         _cam_cache.insert(0, (tens, vers, shape, device, res))
         del _cam_cache[_CAM_CACHE_SIZE:]
     return res
+
+
+_proj_cache = []       # most recent first: (focal tensor, its version, img_shape, (tanfovx, tanfovy, ctypes float[16]))
+
+
+def _proj_host(cam_param, img_shape):
+    """The part of the camera block that depends on focal length and image size only -- tan(fov / 2) as Python floats
+    (kernel arguments) and get_proj_matrix's [4, 4] as sixteen host floats -- memoised on the identity + version of the
+    ``focal`` tensor: a turntable / animation driver that moves the camera (new ``R``, ``t``) keeps one focal length, so
+    this read-back happens once, not per frame."""
+    from .camera import get_fov, get_proj_matrix
+    shape = (int(img_shape[0]), int(img_shape[1]))
+    f = cam_param['focal']
+    if isinstance(f, torch.Tensor):
+        for i, (cf, cv, cs, res) in enumerate(_proj_cache):
+            if cf is f and cv == f._version and cs == shape:
+                if i:
+                    _proj_cache.insert(0, _proj_cache.pop(i))
+                return res
+    focal = torch.as_tensor(f, dtype=torch.float32).detach().reshape(-1).cpu()
+    fov = get_fov(focal, None, shape)
+    proj = get_proj_matrix(focal, None, shape, 0.01, 100.0, 1.0)
+    res = (float(torch.tan(fov[0] / 2)), float(torch.tan(fov[1] / 2)),
+           (ctypes.c_float * 16)(*[float(v) for v in proj.reshape(-1).tolist()]))
+    if isinstance(f, torch.Tensor):
+        _proj_cache.insert(0, (f, f._version, shape, res))
+        del _proj_cache[4:]
+    return res
+
+
+def camera_block_device(cam_param, img_shape, out38):
+    """Write the camera block of ``GaussianRenderer.forward`` (module.py:604-608) for DEVICE tensors ``cam_param['R']``
+    / ``['t']`` into ``out38`` (float32 [>= 35] on the same device: viewmatrix 16 | projmatrix 16 | campos 3) with ONE
+    tiny kernel (``exa_raster_camera_block``): no read-back of the extrinsics, no host matrix code, no upload.
+    Returns ``(tanfovx, tanfovy)``.  The three columns of ``projmatrix`` the rasterizer reads have one non-zero term
+    each and equal the host path's; ``campos`` is ``-R^T t`` instead of a general matrix inverse (equal up to rounding
+    for a rotation matrix; it only enters the SH view direction)."""
+    from . import _lib
+    tanx, tany, proj16 = _proj_host(cam_param, img_shape)
+    dev = out38.device
+    R, t = cam_param['R'], cam_param['t']
+    if not (isinstance(R, torch.Tensor) and R.device == dev and R.dtype == torch.float32 and R.is_contiguous()):
+        R = torch.as_tensor(R, dtype=torch.float32).to(dev).contiguous()
+    if not (isinstance(t, torch.Tensor) and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()):
+        t = torch.as_tensor(t, dtype=torch.float32).to(dev).contiguous()
+    base = out38.data_ptr()
+    _lib.check(_lib.load().exa_raster_camera_block(R.data_ptr(), t.data_ptr(), proj16, base, base + 64, base + 128,
+                                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return tanx, tany
 
 
 def _sh_degree(gaussian_assets):
@@ -254,6 +306,8 @@ class GraphedRenderer:
         self._capacity = int(capacity) if capacity is not None else None
         self._graph, self._tan, self._outs, self._tile = None, None, None, None
         self._last = {}                                       # key -> (source tensor, its version) of the previous frame
+        self._slot = None                                     # (slot, tag) of the header report baked into the graph
+        self._bg_src, self._bg_ver = None, None
         self.captures = 0
 
     @property
@@ -294,9 +348,21 @@ class GraphedRenderer:
                 torch.cuda.current_stream(self.device).wait_stream(side)
                 torch.cuda.synchronize(self.device)
                 rz.check_overflow_quiet()
-                self._graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self._graph):
-                    self._outs = self._raster(tan)
+                # the captured call reports its header into ONE pinned host slot (a plain store from the scatter kernel,
+                # include/exa_raster.h: host_header): every replay rewrites it, the host resets the tag before a replay and
+                # polls it afterwards -- no read-back, no synchronisation per frame
+                pool = rz._pool()
+                self._slot = None
+                if pool is not None:
+                    slot, tag, _ = pool.take()
+                    self._slot = (slot, tag)
+                    rz._capture_report = self._slot
+                try:
+                    self._graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._graph):
+                        self._outs = self._raster(tan)
+                finally:
+                    rz._capture_report = None
                 self._tile = rz._debug_last['tile']           # the captured call's tile workspace (graph-private pool)
                 rz._debug_last.clear()
                 self._tan = tan
@@ -309,7 +375,6 @@ class GraphedRenderer:
         dev = self.device
         if bg is None:
             bg = torch.ones(3, dtype=torch.float32, device=dev)
-        tanx, tany, view, proj, campos = _camera_block(cam_param, self.shape, dev)
         with torch.no_grad():
             for k in self._in:
                 src = gaussian_assets[k]
@@ -327,19 +392,32 @@ class GraphedRenderer:
                     continue
                 self._in[k].copy_(src)
                 self._last[k] = (src, src._version)
-            self._cam[0:16].copy_(view.reshape(-1))
-            self._cam[16:32].copy_(proj.reshape(-1))
-            self._cam[32:35].copy_(campos.reshape(-1))
-            self._cam[35:38].copy_(torch.as_tensor(bg, dtype=torch.float32).reshape(-1))
-        tan = (float(tanx), float(tany))
+            # camera: ONE kernel from the device-resident extrinsics (a new camera per frame costs no read-back, no host
+            # matrix code and no upload); tan(fov / 2) and the projection entries come from the focal length, memoised
+            if self._bg_src is not bg or self._bg_ver != getattr(bg, '_version', None):
+                self._cam[35:38].copy_(torch.as_tensor(bg, dtype=torch.float32).reshape(-1))
+                self._bg_src, self._bg_ver = bg, getattr(bg, '_version', None)
+            tan = camera_block_device(cam_param, self.shape, self._cam)
         with torch.cuda.device(dev):
             for _ in range(3):
                 if self._graph is None or self._tan != tan:
                     self._capture(tan)
+                if self._slot is not None:
+                    words, b = rz._hdr_pool.words, 4 * self._slot[0]
+                    words[b + 3] = 0                          # (the previous replay's report has been read: no store in flight)
                 self._graph.replay()
                 if not self.check:
                     break
-                need, overflow = rz.read_header(self._tile)[:2]
+                if self._slot is not None:
+                    t_end = time.perf_counter() + 5e-3
+                    while words[b + 3] != self._slot[1] and time.perf_counter() < t_end:
+                        pass
+                    if words[b + 3] != self._slot[1]:
+                        torch.cuda.current_stream(dev).synchronize()
+                if self._slot is not None and words[b + 3] == self._slot[1]:
+                    need, overflow = int(words[b]), int(words[b + 1])
+                else:
+                    need, overflow = rz.read_header(self._tile)[:2]
                 if not overflow:
                     break
                 self._capacity = int(need * self.growth)      # this frame needs more instances than any before it

@@ -18,9 +18,17 @@
  *     shapes the reference passes (module.py:632-640): means3D[P,3], opacities[P,1], scales[P,3],
  *     rotations[P,4] (w,x,y,z), colors_precomp[P,3], shs[P,M,3], cov3D_precomp[P,6].
  *   - work is enqueued on `stream`; no call synchronises the device unless `settings->debug != 0`.
- *   - return value: 0 = ok; < 0 = invalid argument; > 0 = HIP error code (hipError_t);
- *     EXA_RASTER_E_OVERFLOW is never returned synchronously -- instance-buffer overflow is
- *     reported through the device-side header (see exa_raster_forward_render).
+ *   - return value: 0 = ok; < 0 = invalid argument (EXA_RASTER_E_*); > 0 = HIP error code (hipError_t).
+ *     Instance-buffer overflow is latched in the device-side header (see exa_raster_forward_render): the launch
+ *     calls never synchronise, so they cannot return it; exa_raster_header_status() turns a header that the
+ *     caller copied to the host (exa_raster_read_header_async) into EXA_RASTER_E_OVERFLOW.
+ *   - `settings->prefiltered` is accepted and IGNORED: upstream uses it only to assert that the caller already
+ *     removed the Gaussians behind the near plane; this library culls them itself in every call (the reference
+ *     always passes False, module.py:620).
+ *   - `settings->scale_modifier`: dL_dscales is the derivative with respect to `scales` itself (chain rule through
+ *     mod * scale).  Upstream returns the derivative with respect to (mod * scale), i.e. it omits the factor mod;
+ *     the two agree for the reference, which passes 1.0 (module.py:615).  A caller that needs upstream's quirk
+ *     divides dL_dscales by scale_modifier.
  */
 #ifndef EXA_RASTER_H
 #define EXA_RASTER_H
@@ -32,12 +40,18 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 121          /* 0.1.2: ExaRasterBackwardJob.grad_first (constant leading Gaussians); .1: exa_raster_read_header_async */
+#define EXA_RASTER_VERSION 130          /* 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+                                           exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
 #define EXA_RASTER_E_INVALID (-1)
 #define EXA_RASTER_E_NULLPTR (-2)
 #define EXA_RASTER_E_WORKSPACE (-3)
+#define EXA_RASTER_E_OVERFLOW (-4)      /* instance-buffer overflow: only ever returned by exa_raster_header_status(), which
+                                           interprets a header that was copied to the host; the launch calls themselves
+                                           never return it (they do not synchronise) */
+#define EXA_RASTER_E_ALIAS (-5)         /* two jobs of one batched backward call update the same densification-statistics
+                                           arrays (the update is a plain read-modify-write per job) */
 
 /* Mirrors the 12-field `GaussianRasterizationSettings` NamedTuple built at module.py:609-622.
  * The four tensor-valued fields stay on the device (the reference builds them with torch ops on
@@ -65,7 +79,7 @@ typedef struct ExaRasterWorkspaceSizes {
     uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
-/* Device-side header at the start of the tile workspace (readable with a 24-byte D2H copy). */
+/* Device-side header at the start of the tile workspace (readable with a 28-byte D2H copy). */
 typedef struct ExaRasterHeader {
     uint32_t num_rendered;   /* instance capacity this call needs: 64 * batch slots (role of upstream's
                                 num_rendered: what the caller sizes the bin workspace with)   */
@@ -74,7 +88,13 @@ typedef struct ExaRasterHeader {
     uint32_t num_visible;    /* V = Gaussians with radius > 0                                */
     uint32_t num_instances;  /* D = (Gaussian, 8x8 sub-tile) instances actually emitted      */
     uint32_t active_cells;   /* 64x64-pixel cells that hold at least one instance            */
+    uint32_t num_tile_instances; /* sum over visible Gaussians of the 16x16 tiles of their rect: upstream's
+                                num_rendered, the D of the byte model in SURVEY.md 8(d)          */
 } ExaRasterHeader;
+
+/* 0 if the header copy `h` (host memory) reports a complete render, EXA_RASTER_E_OVERFLOW if the call needed
+ * h->num_rendered instances but was given fewer (its outputs are invalid; re-run it with that capacity). */
+int exa_raster_header_status(const ExaRasterHeader* h);
 
 int exa_raster_version(void);
 
@@ -169,6 +189,13 @@ typedef struct ExaRasterForwardJob {
     void* geom_ws; void* tile_ws;   /* sized by exa_raster_workspace_sizes(P, W, H, capacity)          */
     void* bin_ws; uint64_t capacity;                     /* ignored by exa_raster_forward_bin_batch    */
     float* out_color; float* out_depth; float* out_alpha; /* ignored by exa_raster_forward_bin_batch   */
+    /* Optional zero-copy header report (NULL = off): a DEVICE-VISIBLE address of 16 bytes of pinned host memory
+     * (exa_raster_host_device_pointer).  As soon as the instance count of this job is known -- in the scatter stage,
+     * long before the blend finishes -- ONE thread stores {num_rendered, overflow, num_visible, header_tag} there
+     * (system-scope, the tag last).  A caller that polls the tag learns whether the capacity was enough without any
+     * runtime call, copy or synchronisation; it works inside a captured hipGraph too (a plain store).  Use a fresh tag
+     * (or reset the slot) per call to tell a new report from an old one. */
+    void* host_header; uint32_t header_tag;
 } ExaRasterForwardJob;
 
 typedef struct ExaRasterBackwardJob {
@@ -183,7 +210,10 @@ typedef struct ExaRasterBackwardJob {
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
     /* optional fused densification statistics (all three NULL = off): updated in place by the per-Gaussian backward
-     * kernel exactly as exa_raster_densify_stats would do it with this job's dL_dmeans2D and radii -- no extra pass */
+     * kernel exactly as exa_raster_densify_stats would do it with this job's dL_dmeans2D and radii -- no extra pass.
+     * The update is a plain read-modify-write: two jobs of one batched call must not name the same array
+     * (EXA_RASTER_E_ALIAS), with one exception -- sum_shared = 1 and the SAME three arrays in all K jobs: the K views'
+     * statistics are then summed inside the kernel and written once per Gaussian. */
     float* densify_grad_accum; float* densify_track_cnt; float* densify_radius_max;
     /* Constant prefix: Gaussians 0 .. grad_first - 1 are inputs only, they get no gradient.  This is the scene under
      * the human in ExAvatar's composite renders (torch.cat((scene.detach(), human)), avatar/main/model.py:119-126): the
@@ -201,12 +231,27 @@ int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32
 
 /*
  * Asynchronous read-back of the first 16 bytes of the header (num_rendered, overflow, max_tile_list, num_visible) of a
- * tile workspace into caller-provided PINNED host memory, enqueued on `stream` behind the forward call: what a binding
+ * tile workspace into caller-provided PINNED host memory (exa_raster_read_header_full_async: all sizeof(ExaRasterHeader)
+ * = 28 bytes, dst needs 32), enqueued on `stream` behind the forward call: what a binding
  * does after a fused exa_raster_forward to learn -- later, without a host synchronisation now -- whether the capacity
  * was enough.  One runtime call instead of a slice + view + copy through the tensor library (~20 us of host time per
  * render in an eager training loop).  Not capturable in a hipGraph (a memcpy node): callers skip it under capture.
  */
 int exa_raster_read_header_async(const void* tile_ws, void* host_dst16, void* stream);
+int exa_raster_read_header_full_async(const void* tile_ws, void* host_dst32, void* stream);
+/* Device-visible address of pinned (page-locked, host-coherent) memory at `host_ptr`, for ExaRasterForwardJob.host_header. */
+int exa_raster_host_device_pointer(void* host_ptr, void** device_ptr_out);
+
+/*
+ * Camera block of GaussianRenderer.forward (module.py:604-608) from DEVICE-resident extrinsics: for R [dev float[9],
+ * row-major 3x3] and t [dev float[3]] writes viewmatrix = [[R, t], [0, 0, 0, 1]]^T (row-major [4,4]), projmatrix =
+ * viewmatrix @ proj^T and campos = -R^T t, the three device tensors ExaRasterSettings points at.  proj16_host = the
+ * [4,4] of get_proj_matrix (transforms.py:43-64; a function of focal length and image size only) in HOST memory,
+ * row-major, read during the call.  One tiny launch: a new camera per animation frame costs no read-back, no host
+ * matrix code and no upload (hipGraph-capturable).
+ */
+int exa_raster_camera_block(const float* R, const float* t, const float* proj16_host, float* viewmatrix_out,
+                            float* projmatrix_out, float* campos_out, void* stream);
 
 /* upstream markVisible: present[i] = (view-space z of means3D[i] > 0.2). */
 int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const float* means3D,

@@ -145,3 +145,28 @@ def clamped_scene(H, W, f):
         a['scale'][i] = torch.tensor([0.5, 0.45, 0.4])
         a['opacity'][i] = 0.6
     return a
+
+
+def fuzz_case(trial):
+    """Seeded random scene salted with edge cases -- opacity 0 / 1 / at the 1/255 bar, scales x1e-4 .. x300, centres at,
+    just beyond, before and behind the 0.2 near plane and exactly ON the camera plane, unnormalised quaternions, ragged image
+    sizes -- plus all three image gradients.  Shared by the CPU fuzz of the two oracles (tests/test_c_oracle.py) and the GPU
+    fuzz of the HIP path (tests/test_gpu_edge_cases.py).  Returns (assets, H, W, cam, G, Gd, Ga, bg)."""
+    from exavatar_release_amd import scenes
+    g = torch.Generator().manual_seed(1000 + trial)
+    H, W = int(torch.randint(9, 70, (1,), generator=g)), int(torch.randint(9, 90, (1,), generator=g))
+    P = int(torch.randint(8, 300, (1,), generator=g))
+    f = float(torch.rand(1, generator=g) * 150 + 20)
+    a = scenes.dist_a_random(P, H, W, seed=trial, focal=f, z_range=(0.1, 8.0))
+    n = max(1, P // 8)
+    idx = torch.randperm(P, generator=g)
+    pick = lambda vals, m: torch.tensor(vals)[torch.randint(0, len(vals), (m,), generator=g)]      # noqa: E731
+    a['opacity'][idx[:n]] = pick([0.0, 1.0, 1 / 255.0, 0.0039, 0.0040], n).view(-1, 1)
+    a['scale'][idx[n:2 * n]] *= pick([1e-4, 1e-2, 30.0, 300.0], n).view(-1, 1)
+    a['mean_3d'][idx[2 * n:3 * n], 2] = pick([0.2, 0.2000001, 0.19, -1.0, 0.0], n)
+    a['rotation'][idx[3 * n:4 * n]] *= 3.0
+    cam = scenes.ring_camera(H, W, trial % 7, 7, radius=3.0, center=(0.0, 0.0, 3.0), focal=f) if trial % 2 else \
+        scenes.neutral_camera(H, W, focal=f)
+    G, Gd, Ga = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    bg = torch.rand(3, generator=g)
+    return a, H, W, cam, G, Gd, Ga, bg

@@ -14,7 +14,7 @@ import torch
 from exavatar_release_amd import scenes
 from oracle import c_oracle as co
 from oracle import raster_oracle as ro
-from tests.helpers import clamped_scene
+from tests.helpers import clamped_scene, fuzz_case
 
 KEYS = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
 IMG_TOL = 2e-6          # float32 rounding of ~100 blended terms (measured <= 3e-7 on colour, <= 2e-6 on depth)
@@ -269,22 +269,7 @@ def test_edge_case_fuzz_agrees_between_the_two_restatements(trial):
     just beyond, before and behind the 0.2 near plane and exactly ON the camera plane, unnormalised quaternions, ragged image
     sizes, all three image gradients -- through both restatements: same radii, same n_contrib, finite results, same
     gradients.  (Found this way: autograd returned NaN instead of 0 for a culled Gaussian on the camera plane.)"""
-    g = torch.Generator().manual_seed(1000 + trial)
-    H, W = int(torch.randint(9, 70, (1,), generator=g)), int(torch.randint(9, 90, (1,), generator=g))
-    P = int(torch.randint(8, 300, (1,), generator=g))
-    f = float(torch.rand(1, generator=g) * 150 + 20)
-    a = scenes.dist_a_random(P, H, W, seed=trial, focal=f, z_range=(0.1, 8.0))
-    n = max(1, P // 8)
-    idx = torch.randperm(P, generator=g)
-    pick = lambda vals, m: torch.tensor(vals)[torch.randint(0, len(vals), (m,), generator=g)]      # noqa: E731
-    a['opacity'][idx[:n]] = pick([0.0, 1.0, 1 / 255.0, 0.0039, 0.0040], n).view(-1, 1)
-    a['scale'][idx[n:2 * n]] *= pick([1e-4, 1e-2, 30.0, 300.0], n).view(-1, 1)
-    a['mean_3d'][idx[2 * n:3 * n], 2] = pick([0.2, 0.2000001, 0.19, -1.0, 0.0], n)
-    a['rotation'][idx[3 * n:4 * n]] *= 3.0
-    cam = scenes.ring_camera(H, W, trial % 7, 7, radius=3.0, center=(0.0, 0.0, 3.0), focal=f) if trial % 2 else \
-        scenes.neutral_camera(H, W, focal=f)
-    G, Gd, Ga = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
-    bg = torch.rand(3, generator=g)
+    a, H, W, cam, G, Gd, Ga, bg = fuzz_case(trial)
     t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
     r = ro.render(t, (H, W), cam, bg, return_aux=True)
     ((r['img'] * G).sum() + (r['depthmap'] * Gd).sum() + (r['mask'] * Ga).sum()).backward()

@@ -23,6 +23,9 @@ def test_shard_views_partition_and_reshuffle():
     assert shard_views(200, 0, 8, epoch=0) != shard_views(200, 0, 8, epoch=1)
     assert shard_views(10, 1, 2, shuffle=False) == [1, 3, 5, 7, 9]
     assert shard_views(10, 2, 3, shuffle=False) == [2, 5, 8, 1] and shard_views(10, 2, 3, shuffle=False, pad=False) == [2, 5, 8]
+    # fewer views than ranks: the permutation is repeated, no rank is left with an empty shard (it would hang the others)
+    assert [shard_views(1, r, 4, shuffle=False) for r in range(4)] == [[0]] * 4
+    assert [len(shard_views(3, r, 8)) for r in range(8)] == [1] * 8
 
 
 def _worker(rank, world, port, q):

@@ -1,0 +1,372 @@
+"""GPU parity on the inputs the reference PRODUCES but a synthetic benchmark scene never shows (round-2 verdict,
+"HIP-path coverage of degenerate inputs"): the seeded edge-case fuzz of tests/test_c_oracle.py through the HIP path,
+the warm-up regime of avatar/main/model.py:92-97 (every human splat clamped to scale <= 1e-3: all at the 0.3 px^2
+low-pass floor, radius 2) at the full C3 size, scene-like inputs (opacities from a sigmoid down to the 1/255 bar,
+unnormalised quaternions as avatar/common/nets/module.py:253-272 can hand them over), the transparent retry after an
+instance-buffer overflow, densification statistics shared by the views of one batch, and a two-rank run whose
+all-reduced flat gradient must equal the single-process sum over the same views.
+Same bars as everywhere: image 1e-4 L-inf off ambiguous pixels, radii bit-equal, gradients 1e-3 relative.
+/root/reference is never read here."""
+import json
+import os
+import subprocess
+import sys
+import warnings
+
+import pytest
+import torch
+
+import exavatar_release_amd as exa
+from exavatar_release_amd import rasterizer as rz
+from exavatar_release_amd import scenes
+from oracle import c_oracle as co
+from oracle import raster_oracle as ro
+from tests.helpers import (IMG_TOL, assert_grads_close, assert_image_close, fuzz_case, gaussians_near_pixels, grad_stats,
+                           image_stats, record_stats, rotation_grad_scale)
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    from exavatar_release_amd import _lib
+    _lib.load()          # fail loudly if the HIP library is missing
+    exa.config.mode = 'exact'
+    exa.config.fixed_capacity = None
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    return torch.device('cuda:0')
+
+
+def _to(d, dev, grad=True):
+    return {k: v.to(dev).requires_grad_(grad) for k, v in d.items()}
+
+
+@pytest.mark.parametrize('trial', range(16))
+def test_edge_case_fuzz_through_the_hip_path(dev, trial):
+    """The 16 seeded trials of tests/test_c_oracle.py::test_edge_case_fuzz_* through GaussianRenderer: opacity 0 / 1 / at
+    the 1/255 bar, scales x1e-4 .. x300, centres at / around / behind the near plane and ON the camera plane, unnormalised
+    quaternions, ragged image sizes, all three image gradients.  Against the C oracle (values) with the float64 run of
+    the PyTorch oracle as arbiter for the gradients, exactly as the CPU fuzz holds the two oracles against each other."""
+    a, H, W, cam, G, Gd, Ga, bg = fuzz_case(trial)
+    ag = _to(a, dev)
+    out = exa.GaussianRenderer()(ag, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    ((out['img'] * G.to(dev)).sum() + (out['depthmap'] * Gd.to(dev)).sum() + (out['mask'] * Ga.to(dev)).sum()).backward()
+    c = co.render(a, (H, W), cam, bg, dL_dimg=G, dL_ddepth=Gd, dL_dalpha=Ga)
+    t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+    r = ro.render(t, (H, W), cam, bg, return_aux=True)
+    amb = ro.ambiguous_pixel_mask(r['aux'], H, W) | (c['pixel_margin'] < 1e-4)
+    # structure: radii / visibility bit-equal, everything finite, culled Gaussians get exactly zero
+    assert torch.equal(out['radius'].cpu(), c['radius']), 'radii differ'
+    assert torch.equal(out['is_vis'].cpu(), c['radius'] > 0)
+    for k in ('img', 'depthmap', 'mask'):
+        assert bool(torch.isfinite(out[k]).all()), k
+    culled = c['radius'] == 0
+    grads = {k: ag[k].grad.cpu() for k in KEYS}
+    grads['mean_2d'] = out['mean_2d'].grad.cpu()
+    for k, g in grads.items():
+        assert bool(torch.isfinite(g).all()), k
+        assert not bool(g[culled].any()), 'culled Gaussians must get zero gradient: ' + k
+    # images on every pixel whose decisions are not at a threshold (depth scaled by its magnitude: z reaches 8)
+    if bool((~amb).any()):
+        for k, ref, scale in (('img', c['img'], 1.0), ('mask', c['mask'], 1.0),
+                              ('depthmap', c['depthmap'], 1.0 + float(c['depthmap'].abs().max()))):
+            d = (out[k].detach().cpu() - ref).abs()
+            d = d.amax(0) if d.dim() == 3 else d
+            assert float(d[~amb].max()) <= IMG_TOL * scale, '%s off by %.3e' % (k, float(d[~amb].max()))
+    # gradients: float64 arbiter, only when no decision flips between float32 and float64 and no pixel is ambiguous
+    # (tiny images where EVERY Gaussian covers every pixel: one flipped decision moves every gradient)
+    t64 = {k: v.clone().double().requires_grad_(True) for k, v in a.items()}
+    r64 = ro.render(t64, (H, W), cam, bg, dtype=torch.float64, return_aux=True)
+    ((r64['img'] * G.double()).sum() + (r64['depthmap'] * Gd.double()).sum() + (r64['mask'] * Ga.double()).sum()).backward()
+    same = bool((c['n_contrib'] == r['aux']['n_contrib']).all()) and bool((r64['aux']['n_contrib'] == r['aux']['n_contrib']).all()) \
+        and bool((r64['radius'] == r['radius']).all())
+    stats = {'trial': trial, 'H': H, 'W': W, 'P': int(a['mean_3d'].shape[0]), 'n_ambiguous': int(amb.sum()), 'same': same}
+    if same and not bool(amb.any()):
+        for k in KEYS + ('mean_2d',):
+            ref = (t64[k].grad if k != 'mean_2d' else r64['mean_2d'].grad).float()
+            scale = float(ref.abs().max()) + 1e-12
+            if k == 'rotation':
+                scale = max(scale, float(t64['scale'].grad.abs().max() * t64['scale'].detach().abs().max()))
+            err = float((grads[k] - ref).abs().max()) / scale
+            stats['grad_' + k] = err
+            assert err <= 1e-3, 'grad %s: %.3e of the max-norm' % (k, err)
+    record_stats('fuzz_%d' % trial, stats)
+
+
+def _warmup_assets(P, seed=0):
+    """What HumanGaussian hands the renderer during warm-up: Dist-B with `scale.clamp(max=1e-3)`
+    (reference avatar/main/model.py:92-97)."""
+    a = scenes.dist_b_avatar(P, seed=seed)
+    a['scale'] = a['scale'].clamp(max=1e-3)
+    return a
+
+
+def test_warmup_scale_clamp_small(dev):
+    """Warm-up regime at a size the PyTorch oracle handles in a second: every splat at the 0.3 px^2 low-pass floor."""
+    H, W, f = 192, 160, 260.0
+    a = _warmup_assets(12000, seed=3)
+    cam = scenes.ring_camera(H, W, 4, 24, focal=f)
+    g = torch.Generator().manual_seed(21)
+    G, bg = torch.randn(3, H, W, generator=g), torch.rand(3, generator=g)
+    ag = _to(a, dev)
+    out = exa.GaussianRenderer()(ag, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    (out['img'] * G.to(dev)).sum().backward()
+    t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+    ref = ro.render(t, (H, W), cam, bg, return_aux=True)
+    (ref['img'] * G).sum().backward()
+    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W)
+    assert int(ref['radius'][ref['radius'] > 0].max()) <= 3        # the regime: radius 2 (3 at the frustum edge)
+    for k, w in (('img', ref['img']), ('depthmap', ref['depthmap']), ('mask', ref['mask'])):
+        assert_image_close(out[k], w, amb, k)
+    assert torch.equal(out['radius'].cpu(), ref['radius'])
+    near = gaussians_near_pixels(ref['aux']['pre'], amb)
+    for k in KEYS:
+        assert_grads_close(ag[k].grad, t[k].grad, k, near,
+                           abs_scale=rotation_grad_scale(t['scale'], t['scale'].grad) if k == 'rotation' else 0.0)
+    assert_grads_close(out['mean_2d'].grad, ref['mean_2d'].grad, 'mean_2d', near)
+
+
+@pytest.mark.parametrize('P,view', [(150_000, 0), (167_000, 77)])
+def test_warmup_scale_clamp_regime_full_size(dev, P, view):
+    """The warm-up regime at the headline size: 150 k (167 k) avatar-like Gaussians with scale <= 1e-3 at 1024x1024 --
+    every splat covers ~2x2 sub-tiles with the minimum footprint, lists are short and uniform (the opposite corner of
+    the binning / sort / blend code from the benchmark scene).  Against the C oracle, same bars as C3."""
+    H = W = 1024
+    a = _warmup_assets(P)
+    cam = scenes.ring_camera(H, W, view, 200)
+    g = torch.Generator().manual_seed(300 + view)
+    G, bg = torch.randn(3, H, W, generator=g), torch.rand(3, generator=g)
+    ag = _to(a, dev)
+    out = exa.GaussianRenderer()(ag, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    (out['img'] * G.to(dev)).sum().backward()
+    ref = co.render(a, (H, W), cam, bg, dL_dimg=G)
+    amb = ref['pixel_margin'] < 1e-4
+    stats = {'P': P, 'H': H, 'W': W, 'max_radius': int(ref['radius'].max())}
+    assert stats['max_radius'] <= 3
+    for name, got, want in (('img', out['img'], ref['img']), ('depth', out['depthmap'], ref['depthmap']),
+                            ('alpha', out['mask'], ref['mask'])):
+        stats[name] = image_stats(got, want, amb)
+        assert_image_close(None, None, amb, name, 1500, stats=stats[name])
+    assert torch.equal(out['radius'].cpu(), ref['radius']), 'radii differ'
+    with torch.no_grad():
+        so = ro.settings_from_camera(cam, (H, W), bg)
+        pre = ro.preprocess(a['mean_3d'], None, a['opacity'], a['scale'], a['rotation'], None, so, torch.float32)
+    near = gaussians_near_pixels(pre, amb)
+    for k in KEYS + ('mean_2d',):
+        got = ag[k].grad if k != 'mean_2d' else out['mean_2d'].grad
+        stats['grad_' + k] = assert_grads_close(
+            got, ref['grads'][k], k, near,
+            abs_scale=rotation_grad_scale(a['scale'], ref['grads']['scale']) if k == 'rotation' else 0.0)
+    record_stats('warmup_P%d_view%d' % (P, view), stats)
+
+
+def test_scene_like_inputs_sigmoid_opacities_and_raw_quaternions(dev):
+    """What SceneGaussian.forward produces (module.py:253-272): opacity = sigmoid(raw) spread down to and below the 1/255
+    bar, scale = exp(raw) over two decades, rotation from a 6D parametrisation (here: quaternions left unnormalised, norm
+    0.5 .. 2 -- the rasterizer must use them as they are)."""
+    H, W, f = 144, 208, 210.0
+    P = 5000
+    a = scenes.dist_a_random(P, H, W, seed=41, focal=f)
+    g = torch.Generator().manual_seed(42)
+    a['opacity'] = torch.sigmoid(torch.randn(P, 1, generator=g) * 2.5 - 2.0)         # many below / around 1/255
+    a['opacity'][:50] = torch.tensor([1 / 255.0, 0.00392, 0.00393, 0.0040, 0.0])[torch.randint(0, 5, (50,), generator=g)].view(-1, 1)
+    a['scale'] = torch.exp(torch.randn(P, 3, generator=g) * 1.0 - 4.0)
+    a['rotation'] = a['rotation'] * (0.5 + 1.5 * torch.rand(P, 1, generator=g))
+    cam = scenes.ring_camera(H, W, 2, 9, radius=3.0, center=(0.0, 0.0, 3.0), focal=f)
+    G, Gd, Ga = torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    bg = torch.rand(3, generator=g)
+    ag = _to(a, dev)
+    out = exa.GaussianRenderer()(ag, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    ((out['img'] * G.to(dev)).sum() + (out['depthmap'] * Gd.to(dev)).sum() + (out['mask'] * Ga.to(dev)).sum()).backward()
+    t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+    ref = ro.render(t, (H, W), cam, bg, return_aux=True)
+    ((ref['img'] * G).sum() + (ref['depthmap'] * Gd).sum() + (ref['mask'] * Ga).sum()).backward()
+    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W)
+    for k in ('img', 'depthmap', 'mask'):
+        assert_image_close(out[k], ref[k], amb, k)
+    assert torch.equal(out['radius'].cpu(), ref['radius'])
+    near = gaussians_near_pixels(ref['aux']['pre'], amb)
+    for k in KEYS:
+        assert_grads_close(ag[k].grad, t[k].grad, k, near,
+                           abs_scale=rotation_grad_scale(t['scale'], t['scale'].grad) if k == 'rotation' else 0.0)
+    assert_grads_close(out['mean_2d'].grad, ref['mean_2d'].grad, 'mean_2d', near)
+
+
+# ---- overflow: transparent retry ---------------------------------------------------------------------------------
+def _reset_config():
+    exa.config.mode = 'exact'
+    exa.config.fixed_capacity = None
+    exa.config.on_overflow = 'retry'
+    exa.config.overflow_check = 'adaptive'
+
+
+def test_overflowed_render_is_retried_in_backward_with_correct_gradients(dev):
+    """Capacity mode with a buffer that is far too small: the render's own backward finds the overflow in the header report,
+    re-runs the forward with the capacity the report names (outputs corrected in place) and returns the gradients of the
+    complete render -- equal to an exact-mode render bit for bit (the pipeline is deterministic)."""
+    assets, shape, cam = scenes.make_config('c1')
+    camd = {k: v.to(dev) for k, v in cam.items()}
+    G = torch.randn(3, *shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    a_ref = _to(assets, dev)
+    ref = exa.GaussianRenderer()(a_ref, shape, camd, torch.ones(3, device=dev))
+    (ref['img'] * G).sum().backward()
+    try:
+        exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
+        n0 = len(rz.overflow_events)
+        a = _to(assets, dev)
+        out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            (out['img'] * G).sum().backward()
+        assert any('re-rendered' in str(x.message) for x in w)
+        assert len(rz.overflow_events) == n0 + 1 and rz.overflow_events[-1][3] == 'retried'
+        torch.cuda.synchronize()
+        assert torch.equal(out['img'].detach(), ref['img'].detach())          # corrected in place
+        assert torch.equal(out['radius'], ref['radius'])
+        for k in KEYS:
+            assert torch.equal(a[k].grad, a_ref[k].grad), k
+        assert torch.equal(out['mean_2d'].grad, ref['mean_2d'].grad)
+        # strict mode: the same situation raises from backward, as before
+        exa.config.on_overflow = 'raise'
+        a2 = _to(assets, dev)
+        out2 = exa.GaussianRenderer()(a2, shape, camd, torch.ones(3, device=dev))
+        with pytest.raises(RuntimeError, match='overflow'):
+            out2['img'].sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        _reset_config()
+
+
+def test_overflowed_no_grad_render_is_rerendered_when_drained(dev):
+    assets, shape, cam = scenes.make_config('c1')
+    camd = {k: v.to(dev) for k, v in cam.items()}
+    a = _to(assets, dev, grad=False)
+    with torch.no_grad():
+        ref = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+    try:
+        exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
+        with torch.no_grad():
+            out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter('always')
+            exa.check_overflow()
+        torch.cuda.synchronize()
+        assert torch.equal(out['img'], ref['img']) and torch.equal(out['depthmap'], ref['depthmap'])
+        exa.config.on_overflow = 'raise'
+        with torch.no_grad():
+            exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+        with pytest.raises(RuntimeError, match='overflow'):
+            exa.check_overflow()
+    finally:
+        _reset_config()
+
+
+def test_two_sets_of_equal_size_alternate_without_errors(dev):
+    """Two Gaussian sets with the SAME P (so they share the capacity memo keyed on (P, H, W)) whose instance counts differ
+    by > 3x, rendered alternately in 'auto' mode: the first render of the dense set overflows the memo of the sparse one,
+    is retried inside its backward, and from then on the memo covers both -- no RuntimeError, gradients always those of
+    the exact-mode render."""
+    H, W, f, P = 160, 192, 220.0, 6000
+    sparse = scenes.dist_a_random(P, H, W, seed=51, focal=f)
+    dense = {k: v.clone() for k, v in sparse.items()}
+    dense['scale'] = dense['scale'] * 4.0                     # ~16x the footprint area
+    cam = {k: v.to(dev) for k, v in scenes.neutral_camera(H, W, focal=f).items()}
+    G = torch.randn(3, H, W, generator=torch.Generator().manual_seed(52)).to(dev)
+    bg = torch.ones(3, device=dev)
+    refs = []
+    for s in (sparse, dense):
+        a = _to(s, dev)
+        o = exa.GaussianRenderer()(a, (H, W), cam, bg)
+        (o['img'] * G).sum().backward()
+        refs.append(({k: a[k].grad.clone() for k in KEYS}, o['img'].detach().clone()))
+    try:
+        exa.config.mode = 'auto'
+        rz._seen_D.clear()
+        rz._verified.clear()
+        n0 = len(rz.overflow_events)
+        with warnings.catch_warnings(record=True):
+            warnings.simplefilter('always')
+            for it in range(6):
+                for s, (gref, iref) in zip((sparse, dense), refs):
+                    a = _to(s, dev)
+                    o = exa.GaussianRenderer()(a, (H, W), cam, bg)
+                    (o['img'] * G).sum().backward()
+                    torch.cuda.synchronize()
+                    assert torch.equal(o['img'].detach(), iref)
+                    for k in KEYS:
+                        assert torch.equal(a[k].grad, gref[k]), (it, k)
+        assert len(rz.overflow_events) - n0 <= 1              # at most the one retry
+    finally:
+        _reset_config()
+
+
+# ---- densification statistics shared by the views of a batch -----------------------------------------------------
+def test_views_of_one_batch_may_share_one_set_of_densify_stats(dev):
+    """K views of the same Gaussians accumulating into ONE (xyz_grad_accum, track_cnt, radius_max): the batched backward
+    sums the K views' statistics in the kernel and writes once per Gaussian (round-2 advisor finding: the per-view
+    read-modify-write raced between the waves that split the views).  Equals K sequential renders."""
+    H, W, f, P, K = 128, 160, 200.0, 5000, 5
+    a = scenes.dist_a_random(P, H, W, seed=61, focal=f)
+    cams = [{k: v.to(dev) for k, v in scenes.ring_camera(H, W, v, 11, radius=3.0, center=(0, 0, 4.0), focal=f).items()} for v in range(K)]
+    bg = torch.ones(3, device=dev)
+    rend = exa.GaussianRenderer()
+    seq = [torch.zeros(P, device=dev) for _ in range(3)]
+    for c in cams:
+        ag = _to(a, dev)
+        o = rend(ag, (H, W), c, bg, densify_stats=tuple(seq))
+        o['img'].square().sum().backward()
+    bat = [torch.zeros(P, device=dev) for _ in range(3)]
+    ag = _to(a, dev)
+    outs = exa.render_many(rend, [(ag, (H, W), c, bg, tuple(bat)) for c in cams])
+    sum(o['img'].square().sum() for o in outs).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(bat[1], seq[1]) and torch.equal(bat[2], seq[2])
+    assert torch.allclose(bat[0], seq[0], rtol=1e-5, atol=1e-12)           # K-term sums in a different order
+    assert float(bat[1].max()) == K
+    # two DIFFERENT Gaussian sets updating the same statistics in one batch: rejected (would race)
+    other = _to(scenes.dist_a_random(P, H, W, seed=62, focal=f), dev)
+    with pytest.raises(ValueError, match='densify_stats'):
+        exa.render_many(rend, [(ag, (H, W), cams[0], bg, tuple(bat)), (other, (H, W), cams[1], bg, tuple(bat))])
+
+
+def test_non_contiguous_inputs_in_a_batch_of_views(dev):
+    """Round-2 advisor finding: K views passing the same NON-contiguous tensor objects (rgb = feats[:, :3]) used to get K
+    private .contiguous() copies and fail the sum_shared pointer check in backward."""
+    H, W, f, P = 96, 128, 150.0, 3000
+    a = scenes.dist_a_random(P, H, W, seed=63, focal=f)
+    feats = torch.cat((a['rgb'], torch.zeros(P, 5)), 1).to(dev).requires_grad_(True)
+    ag = _to({k: v for k, v in a.items() if k != 'rgb'}, dev)
+    ag['rgb'] = feats[:, :3]
+    cams = [{k: v.to(dev) for k, v in scenes.ring_camera(H, W, v, 7, radius=3.0, center=(0, 0, 3.0), focal=f).items()} for v in range(3)]
+    outs = exa.render_views(exa.GaussianRenderer(), ag, (H, W), cams, torch.ones(3, device=dev))
+    sum(o['img'].sum() for o in outs).backward()
+    ref = _to(a, dev)
+    loss = 0
+    for c in cams:
+        loss = loss + exa.GaussianRenderer()(ref, (H, W), c, torch.ones(3, device=dev))['img'].sum()
+    loss.backward()
+    scale = float(ref['rgb'].grad.abs().max())
+    assert float((feats.grad[:, :3] - ref['rgb'].grad).abs().max()) <= 2e-6 * scale
+    assert not bool(feats.grad[:, 3:].any())
+
+
+# ---- two ranks: the all-reduced flat gradient equals the single-process sum over the same views ----------------------
+def test_two_rank_reduced_gradient_equals_single_process_sum(tmp_path):
+    """Two ranks (gloo, sharing this GPU -- RCCL refuses duplicate devices) rasterize their shards of 6 ring views fwd+bwd,
+    pack the gradients with the product's FlatGradAllReducer and all-reduce them; rank 0 then renders the union of the views
+    in ONE process (render_views, sum_shared) and compares: <= 1e-6 relative per tensor.  tests/_dist_grad_worker.py."""
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(29650 + os.getpid() % 200), os.path.join(ROOT, 'tests', '_dist_grad_worker.py')]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['world'] == 2 and res['views'] == 6
+    for k, v in res['rel_err'].items():
+        assert v <= 1e-6, (k, v)
+    record_stats('two_rank_gradient', res)

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 121
+    assert lib.exa_raster_version() == 130
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
@@ -83,7 +83,8 @@ def test_argument_validation_returns_negative_status_without_touching_the_gpu():
 
 def test_batch_job_structs_match_c_layout():
     # LP64: pointer, 2 x int32, then 8-byte fields only
-    assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8
+    assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8 + 8 + 8     # + host_header, header_tag (padded)
+    assert _lib.ExaRasterForwardJob.host_header.offset == 136 and _lib.ExaRasterForwardJob.header_tag.offset == 144
     assert _lib.ExaRasterForwardJob.capacity.offset == 104 and _lib.ExaRasterForwardJob.out_color.offset == 112
     assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8 + 8
     assert _lib.ExaRasterBackwardJob.grad_first.offset == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8
@@ -115,6 +116,34 @@ def test_batch_job_structs_match_c_layout():
     b.grad_first = 10                     # nothing trainable: a no-op that touches no pointer
     assert lib.exa_raster_backward_batch(bj, 1, 0, None) == 0
     assert lib.exa_raster_read_header_async(None, None, None) == -2
+    assert lib.exa_raster_read_header_full_async(None, None, None) == -2
+    assert lib.exa_raster_camera_block(None, None, None, None, None, None, None) == -2
+    assert lib.exa_raster_host_device_pointer(None, None) == -2
+    # two jobs of one batch updating the same densification statistics: rejected (-5) unless sum_shared with the same
+    # three arrays in every job
+    bj2 = (_lib.ExaRasterBackwardJob * 2)()
+    for q in bj2:
+        q.settings = ctypes.pointer(st)
+        q.P = 10
+        for name in ('means3D', 'colors_precomp', 'opacities', 'scales', 'rotations', 'radii', 'geom_ws', 'tile_ws', 'grad_ws',
+                     'dL_dcolor'):
+            setattr(q, name, 4096)
+        q.grad_first = 10
+        q.densify_grad_accum = 8192
+    assert lib.exa_raster_backward_batch(bj2, 2, 0, None) == -5 and b'densification' in lib.exa_raster_last_error()
+    bj2[1].densify_grad_accum = 16384
+    assert lib.exa_raster_backward_batch(bj2, 2, 0, None) == 0
+
+
+def test_header_status_and_struct():
+    lib = _lib.load()
+    assert ctypes.sizeof(_lib.ExaRasterHeader) == 28
+    h = _lib.ExaRasterHeader()
+    h.num_rendered, h.overflow = 4096, 0
+    assert lib.exa_raster_header_status(ctypes.byref(h)) == 0
+    h.overflow = 1
+    assert lib.exa_raster_header_status(ctypes.byref(h)) == -4 and b'4096' in lib.exa_raster_last_error()
+    assert lib.exa_raster_header_status(None) == -2
 
 
 def test_python_surface_matches_the_reference_plugin():

@@ -11,7 +11,8 @@ def tile_offsets(P, W, H):
     chunks = (P + CHUNK - 1) // CHUNK
     off, out = HEADER_BYTES, {}
     for name, size in (('chunk_cell', chunks * cells * 8), ('cell_cnt', cells * 8), ('cell_off', (cells + 1) * 8),
-                       ('chunk_inst', (chunks + 1) * 4), ('chunk_vis', (chunks + 1) * 4), ('chunk_off', (chunks + 1) * 4),
+                       ('chunk_inst', (chunks + 1) * 4), ('chunk_vis', (chunks + 1) * 4), ('chunk_tiles', (chunks + 1) * 4),
+                       ('chunk_off', (chunks + 1) * 4),
                        ('cell_desc', cells * 16), ('ranges', cells * SUBS * 8), ('slots', cells * SUBS * 16),
                        ('fwd_exit', cells * SUBS * 8), ('part_cnt', cells * BIN_PARTS * SUBS * 4), ('cell_long', cells * 4)):
         out[name] = (off, size)
