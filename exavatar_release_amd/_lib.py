@@ -106,7 +106,8 @@ SIGNATURES = {
     'exa_raster_host_device_pointer': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
     'exa_raster_header_status': (ctypes.c_int, [ctypes.POINTER(ExaRasterHeader)]),
     'exa_raster_camera_block': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_float), c_void_p, c_void_p,
-                                               c_void_p, c_void_p]),
+                                               c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p,
+                                               ctypes.c_uint32, c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),

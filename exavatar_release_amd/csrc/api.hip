@@ -447,12 +447,16 @@ int exa_raster_header_status(const ExaRasterHeader* h) {
 }
 
 int exa_raster_camera_block(const float* R, const float* t, const float* proj16_host, float* viewmatrix_out,
-                            float* projmatrix_out, float* campos_out, void* stream) {
+                            float* projmatrix_out, float* campos_out, const float* focal, float fx_expected,
+                            float fy_expected, void* host_flag, uint32_t flag_tag, void* stream) {
     if (!R || !t || !proj16_host || !viewmatrix_out || !projmatrix_out || !campos_out)
         return fail(EXA_RASTER_E_NULLPTR, "camera_block: NULL pointer");
+    if ((focal != nullptr) != (host_flag != nullptr))
+        return fail(EXA_RASTER_E_INVALID, "camera_block: pass both focal and host_flag, or neither");
     Proj16 p;
     memcpy(p.m, proj16_host, sizeof(p.m));
-    EXA_HIP(launch_camera_block(R, t, p, viewmatrix_out, projmatrix_out, campos_out, static_cast<hipStream_t>(stream)),
+    EXA_HIP(launch_camera_block(R, t, p, viewmatrix_out, projmatrix_out, campos_out, focal, fx_expected, fy_expected,
+                                static_cast<uint32_t*>(host_flag), flag_tag, static_cast<hipStream_t>(stream)),
             "camera_block");
     return 0;
 }

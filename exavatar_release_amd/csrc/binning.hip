@@ -259,13 +259,13 @@ __device__ __forceinline__ bool footprint_row(const Footprint& f, float yl, floa
 // every cell comes from the scanned count matrix, ranks inside it from LDS atomics, (c) clears this
 // workgroup's slice of the batch-owner array.
 constexpr int SC_BLOCK = CHUNK;        // one Gaussian per thread
-// Zero-copy header report (ExaRasterForwardJob.host_header): four system-scope dword stores into host-coherent pinned
-// memory, the tag behind a system-scope release fence so that a host that sees the tag sees the values.
+// Zero-copy header report (ExaRasterForwardJob.host_header): ONE 16-byte write-through store (sc0 sc1 = system scope) into
+// host-coherent pinned memory -- a single bus transaction, so a host that sees the tag sees the three values, without
+// a release fence (which would write the whole L2 of this XCD back first).
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void report_header(uint32_t* host_hdr, uint32_t need, uint32_t overflow, uint32_t vis, uint32_t tag) {
-    __hip_atomic_store(host_hdr + 0, need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_hdr + 1, overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_hdr + 2, vis, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(host_hdr + 3, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const v4u v = {need, overflow, vis, tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(host_hdr), "v"(v) : "memory");
 }
 __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> batch) {
     // base[cells] | cnt2[cells] (u32)  [ | tot[cells] | bef[cells] (u64) when the scans are merged into this kernel ]

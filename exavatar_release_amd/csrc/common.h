@@ -253,7 +253,8 @@ hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 struct Proj16 { float m[16]; };
 hipError_t launch_camera_block(const float* R, const float* t, const Proj16& proj, float* view_out, float* proj_out,
-                               float* campos_out, hipStream_t s);
+                               float* campos_out, const float* focal, float fx, float fy, uint32_t* host_flag, uint32_t tag,
+                               hipStream_t s);
 
 hipError_t launch_zero(void* p, size_t bytes, hipStream_t s);
 

@@ -371,10 +371,20 @@ __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float*
 // get_proj_matrix's [4, 4] (transforms.py:43-64; depends on focal and image size only), row-major, passed by value.
 // The sums run k = 0..3 left to right (this file is compiled with -ffp-contract=off); the columns the kernels read
 // (0, 1, 3) have a single non-zero term each, so they equal what any matmul computes.
+// Optional focal-length check: `proj` (and the tan(fov) baked into the rasterizer's kernel arguments) were derived on the
+// host from a focal length the caller REMEMBERS; when `focal` (device float[2]) is given, lane 19 compares it with that
+// memory (fx, fy) and reports {equal, 0, 0, tag} into 16 bytes of pinned host memory (same zero-copy scheme as the header
+// report in binning.hip), so a caller that gets a fresh focal tensor every frame never has to read it back.
+typedef uint32_t cam_v4u __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void camera_block_kernel(const float* __restrict__ R, const float* __restrict__ t, Proj16 proj,
                                                           float* __restrict__ view_out, float* __restrict__ proj_out,
-                                                          float* __restrict__ campos_out) {
+                                                          float* __restrict__ campos_out, const float* __restrict__ focal,
+                                                          float fx, float fy, uint32_t* host_flag, uint32_t tag) {
     const int l = threadIdx.x;
+    if (l == 19 && focal && host_flag) {
+        const cam_v4u v = {(focal[0] == fx && focal[1] == fy) ? 1u : 0u, 0u, 0u, tag};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(host_flag), "v"(v) : "memory");
+    }
     if (l < 16) {
         const int i = l >> 2, j = l & 3;                        // row i, column j of the TRANSPOSED view matrix
         auto vt = [&](int r, int c) -> float {                  // view^T[r][c] = view[c][r]
@@ -392,8 +402,9 @@ __global__ __launch_bounds__(64) void camera_block_kernel(const float* __restric
 }
 
 hipError_t launch_camera_block(const float* R, const float* t, const Proj16& proj, float* view_out, float* proj_out,
-                               float* campos_out, hipStream_t s) {
-    camera_block_kernel<<<1, 64, 0, s>>>(R, t, proj, view_out, proj_out, campos_out);
+                               float* campos_out, const float* focal, float fx, float fy, uint32_t* host_flag, uint32_t tag,
+                               hipStream_t s) {
+    camera_block_kernel<<<1, 64, 0, s>>>(R, t, proj, view_out, proj_out, campos_out, focal, fx, fy, host_flag, tag);
     return hipGetLastError();
 }
 

@@ -76,32 +76,59 @@ def _proj_host(cam_param, img_shape):
     fov = get_fov(focal, None, shape)
     proj = get_proj_matrix(focal, None, shape, 0.01, 100.0, 1.0)
     res = (float(torch.tan(fov[0] / 2)), float(torch.tan(fov[1] / 2)),
-           (ctypes.c_float * 16)(*[float(v) for v in proj.reshape(-1).tolist()]))
+           (ctypes.c_float * 16)(*[float(v) for v in proj.reshape(-1).tolist()]), float(focal[0]), float(focal[1]))
     if isinstance(f, torch.Tensor):
         _proj_cache.insert(0, (f, f._version, shape, res))
         del _proj_cache[4:]
     return res
 
 
-def camera_block_device(cam_param, img_shape, out38):
+def camera_block_device(cam_param, img_shape, out38, expect=None, flag=None):
     """Write the camera block of ``GaussianRenderer.forward`` (module.py:604-608) for DEVICE tensors ``cam_param['R']``
     / ``['t']`` into ``out38`` (float32 [>= 35] on the same device: viewmatrix 16 | projmatrix 16 | campos 3) with ONE
     tiny kernel (``exa_raster_camera_block``): no read-back of the extrinsics, no host matrix code, no upload.
-    Returns ``(tanfovx, tanfovy)``.  The three columns of ``projmatrix`` the rasterizer reads have one non-zero term
-    each and equal the host path's; ``campos`` is ``-R^T t`` instead of a general matrix inverse (equal up to rounding
-    for a rotation matrix; it only enters the SH view direction)."""
+    Returns the intrinsics record ``(tanfovx, tanfovy, proj16, fx, fy)`` it used.  The three columns of ``projmatrix``
+    the rasterizer reads have one non-zero term each and equal the host path's; ``campos`` is ``-R^T t`` instead of a
+    general matrix inverse (equal up to rounding for a rotation matrix; it only enters the SH view direction).
+
+    ``expect`` + ``flag``: an intrinsics record from an earlier call and a ``(device address, tag)`` of 16 bytes of
+    pinned host memory: the focal tensor is then NOT read back -- the kernel compares it with ``expect`` on the device
+    and reports into the flag slot (1 = unchanged), which the caller polls after its frame."""
     from . import _lib
-    tanx, tany, proj16 = _proj_host(cam_param, img_shape)
     dev = out38.device
+    f = cam_param['focal']
+    check = expect is not None and flag is not None and isinstance(f, torch.Tensor) and f.device == dev and \
+        f.dtype == torch.float32 and f.is_contiguous() and f.numel() == 2
+    intr = expect if check else _proj_host(cam_param, img_shape)
     R, t = cam_param['R'], cam_param['t']
     if not (isinstance(R, torch.Tensor) and R.device == dev and R.dtype == torch.float32 and R.is_contiguous()):
         R = torch.as_tensor(R, dtype=torch.float32).to(dev).contiguous()
     if not (isinstance(t, torch.Tensor) and t.device == dev and t.dtype == torch.float32 and t.is_contiguous()):
         t = torch.as_tensor(t, dtype=torch.float32).to(dev).contiguous()
     base = out38.data_ptr()
-    _lib.check(_lib.load().exa_raster_camera_block(R.data_ptr(), t.data_ptr(), proj16, base, base + 64, base + 128,
-                                                   ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
-    return tanx, tany
+    _lib.check(_lib.load().exa_raster_camera_block(
+        R.data_ptr(), t.data_ptr(), intr[2], base, base + 64, base + 128,
+        f.data_ptr() if check else None, intr[3], intr[4], flag[0] if check else None, flag[1] if check else 0,
+        ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    return intr, check
+
+
+_probe_cache = []      # most recent first: (P, device, zeros [P, 3]); treat the probes as read-only
+
+
+def _zero_probe(P, device):
+    for i, (cp, cd, z) in enumerate(_probe_cache):
+        if cp == P and cd == device:
+            if i:
+                _probe_cache.insert(0, _probe_cache.pop(i))
+            break
+    else:
+        z = torch.zeros((P, 3), dtype=torch.float32, device=device)
+        _probe_cache.insert(0, (P, device, z))
+        del _probe_cache[4:]
+    m = z.detach()
+    m.requires_grad = True
+    return m
 
 
 def _sh_degree(gaussian_assets):
@@ -144,11 +171,10 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
         prefiltered=False,
         debug=False,
     )
-    # screen-space position probe for the densification gradient (module.py:626-629)
-    point_num = mean_3d.shape[0]
-    mean_2d = torch.zeros((point_num, 3), dtype=torch.float32, device=device)
-    mean_2d.requires_grad = True
-    mean_2d.retain_grad()
+    # screen-space position probe for the densification gradient (module.py:626-629: zeros, requires_grad, retain_grad).
+    # The rasterizer never reads its VALUES (only its .grad is produced), so every render gets a fresh leaf that aliases one
+    # cached block of zeros instead of paying an allocation + a fill kernel per render (retain_grad is a no-op on a leaf).
+    mean_2d = _zero_probe(mean_3d.shape[0], device)
     frozen = None
     if frozen_assets is not None:
         if (_sh_degree(frozen_assets) is None) != (sh_degree is None):
@@ -308,6 +334,7 @@ class GraphedRenderer:
         self._last = {}                                       # key -> (source tensor, its version) of the previous frame
         self._slot = None                                     # (slot, tag) of the header report baked into the graph
         self._bg_src, self._bg_ver = None, None
+        self._intr, self._focal_src, self._focal_ver = None, None, None     # last verified intrinsics record / focal tensor
         self.captures = 0
 
     @property
@@ -397,15 +424,39 @@ class GraphedRenderer:
             if self._bg_src is not bg or self._bg_ver != getattr(bg, '_version', None):
                 self._cam[35:38].copy_(torch.as_tensor(bg, dtype=torch.float32).reshape(-1))
                 self._bg_src, self._bg_ver = bg, getattr(bg, '_version', None)
-            tan = camera_block_device(cam_param, self.shape, self._cam)
-        with torch.cuda.device(dev):
-            for _ in range(3):
+        f = cam_param['focal']
+        with rz._on_device(dev):
+            for _ in range(4):
+                # A focal tensor that is the very object (and version) of the last verified frame is trusted; a new object
+                # (a data loader hands out a fresh tensor per frame) is compared ON THE DEVICE with the remembered focal
+                # length by the camera kernel, which reports into a pinned host word polled after the replay: no read-back.
+                pool = rz._pool()
+                trusted = self._intr is not None and f is self._focal_src and getattr(f, '_version', None) == self._focal_ver
+                flag = None
+                if self._intr is not None and not trusted and pool is not None:
+                    fslot, ftag, faddr = pool.take()
+                    flag = (faddr, ftag)
+                intr, checking = camera_block_device(cam_param, self.shape, self._cam, self._intr if flag else None, flag)
+                if not checking:                              # intrinsics came from the host path (memo or read-back): verified
+                    self._intr, self._focal_src, self._focal_ver = intr, f, getattr(f, '_version', None)
+                tan = (intr[0], intr[1])
                 if self._graph is None or self._tan != tan:
                     self._capture(tan)
                 if self._slot is not None:
                     words, b = rz._hdr_pool.words, 4 * self._slot[0]
                     words[b + 3] = 0                          # (the previous replay's report has been read: no store in flight)
                 self._graph.replay()
+                if checking:
+                    words_f, bf = pool.words, 4 * fslot
+                    t_end = time.perf_counter() + 5e-3
+                    while words_f[bf + 3] != ftag and time.perf_counter() < t_end:
+                        pass
+                    if words_f[bf + 3] != ftag:
+                        torch.cuda.current_stream(dev).synchronize()
+                    if words_f[bf + 3] != ftag or words_f[bf] != 1:
+                        self._intr = None                     # the focal length changed: derive it again (one read-back),
+                        continue                              # re-capture if tan(fov) moved, and render this frame again
+                    self._focal_src, self._focal_ver = f, getattr(f, '_version', None)
                 if not self.check:
                     break
                 if self._slot is not None:

@@ -249,9 +249,15 @@ int exa_raster_host_device_pointer(void* host_ptr, void** device_ptr_out);
  * [4,4] of get_proj_matrix (transforms.py:43-64; a function of focal length and image size only) in HOST memory,
  * row-major, read during the call.  One tiny launch: a new camera per animation frame costs no read-back, no host
  * matrix code and no upload (hipGraph-capturable).
+ * Optional focal-length check (both NULL = off): proj16_host and the tan(fov) of ExaRasterSettings were derived from a
+ * focal length the caller remembers (fx_expected, fy_expected); `focal` = this frame's [dev float[2]].  The kernel
+ * compares them and stores {equal ? 1 : 0, 0, 0, flag_tag} into the 16 bytes at `host_flag` (a device-visible address of
+ * pinned host memory, exa_raster_host_device_pointer) -- a caller that is handed a fresh focal tensor with every frame
+ * (a data loader) learns about a zoom without ever reading the tensor back.
  */
 int exa_raster_camera_block(const float* R, const float* t, const float* proj16_host, float* viewmatrix_out,
-                            float* projmatrix_out, float* campos_out, void* stream);
+                            float* projmatrix_out, float* campos_out, const float* focal, float fx_expected,
+                            float fy_expected, void* host_flag, uint32_t flag_tag, void* stream);
 
 /* upstream markVisible: present[i] = (view-space z of means3D[i] > 0.2). */
 int exa_raster_mark_visible(const ExaRasterSettings* settings, int32_t P, const float* means3D,

@@ -117,7 +117,7 @@ def test_batch_job_structs_match_c_layout():
     assert lib.exa_raster_backward_batch(bj, 1, 0, None) == 0
     assert lib.exa_raster_read_header_async(None, None, None) == -2
     assert lib.exa_raster_read_header_full_async(None, None, None) == -2
-    assert lib.exa_raster_camera_block(None, None, None, None, None, None, None) == -2
+    assert lib.exa_raster_camera_block(None, None, None, None, None, None, None, 0.0, 0.0, None, 0, None) == -2
     assert lib.exa_raster_host_device_pointer(None, None) == -2
     # two jobs of one batch updating the same densification statistics: rejected (-5) unless sum_shared with the same
     # three arrays in every job

@@ -49,3 +49,24 @@ rgb_in = {k: a[k] for k in ('mean_3d', 'scale', 'rotation', 'opacity')}; rgb_in[
 gr2 = exa.GraphedRenderer(P, shape, dev, check=False)
 ms = timeit(lambda c: gr2(rgb_in, cams[0], bg))
 print('... with precomputed colours instead of SH (the reference\'s own path)  : %.3f ms / frame = %.0f frames/s' % (ms, 1e3 / ms))
+
+# where a frame's time goes: the bare replay of the captured graph, + the camera kernel, the whole __call__
+g = gr2._graph
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(64):
+    g.replay()
+torch.cuda.synchronize(); print('bare graph replay (rgb)              : %.3f ms' % ((time.perf_counter() - t0) / 64 * 1e3))
+from exavatar_release_amd.renderer import camera_block_device
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(64):
+    camera_block_device(cams[i % 16], shape, gr2._cam)
+    g.replay()
+torch.cuda.synchronize(); print('camera kernel (host path memo) + replay: %.3f ms' % ((time.perf_counter() - t0) / 64 * 1e3))
+t0 = time.perf_counter()
+for i in range(64):
+    gr2(rgb_in, cams[i % 16], bg)
+t1 = time.perf_counter(); torch.cuda.synchronize()
+print('GraphedRenderer.__call__ (rgb, new camera / frame, check=False): host %.3f ms / frame, wall %.3f ms / frame' % ((t1 - t0) / 64 * 1e3, (time.perf_counter() - t0) / 64 * 1e3))
+gr3 = exa.GraphedRenderer(P, shape, dev, check=True)
+ms = timeit(lambda c: gr3(rgb_in, c, bg))
+print('GraphedRenderer (rgb, new camera / frame, check=True): %.3f ms / frame' % ms)

@@ -22,4 +22,20 @@ print('eager render fwd+bwd through GaussianRenderer (mode %s): %.3f ms -> %.0f 
 pr = cProfile.Profile(); pr.enable()
 for _ in range(50): it()
 torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+pstats.Stats(pr).sort_stats('tottime').print_stats(30)
+
+# host time of the two halves (no synchronisation inside the loop: what the Python thread spends queueing work)
+import statistics
+tf, tb = [], []
+for _ in range(60):
+    for v in human.values(): v.grad = None
+    t0 = time.perf_counter(); o = rend(human, (H, W), cam, bg); t1 = time.perf_counter()
+    L = (o['img'] * G).sum(); t2 = time.perf_counter()
+    L.backward(); t3 = time.perf_counter()
+    tf.append(t1 - t0); tb.append(t3 - t2)
+    if _ % 8 == 7: torch.cuda.synchronize()
+print('host: forward %.1f us, backward (engine + raster backward + AccumulateGrad) %.1f us (medians)' % (statistics.median(tf) * 1e6, statistics.median(tb) * 1e6))
+# the five-render iteration of bench.py (extra_exavatar_iteration), 'sets' flavour
+import bench
+print(bench.iteration_throughput(dev, iters=20))
