@@ -66,8 +66,40 @@ constexpr int RBLOCK = 64;            // ONE wave per workgroup
 //   GC =  8: row =  8 pixels x {aG, w}         = 16 floats, group stride 132 floats         (4 224 B, 5 waves / SIMD;
 //            one pixel ROW per group: no y moments inside the loop, but three shuffle steps instead of two)
 template <int GC> struct XLayout;
-template <> struct XLayout<16> { static constexpr int ROW = 36, GROUP = 16 * 36, FLOATS = 4 * 16 * 36; };
-template <> struct XLayout<8> { static constexpr int ROW = 16, GROUP = 132, FLOATS = 8 * 132; };
+template <> struct XLayout<16> {
+    static constexpr int ROW = 36, GROUP = 16 * 36, FLOATS = 4 * 16 * 36;
+    static constexpr int WK = ROW;                                          // floats between consecutive entries (phase A)
+    __device__ static __forceinline__ int g(int lane) { return lane % 16; }      // phase B: entry of the chunk ...
+    __device__ static __forceinline__ int h(int lane) { return lane / 16; }      // ... and pixel group (two pixel rows)
+    __device__ static __forceinline__ int wbase(int lane) { return (lane / 16) * GROUP + 2 * (lane % 16); }
+    __device__ static __forceinline__ int rbase(int lane) { return h(lane) * GROUP + g(lane) * ROW; }
+    __device__ static __forceinline__ float reduce(float x) {              // sum over the four pixel groups of an entry
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        return x;
+    }
+};
+// GC = 8, entry-major lanes: lane = g * 8 + h sums pixel ROW h of entry g, so the eight partial sums of an entry sit in
+// eight CONSECUTIVE lanes and are combined with three DPP adds (quad_perm xor 1, xor 2, row_half_mirror) -- plain VALU
+// instructions, no LDS-pipe shuffle (the first GC = 8 layout was row-major: xor 8 / 16 / 32 = three ds_bpermute rounds on
+// ten values per chunk, measured 63.5 vs 56.4 us).  Layout [entry][pixel row][8 pixels x {aG, w}], entry stride 132
+// floats: phase-A stores of one entry are 64 contiguous 8-byte words, phase-B ds_read_b128 of the 16 lanes a quarter-wave
+// services start at 16 distinct multiples of 4 banks (entry stride = 4 banks mod 16).  4 224 B instead of 9 216:
+// 8 128 B of LDS per wave = 5 waves per SIMD instead of 3.
+template <> struct XLayout<8> {
+    static constexpr int ROW = 16, GROUP = 132, FLOATS = 8 * 132;
+    static constexpr int WK = GROUP;
+    __device__ static __forceinline__ int g(int lane) { return lane >> 3; }
+    __device__ static __forceinline__ int h(int lane) { return lane & 7; }
+    __device__ static __forceinline__ int wbase(int lane) { return (lane >> 3) * ROW + 2 * (lane & 7); }
+    __device__ static __forceinline__ int rbase(int lane) { return g(lane) * GROUP + h(lane) * ROW; }
+    __device__ static __forceinline__ float reduce(float x) {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));  // row_half_mirror
+        return x;
+    }
+};
 
 __device__ __forceinline__ int mask_rank(uint32_t lo, uint32_t hi) {          // set bits of (hi:lo) below this lane
     return (int)__builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
@@ -92,7 +124,7 @@ constexpr uint32_t NO_SLOT = 0xffffffffu;         // s_pslot of a constant (froz
 
 template <bool HAS_DEPTH, int GC, int SPW, bool PREFIX>
 __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
-    constexpr int XROW = XLayout<GC>::ROW, XGROUP = XLayout<GC>::GROUP;
+    typedef XLayout<GC> XL;
     __shared__ BatchLds s_b;
     __shared__ float4 s_pg[4 * 17];             // incoming gradient of each pixel (r, g, b, depth), 16 per pixel group;
                                                 // group stride 17: the two groups one ds_read_b128 quarter-wave sees
@@ -219,9 +251,9 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     // staged entries (compacted order) that are trainable; a chunk without any skips phase B
     const unsigned long long need = PREFIX ? __ballot(lane < cnt && s_pslot[lane] != NO_SLOT) : ~0ull;
 
-    const int g = lane % GC, h = lane / GC;                     // phase B role: splat g of the chunk, pixel group h
-    float2* const xw_row = reinterpret_cast<float2*>(s_x + (lane / GC) * XGROUP + 2 * (lane % GC));    // phase A: my column
-    const float4* const xr_row = reinterpret_cast<const float4*>(s_x + h * XGROUP + g * XROW);          // phase B: my row
+    const int g = XL::g(lane), h = XL::h(lane);                 // phase B role: splat g of the chunk, pixel group h
+    float2* const xw_row = reinterpret_cast<float2*>(s_x + XL::wbase(lane));                            // phase A: my column
+    const float4* const xr_row = reinterpret_cast<const float4*>(s_x + XL::rbase(lane));                // phase B: my row
 
     for (int c0 = 0; c0 < cnt; c0 += GC) {
         if (__all(live == 0.0f)) break;                         // (only after a 1e-7-probability stop flip, see header)
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             auto grad4 = [&](const Alpha4& e, const float4 (&col)[4], int k) {
                 float aeff[4], Tb[4], w[4];
                 blend_group4(T, live, e.alpha, aeff, Tb, w);
-                float2* x = xw_row + (k - c0) * (XROW / 2);
+                float2* x = xw_row + (k - c0) * (XL::WK / 2);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float4 c = col[u];
@@ -240,7 +272,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
                     R = fmaf(-cg, w[u], R);                                  // R_{i+1}
                     const float inv = __builtin_amdgcn_rcpf(1.0f - aeff[u]);
                     const float dLda = fmaf(Tb[u], cg, -(R * inv));
-                    x[u * (XROW / 2)] = make_float2(w[u] > 0.0f ? e.G[u] * dLda : 0.0f, w[u]);
+                    x[u * (XL::WK / 2)] = make_float2(w[u] > 0.0f ? e.G[u] * dLda : 0.0f, w[u]);
                 }
             };
             auto group4 = [&](const Ops4& ops, int k) {
@@ -290,15 +322,10 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             float mxy = fmaf(v0, mx, fmaf(-u0, Sy, Sxy));
             float myy = fmaf(v0, my - Sy, Sy);
             float dop = S0;
-#pragma unroll
-            for (int d = GC; d < 64; d <<= 1) {
-                mx += __shfl_xor(mx, d, 64); my += __shfl_xor(my, d, 64);
-                mxx += __shfl_xor(mxx, d, 64); mxy += __shfl_xor(mxy, d, 64); myy += __shfl_xor(myy, d, 64);
-                dop += __shfl_xor(dop, d, 64);
-                dr += __shfl_xor(dr, d, 64); dg += __shfl_xor(dg, d, 64);
-                db += __shfl_xor(db, d, 64);
-                if (HAS_DEPTH) dz += __shfl_xor(dz, d, 64);
-            }
+            mx = XL::reduce(mx); my = XL::reduce(my); mxx = XL::reduce(mxx); mxy = XL::reduce(mxy); myy = XL::reduce(myy);
+            dop = XL::reduce(dop);
+            dr = XL::reduce(dr); dg = XL::reduce(dg); db = XL::reduce(db);
+            if (HAS_DEPTH) dz = XL::reduce(dz);
             if (h == 0 && kk < cend) {
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
                 const uint32_t ps = s_pslot[kk];
@@ -330,7 +357,9 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
     static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();     // developer knobs
     static const int spw = [] { const char* e = getenv("EXA_BWD_SPW"); return e ? atoi(e) : 1; }();
     const Batch<RenderBwdArgs> b = make_batch(a, K);
-#define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S, false><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, 0, s>>>(b)
+    // EXA_BWD_LDS_PAD (bytes, developer knob): unused dynamic LDS per workgroup = fewer resident waves per SIMD (occupancy probe)
+    static const int pad = [] { const char* e = getenv("EXA_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();
+#define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S, false><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, (size_t)pad, s>>>(b)
     if (prefix) {
         if (depth) render_bwd_kernel<true, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(b);
         else render_bwd_kernel<false, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(b);
