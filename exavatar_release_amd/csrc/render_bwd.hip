@@ -354,7 +354,9 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
         prefix = prefix || a[k].grad_first > 0;
     }
     if (slots == 0) return hipSuccess;
-    static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 16; }();     // developer knobs
+    // chunk size: 8 (default: 8 KB of LDS per wave = 5 waves per SIMD, DPP reductions) or 16 (13 KB, 3 waves per SIMD);
+    // C3 on MI355X: 52.5 vs 54.7 us (HIP events, eager), occupancy probe EXA_BWD_LDS_PAD: 2.25 waves / SIMD = 60.6 us
+    static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 8; }();     // developer knobs
     static const int spw = [] { const char* e = getenv("EXA_BWD_SPW"); return e ? atoi(e) : 1; }();
     const Batch<RenderBwdArgs> b = make_batch(a, K);
     // EXA_BWD_LDS_PAD (bytes, developer knob): unused dynamic LDS per workgroup = fewer resident waves per SIMD (occupancy probe)

@@ -496,8 +496,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         unsigned long long blended = 0ull;
         // Blend one group of four splats whose alphas are known; returns true when every pixel of the sub-tile has stopped.
         auto blend4 = [&](const Alpha4& e, const float4& c0, const float4& c1, const float4& c2, const float4& c3, int k) -> bool {
+#ifndef EXA_FWD_NOSKIP     // (experiment: blend every group, no wave-wide vote on "does any pixel take any of the four")
             const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
             if (!__any(amax > 0.0f)) return false;
+#endif
             float aeff[4], Tb[4], w[4];
             blend_group4(T, live, e.alpha, aeff, Tb, w);
             if (STORE) {                                         // wave-uniform bits: v_cmp into an SGPR pair + scalar ops
@@ -514,7 +516,11 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             Cbd = __builtin_elementwise_fma(v2f{c2.z, c2.w}, v2f{w[2], w[2]}, Cbd);
             Crg = __builtin_elementwise_fma(v2f{c3.x, c3.y}, v2f{w[3], w[3]}, Crg);
             Cbd = __builtin_elementwise_fma(v2f{c3.z, c3.w}, v2f{w[3], w[3]}, Cbd);
+#ifdef EXA_FWD_EXIT8       // (experiment: look for "every pixel dead" once per eight splats instead of once per four)
+            return (k & 4) ? __all(live == 0.0f) : false;
+#else
             return __all(live == 0.0f);
+#endif
         };
         // two groups per trip with ping-pong operand registers: the operands of the next group are in flight during the
         // current one, and no register-to-register rotation is needed (a `cur = nxt` copy cost 12 v_mov_b64 per group)

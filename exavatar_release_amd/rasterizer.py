@@ -420,6 +420,9 @@ class _Job:
                  'gb', 'tb')
 
 
+_F32 = torch.float32
+
+
 def _fill_forward_job(a, j, report=None):
     a.settings = ctypes.pointer(j.settings)
     a.P, a.sh_M = j.P, j.sh_M
@@ -436,8 +439,17 @@ def _fill_forward_job(a, j, report=None):
         a.host_header, a.header_tag = None, 0
 
 
+def _grad_in(g, shape, device):
+    """Incoming image gradient as a contiguous float32 tensor of ``shape`` (the common case returns ``g`` itself)."""
+    if g is None:
+        return None
+    if g.dtype is _F32 and g.shape == shape and g.is_contiguous():
+        return g
+    g = g.to(dtype=_F32, device=device).expand(shape)
+    return g if g.is_contiguous() else g.contiguous()
+
+
 N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D
-_F32 = torch.float32
 
 
 class _Rasterize(torch.autograd.Function):
@@ -669,18 +681,13 @@ class _Rasterize(torch.autograd.Function):
                 means3D, sh, col, opac, scales, rot, cov, radii = saved[8 * k: 8 * k + 8]
                 g_color, g_depth, g_alpha = grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]
 
-                def grad_in(g, shape):
-                    if g is None:
-                        return None
-                    if g.dtype is _F32 and g.shape == shape and g.is_contiguous():
-                        return g
-                    g = g.to(dtype=_F32, device=device).expand(shape)
-                    return g if g.is_contiguous() else g.contiguous()
-                g_color = grad_in(g_color, (3, H, W))
+                g_color = _grad_in(g_color, (3, H, W), device)
                 if g_color is None:
                     g_color = torch.zeros((3, H, W), dtype=_F32, device=device)
-                g_depth = grad_in(g_depth, (1, H, W))
-                g_alpha = grad_in(g_alpha, (1, H, W))
+                if g_depth is not None:
+                    g_depth = _grad_in(g_depth, (1, H, W), device)
+                if g_alpha is not None:
+                    g_alpha = _grad_in(g_alpha, (1, H, W), device)
                 nd = need[N_IN * k: N_IN * (k + 1)]
                 own = (not ctx.shared) or k == 0          # shared: job 0's outputs receive the sum over the K views
                 # ONE arena for the small per-Gaussian gradients of this job (3 + 3 + 3 + 1 + 3 + 4 + 6 floats per row at

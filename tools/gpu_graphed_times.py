@@ -12,7 +12,7 @@ assets, shape, cam0 = scenes.make_config('c5'); H, W = shape
 P = assets['mean_3d'].shape[0]
 sh = scenes.sh_from_rgb(assets['rgb'], 3, seed=5, rest_sigma=0.1)
 a = {k: assets[k].to(dev) for k in ('mean_3d', 'scale', 'rotation', 'opacity')}; a['sh'] = sh.to(dev)
-cams = [{k: t.to(dev) for k, t in scenes.ring_camera(H, W, k, 200, focal=1500.0 * H / 1024).items()} for k in range(16)]
+cams = [{k: t.to(dev) for k, t in scenes.ring_camera(H, W, (k * 25) // 2, 200, focal=1500.0 * H / 1024).items()} for k in range(16)]   # 16 views spread over the ring, like bench.py's 200
 bg = torch.ones(3, device=dev)
 m2 = torch.zeros(P, 3, device=dev)
 
