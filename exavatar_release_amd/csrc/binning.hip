@@ -3,10 +3,8 @@
 //   digit 1 = 64x64-px cell     per-chunk histogram in preprocess_fwd.hip, stored as a row of the (chunk, cell)
 //                               count matrix; col_scan_kernel (column totals + per-chunk offsets),
 //                               cell_scan_kernel (prefix over cells), cell_scatter_kernel (entries -> buckets)
-//   digit 2 = 8x8-px sub-tile   the exact footprint of every (splat, cell) entry as a 64-bit sub-tile mask, computed by
-//                               cell_scatter_kernel where the record is in registers; subtile_bin_kernel: four
-//                               workgroups per cell, counts and ranks in LDS, emits (depth bits << 32 | id) keys
-//                               grouped by sub-tile -- ONE launch
+//   digit 2 = 8x8-px sub-tile   subtile_count_kernel + subtile_bin_kernel: four workgroups per cell, counts and
+//                               ranks in LDS, emits (depth bits << 32 | id) keys grouped by sub-tile
 //   digit 3 = depth (+ id)      sorted per sub-tile inside LDS by sort_subtiles_kernel (render_fwd.hip)
 // which reproduces the order of upstream's stable global sort on (tile << 32 | depth bits): ascending
 // depth, ties by ascending Gaussian id.  Counts travel between workgroups through plain-store matrices and
@@ -14,7 +12,7 @@
 //
 // Replaces upstream InclusiveSum + duplicateWithKeys + SortPairs(tile digit) + identifyTileRanges of the
 // rasterizer behind reference avatar/common/nets/module.py:632-640.
-// HBM traffic: reads the 64-byte record of every visible splat once, writes 16 B per cell entry and 8 B per
+// HBM traffic: reads 16 B of every visible splat record twice, writes 16 B per cell entry and 8 B per
 // instance, 4 B inst_off per Gaussian; scans are O(chunks x cells).
 #include <stdlib.h>
 #include "common.h"
@@ -256,41 +254,6 @@ __device__ __forceinline__ bool footprint_row(const Footprint& f, float yl, floa
     return true;
 }
 
-// The sub-tiles of a cell (origin csx0, csy0 in sub-tiles) that the footprint of a splat really reaches, as a 64-bit mask
-// (bit = y * 8 + x).  r0 / r1 = rows 0 / 1 of its Splat record (pixel centre; pre-scaled conic + opacity), rect_x / rect_y
-// its sub-tile rect (sx0 | sx1 << 16, sy0 | sy1 << 16).  FOOTPRINT = false: the whole rect.  Computed ONCE per (splat, cell)
-// entry by cell_scatter_kernel, where the record is in registers anyway, and stored in the entry: the sub-tile binning only
-// walks bits (it used to gather the record a second time in its own launch).
-template <bool FOOTPRINT>
-__device__ __forceinline__ unsigned long long entry_mask(const uint4& r0in, const uint4& r1in, uint32_t rect_x, uint32_t rect_y,
-                                                         int csx0, int csy0) {
-    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;              // (A = 0: no test, the whole rect)
-    if (FOOTPRINT) { r0 = r0in; r1 = r1in; }
-    const int x0 = max((int)(rect_x & 0xffff) - csx0, 0), x1 = min((int)(rect_x >> 16) - csx0, CELL_SUBS);
-    const int y0 = max((int)(rect_y & 0xffff) - csy0, 0), y1 = min((int)(rect_y >> 16) - csy0, CELL_SUBS);
-    const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
-    const Footprint fp = make_footprint(r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
-                                        fmaxf(fabsf(yl0), fabsf(yl0 + (float)((y1 - y0) * SUB))));
-    unsigned long long mask = 0ull;
-    for (int y = y0; y < y1; ++y) {
-        int c0 = x0, c1 = x1 - 1;
-        if (fp.test) {
-            float xa, xb;
-            if (!footprint_row(fp, yl0 + (float)((y - y0) * SUB), xa, xb)) continue;
-            if (xa <= xb) {                                     // (NaN: keep the row)
-                const float m = 1e-3f * (1.0f + fmaxf(fabsf(xa), fabsf(xb)));
-                const float lo = clampf((xa - m - (float)(SUB - 1) - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
-                const float hi = clampf((xb + m - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
-                c0 = max(x0, x0 + (int)ceilf(lo));
-                c1 = min(x1 - 1, x0 + (int)floorf(hi));
-            }
-        }
-        if (c1 < c0) continue;
-        mask |= (unsigned long long)((2u << c1) - (1u << c0)) << (y * CELL_SUBS);
-    }
-    return mask;
-}
-
 // CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
 // into the splat record, (b) 16-byte entries scattered into their cells' buckets: the chunk's first slot in
 // every cell comes from the scanned count matrix, ranks inside it from LDS atomics, (c) clears this
@@ -304,7 +267,6 @@ __device__ __forceinline__ void report_header(uint32_t* host_hdr, uint32_t need,
     const v4u v = {need, overflow, vis, tag};
     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(host_hdr), "v"(v) : "memory");
 }
-template <bool FOOTPRINT>
 __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> batch) {
     // base[cells] | cnt2[cells] (u32)  [ | tot[cells] | bef[cells] (u64) when the scans are merged into this kernel ]
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
@@ -422,19 +384,18 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     __syncthreads();
 
     constexpr int PER = CHUNK / SC_BLOCK;
-    uint4 r3[PER], r0[PER], r1[PER];
+    uint4 r3[PER];
     int ids[PER];
+    uint32_t depth_bits[PER];
     uint32_t mine = 0;
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
         ids[it] = blockIdx.x * CHUNK + it * SC_BLOCK + tid;
         r3[it] = make_uint4(0, 0, 0, 0);
-        r0[it] = r3[it]; r1[it] = r3[it];
+        depth_bits[it] = 0;
         if (ids[it] < P) {
-            const uint4* rec = reinterpret_cast<const uint4*>(splats + ids[it]);     // one 64-byte line
-            r3[it] = rec[3];
-            r0[it] = rec[0];
-            if (FOOTPRINT) r1[it] = rec[1];
+            r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
+            depth_bits[it] = reinterpret_cast<const uint4*>(splats + ids[it])[0].z;
         }
         mine += r3[it].z;
     }
@@ -451,11 +412,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                     const int c = cy * g.cx + cx;
                     const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[c], 1u, __ATOMIC_RELAXED,
                                                               __HIP_MEMORY_SCOPE_WORKGROUP);
-                    // the sub-tiles of this cell the footprint reaches (the conic is in registers here: no second gather
-                    // of the record in the sub-tile binning, and no launch of its own for the footprint test)
-                    const unsigned long long mask = entry_mask<FOOTPRINT>(r0[it], r1[it], r3[it].x, r3[it].y,
-                                                                          cx * CELL_SUBS, cy * CELL_SUBS);
-                    b.bucket[s_base[c] + r] = make_uint4((uint32_t)ids[it], r0[it].z, (uint32_t)mask, (uint32_t)(mask >> 32));
+                    b.bucket[s_base[c] + r] = make_uint4((uint32_t)ids[it], depth_bits[it], r3[it].x, r3[it].y);
                 }
         }
     }
@@ -468,9 +425,15 @@ constexpr int BIN_THREADS = 1024;
 constexpr int SINGLE_PART_CELLS = 1024;   // from this many cells on (2048 x 2048 px) one workgroup per cell
 // An avatar's instances sit in a few dozen cells, and both halves of this digit -- LDS counting atomics and the
 // scattered 8-byte key stores, one per instance -- are throughput limits of ONE CU.  Every cell is therefore
-// handled by BIN_PARTS workgroups of ONE launch (subtile_bin_kernel): each part counts ALL the cell's mask bits per
-// (part, sub-tile) on its own (totals -> 64-aligned ranges; earlier parts -> its own first slot in every sub-tile) and
-// scatters its quarter of the keys.  No cross-workgroup hand-off at all; part 0 publishes ranges and owners.
+// handled by BIN_PARTS workgroups in two launches:
+//   subtile_count_kernel  part p counts its quarter of the cell's entries per sub-tile -> part_cnt[cell][p][64]
+//   subtile_bin_kernel    reads the cell's BIN_PARTS x 64 counts (totals -> 64-aligned ranges; earlier parts ->
+//                         its own first slot in every sub-tile) and scatters its quarter of the keys.
+// Plain stores and a kernel boundary instead of any cross-workgroup atomics; part 0 publishes ranges and owners.
+// (Round 3 tried ONE launch: footprint masks computed by cell_scatter_kernel -- the record is in registers there -- and
+//  every part counting the whole cell itself.  Bitwise the same lists, but slower: the mask work is Gaussian-major there,
+//  one thread walks ALL cells of its splat -- C3 cell_scatter 18.4 -> 22.8 us for 19.7 -> 16.8 us here, C5 (scene splats
+//  over hundreds of cells) 20.7 -> 76 us.  Entry-parallel masks in their own launch stay.)
 struct CellPart { int cell, part; uint32_t e0, e1, lo, hi, slot0; bool overflow, active; };
 template <int PARTS>
 __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * PARTS
@@ -491,14 +454,64 @@ __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity
     return c;
 }
 
-// Count + scatter in ONE launch, BIN_PARTS workgroups per cell and no cross-workgroup hand-off: every part counts the mask
-// bits of ALL the cell's entries per (part, sub-tile) -- 8 bytes per entry from L2, a handful of LDS atomics -- so it knows
-// the totals (-> the 64-aligned ranges of all 64 sub-tiles) and how many entries the EARLIER parts will put into each
-// sub-tile (-> its own first slot), then scatters the keys of its own quarter of the entries.  (Until round 3 the counts
-// travelled through a part_cnt matrix and a kernel boundary: subtile_count_kernel, 9.8 us on C3.)
+// The sub-tiles of its cell (origin csx0, csy0 in sub-tiles) that the footprint of entry `en` = {id, depth, rect x, rect y}
+// really reaches, as a 64-bit mask (bit = y * 8 + x).  It replaces the rect in the entry; the scatter walks the same bits.
+template <bool FOOTPRINT>
+__device__ __forceinline__ unsigned long long entry_mask(const Splat* __restrict__ splats, const uint4& en, int csx0, int csy0) {
+    const uint4* rec = reinterpret_cast<const uint4*>(splats + en.x);
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;              // (A = 0: no test, the whole rect)
+    if (FOOTPRINT) { r0 = rec[0]; r1 = rec[1]; }
+    const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
+    const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
+    const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
+    const Footprint fp = make_footprint(r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
+                                        fmaxf(fabsf(yl0), fabsf(yl0 + (float)((y1 - y0) * SUB))));
+    unsigned long long mask = 0ull;
+    for (int y = y0; y < y1; ++y) {
+        int c0 = x0, c1 = x1 - 1;
+        if (fp.test) {
+            float xa, xb;
+            if (!footprint_row(fp, yl0 + (float)((y - y0) * SUB), xa, xb)) continue;
+            if (xa <= xb) {                                     // (NaN: keep the row)
+                const float m = 1e-3f * (1.0f + fmaxf(fabsf(xa), fabsf(xb)));
+                const float lo = clampf((xa - m - (float)(SUB - 1) - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
+                const float hi = clampf((xb + m - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);
+                c0 = max(x0, x0 + (int)ceilf(lo));
+                c1 = min(x1 - 1, x0 + (int)floorf(hi));
+            }
+        }
+        if (c1 < c0) continue;
+        mask |= (unsigned long long)((2u << c1) - (1u << c0)) << (y * CELL_SUBS);
+    }
+    return mask;
+}
+
+template <bool FOOTPRINT, int PARTS>
+__global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArgs> batch) {
+    __shared__ uint32_t s_cnt[SUBS_PER_CELL];
+    const BinArgs& a = batch.v[blockIdx.y];
+    const TileWs& w = a.tw;
+    const Grid& g = a.grid;
+    const BinWs& b = a.bw;
+    if ((int)blockIdx.x >= g.cells * PARTS) return;
+    const CellPart cp = cell_part<PARTS>(w, a.capacity);
+    if (!cp.active) return;                                             // empty cell: nothing to count
+    const int tid = threadIdx.x;
+    if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
+    __syncthreads();
+    const int csx0 = (cp.cell % g.cx) * CELL_SUBS, csy0 = (cp.cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        for (unsigned long long m = mask; m; m &= m - 1)
+            __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
+    }
+    __syncthreads();
+    if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
+}
+
 template <int PARTS>
 __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs> batch) {
-    __shared__ uint32_t s_cnt[PARTS][SUBS_PER_CELL];
     __shared__ uint32_t s_off[SUBS_PER_CELL];
     __shared__ uint32_t s_cnt2[SUBS_PER_CELL];
     const BinArgs& a = batch.v[blockIdx.y];
@@ -513,26 +526,11 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         return;
     }
     const int cell = cp.cell, tid = threadIdx.x;
-    if (tid < PARTS * SUBS_PER_CELL) (&s_cnt[0][0])[tid] = 0u;
-    __syncthreads();
-    {   // count pass over the whole cell, part by part (the parts' entry ranges as cell_part() deals them)
-        const uint32_t per = (cp.e1 - cp.e0 + PARTS - 1) / PARTS;
-#pragma unroll
-        for (int p = 0; p < PARTS; ++p) {
-            const uint32_t lo = min(cp.e1, cp.e0 + (uint32_t)p * per), hi = min(cp.e1, lo + per);
-            for (uint32_t e = lo + tid; e < hi; e += BIN_THREADS) {
-                const uint2 mk = reinterpret_cast<const uint2*>(b.bucket + e)[1];
-                for (unsigned long long m = ((unsigned long long)mk.y << 32) | mk.x; m; m &= m - 1)
-                    __hip_atomic_fetch_add(&s_cnt[p][__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-    }
-    __syncthreads();
     if (tid < 64) {
         uint32_t n = 0, before = 0;
 #pragma unroll
         for (int p = 0; p < PARTS; ++p) {
-            const uint32_t v = s_cnt[p][tid];
+            const uint32_t v = w.part_cnt[((size_t)cell * PARTS + p) * SUBS_PER_CELL + tid];
             before += p < cp.part ? v : 0u;
             n += v;
         }
@@ -563,6 +561,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
 
 // One workgroup per cell, both halves in one launch: for images with >= SINGLE_PART_CELLS cells (2048 x 2048 px) there are
 // enough cells to fill the chip without splitting them, and the split only multiplies the fixed costs.
+template <bool FOOTPRINT>
 __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<BinArgs> batch) {
     __shared__ uint32_t s_cnt[SUBS_PER_CELL], s_off[SUBS_PER_CELL], s_cnt2[SUBS_PER_CELL];
     const BinArgs& a = batch.v[blockIdx.y];
@@ -579,10 +578,12 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
     }
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
+    const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
-        const uint2 mk = reinterpret_cast<const uint2*>(b.bucket + e)[1];      // footprint mask, written by cell_scatter_kernel
-        for (unsigned long long m = ((unsigned long long)mk.y << 32) | mk.x; m; m &= m - 1)
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        for (unsigned long long m = mask; m; m &= m - 1)
             __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));   // read back by this thread
     }
     __syncthreads();
     if (tid < 64) {
@@ -634,9 +635,7 @@ hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s) {
         chunks = max(chunks, a[k].chunks);
         cells = max(cells, a[k].grid.cells);
     }
-    static const bool footprint = [] { const char* e = getenv("EXA_FOOTPRINT"); return !e || atoi(e) != 0; }();   // developer knob
-    if (footprint) cell_scatter_kernel<true><<<dim3(chunks, K), SC_BLOCK, (size_t)cells * (a[0].merged ? 24 : 8), s>>>(b);
-    else cell_scatter_kernel<false><<<dim3(chunks, K), SC_BLOCK, (size_t)cells * (a[0].merged ? 24 : 8), s>>>(b);
+    cell_scatter_kernel<<<dim3(chunks, K), SC_BLOCK, (size_t)cells * (a[0].merged ? 24 : 8), s>>>(b);
     return hipGetLastError();
 }
 
@@ -645,12 +644,19 @@ hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
     int cells = 0;
     for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
     if (cells == 0) return hipSuccess;
+    static const bool footprint = [] { const char* e = getenv("EXA_FOOTPRINT"); return !e || atoi(e) != 0; }();   // developer knob
     // Workgroups per cell: an avatar view fills a few dozen of its 256 cells, so every cell is split over BIN_PARTS
-    // workgroups to get the chip busy; a large image (C5: 1024 cells, content everywhere) has enough cells already and
-    // takes one workgroup per cell.  Either way counting and scattering are ONE launch.
+    // workgroups (two launches) to get the chip busy; a large image (C5: 1024 cells, content everywhere) has enough
+    // cells already and takes one workgroup per cell that counts and scatters in ONE launch.
     static const int single_cells = [] { const char* e = getenv("EXA_BIN_SINGLE_CELLS"); return e ? atoi(e) : SINGLE_PART_CELLS; }();
-    if (cells >= single_cells) subtile_count_bin_kernel<<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
-    else subtile_bin_kernel<BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    if (cells >= single_cells) {
+        if (footprint) subtile_count_bin_kernel<true><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
+        else subtile_count_bin_kernel<false><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
+    } else {
+        if (footprint) subtile_count_kernel<true, BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+        else subtile_count_kernel<false, BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+        subtile_bin_kernel<BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+    }
     return hipGetLastError();
 }
 

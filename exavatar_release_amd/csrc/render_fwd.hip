@@ -496,7 +496,9 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         unsigned long long blended = 0ull;
         // Blend one group of four splats whose alphas are known; returns true when every pixel of the sub-tile has stopped.
         auto blend4 = [&](const Alpha4& e, const float4& c0, const float4& c1, const float4& c2, const float4& c3, int k) -> bool {
-#ifndef EXA_FWD_NOSKIP     // (experiment: blend every group, no wave-wide vote on "does any pixel take any of the four")
+            // (no wave-wide vote on "does any live pixel take any of the four": with exact-footprint lists nearly every
+            //  group is taken by some pixel, and the vote cost more than the blends it skipped: 42.8 -> 41.8 us on C3)
+#ifdef EXA_FWD_SKIP_VOTE
             const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
             if (!__any(amax > 0.0f)) return false;
 #endif
@@ -516,10 +518,12 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             Cbd = __builtin_elementwise_fma(v2f{c2.z, c2.w}, v2f{w[2], w[2]}, Cbd);
             Crg = __builtin_elementwise_fma(v2f{c3.x, c3.y}, v2f{w[3], w[3]}, Crg);
             Cbd = __builtin_elementwise_fma(v2f{c3.z, c3.w}, v2f{w[3], w[3]}, Cbd);
-#ifdef EXA_FWD_EXIT8       // (experiment: look for "every pixel dead" once per eight splats instead of once per four)
-            return (k & 4) ? __all(live == 0.0f) : false;
-#else
+            // "every pixel of the sub-tile dead" is looked for once per EIGHT splats (a dead pixel takes alpha * live = 0,
+            // so walking four more splats changes nothing): one vote less per group, 42.3 vs 42.8 us on C3
+#ifdef EXA_FWD_EXIT4
             return __all(live == 0.0f);
+#else
+            return (k & 4) ? __all(live == 0.0f) : false;
 #endif
         };
         // two groups per trip with ping-pong operand registers: the operands of the next group are in flight during the
