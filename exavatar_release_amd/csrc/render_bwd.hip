@@ -363,8 +363,13 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
     static const int pad = [] { const char* e = getenv("EXA_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();
 #define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S, false><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, (size_t)pad, s>>>(b)
     if (prefix) {
-        if (depth) render_bwd_kernel<true, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(b);
-        else render_bwd_kernel<false, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, 0, s>>>(b);
+        if (gc == 8) {
+            if (depth) render_bwd_kernel<true, 8, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
+            else render_bwd_kernel<false, 8, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
+        } else {
+            if (depth) render_bwd_kernel<true, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
+            else render_bwd_kernel<false, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
+        }
     } else if (gc == 8) {
         if (depth) EXA_LAUNCH_BWD(true, 8, 1); else EXA_LAUNCH_BWD(false, 8, 1);
     } else if (spw == 2) {
