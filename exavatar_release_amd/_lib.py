@@ -57,6 +57,20 @@ class ExaRasterForwardJob(ctypes.Structure):
         ('geom_ws', c_void_p), ('tile_ws', c_void_p),
         ('bin_ws', c_void_p), ('capacity', ctypes.c_uint64),
         ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
+        ('keep_sorted_keys', ctypes.c_int32),
+        ('host_header', c_void_p), ('header_tag', ctypes.c_uint32),
+    ]
+
+
+class ExaRasterComposeJob(ctypes.Structure):
+    """One composite render of two finished renders of the same camera (include/exa_raster.h)."""
+    _fields_ = [
+        ('settings', ctypes.POINTER(ExaRasterSettings)),
+        ('P_a', ctypes.c_int32), ('P_b', ctypes.c_int32),
+        ('geom_a', c_void_p), ('tile_a', c_void_p), ('bin_a', c_void_p), ('capacity_a', ctypes.c_uint64),
+        ('geom_b', c_void_p), ('tile_b', c_void_p), ('bin_b', c_void_p), ('capacity_b', ctypes.c_uint64),
+        ('tile_ws', c_void_p), ('bin_ws', c_void_p), ('capacity', ctypes.c_uint64),
+        ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
         ('host_header', c_void_p), ('header_tag', ctypes.c_uint32),
     ]
 
@@ -76,6 +90,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
         ('dL_dscales', c_void_p), ('dL_drotations', c_void_p), ('dL_dsh', c_void_p), ('dL_dcov3D', c_void_p),
         ('densify_grad_accum', c_void_p), ('densify_track_cnt', c_void_p), ('densify_radius_max', c_void_p),
         ('grad_first', ctypes.c_int32),
+        ('compose_geom_a', c_void_p), ('compose_P_a', ctypes.c_int32), ('compose_capacity_b', ctypes.c_uint64),
     ]
 
 
@@ -101,6 +116,8 @@ SIGNATURES = {
     'exa_raster_forward_render_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
     'exa_raster_forward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterForwardJob), _I32, _I32, c_void_p]),
     'exa_raster_backward_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterBackwardJob), _I32, _I32, c_void_p]),
+    'exa_raster_compose_sizes': (ctypes.c_int, [_I32, _I32, _U64, _U64, ctypes.POINTER(ExaRasterWorkspaceSizes)]),
+    'exa_raster_forward_compose_batch': (ctypes.c_int, [ctypes.POINTER(ExaRasterComposeJob), _I32, _I32, c_void_p]),
     'exa_raster_read_header_async': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     'exa_raster_read_header_full_async': (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     'exa_raster_host_device_pointer': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
@@ -143,7 +160,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 130:
+    if lib.exa_raster_version() < 131:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

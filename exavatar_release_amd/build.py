@@ -25,6 +25,7 @@ SOURCES = {
     'binning.hip': [],
     'render_fwd.hip': [],
     'render_bwd.hip': [],
+    'compose.hip': [],
     'preprocess_bwd.hip': [],
     'ssim.hip': [],
     'api.hip': [],

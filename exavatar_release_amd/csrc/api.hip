@@ -194,6 +194,7 @@ int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, 
         r.grid = ba[k].grid; r.splats = ba[k].splats; r.tw = ba[k].tw; r.bw = ba[k].bw; r.capacity = j.capacity;
         r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
         r.store_ctx = store_ctx;
+        r.keep_sorted_keys = j.keep_sorted_keys; r.splats2 = nullptr;
     }
     int rc;
     // (cell_scatter_kernel also clears the zero-filled section of the bin workspace: batch owners, blended masks, touched bytes)
@@ -220,6 +221,8 @@ int check_backward_job(const ExaRasterBackwardJob& j) {
     if (j.capacity % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
     if (!j.dL_dcolor) return fail(EXA_RASTER_E_NULLPTR, "dL_dcolor is NULL");
     if (j.grad_first < 0 || j.grad_first > j.P) return fail(EXA_RASTER_E_INVALID, "grad_first must be in 0..P");
+    if (j.compose_geom_a && (j.grad_first != 0 || j.compose_P_a <= 0 || j.compose_capacity_b % BATCH))
+        return fail(EXA_RASTER_E_INVALID, "composite backward: grad_first must be 0, compose_P_a > 0, compose_capacity_b a multiple of 64");
     return 0;
 }
 
@@ -235,11 +238,19 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         const Grid g = make_grid(s->image_width, s->image_height);
         RenderBwdArgs& r = ra[n];
         r.grid = g; r.capacity = j.capacity; r.P = j.P; r.splats = static_cast<const Splat*>(j.geom_ws);
+        r.splats2 = nullptr; r.P2 = 0;
         r.tw = carve_tile_ws(const_cast<void*>(j.tile_ws), g.cells, num_chunks(j.P));
         r.bw = carve_bin_ws(const_cast<void*>(j.bin_ws), j.capacity);
         r.bg = s->bg; r.dL_dcolor = j.dL_dcolor; r.dL_ddepth = j.dL_ddepth; r.dL_dalpha = j.dL_dalpha;
         r.partials = carve_grad_ws(j.grad_ws, j.capacity);
         r.grad_first = j.grad_first;
+        if (j.compose_geom_a) {                 // composite: ids of two record arrays, A constant, B (= this job's tensors) trainable
+            r.splats = static_cast<const Splat*>(j.compose_geom_a); r.P = j.compose_P_a;
+            r.splats2 = static_cast<const Splat*>(j.geom_ws); r.P2 = j.P;
+            r.tw = carve_tile_ws(const_cast<void*>(j.tile_ws), g.cells, 0);
+            r.bw = carve_compose_ws(const_cast<void*>(j.bin_ws), j.capacity, j.compose_capacity_b);
+            r.grad_first = 1;                   // selects the prefix-aware instantiation; the kernel decides on the source bit
+        }
         PreprocessBwdArgs& b = pa[n];
         b.P = j.P; b.sh_M = j.sh_M; b.sh_degree = s->sh_degree; b.grid = g;
         b.tanfovx = s->tanfovx; b.tanfovy = s->tanfovy;
@@ -248,13 +259,13 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         b.scale_modifier = s->scale_modifier;
         b.viewmatrix = s->viewmatrix; b.projmatrix = s->projmatrix; b.campos = s->campos;
         b.means3D = j.means3D; b.shs = j.shs; b.opacities = j.opacities; b.scales = j.scales; b.rotations = j.rotations;
-        b.cov3D_precomp = j.cov3D_precomp; b.radii = j.radii; b.splats = r.splats;
+        b.cov3D_precomp = j.cov3D_precomp; b.radii = j.radii; b.splats = static_cast<const Splat*>(j.geom_ws);   // (composite: B's records)
         b.partials = r.partials; b.touched = r.bw.touched; b.header = r.tw.header;
         b.dL_dmeans2D = j.dL_dmeans2D; b.dL_dmeans3D = j.dL_dmeans3D; b.dL_dcolors = j.dL_dcolors;
         b.dL_dopacity = j.dL_dopacity; b.dL_dscales = j.dL_dscales; b.dL_drotations = j.dL_drotations;
         b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;
         b.dens_accum = j.densify_grad_accum; b.dens_cnt = j.densify_track_cnt; b.dens_rmax = j.densify_radius_max;
-        b.grad_first = j.grad_first;
+        b.grad_first = j.grad_first;            // (composite: 0 -- every Gaussian of B is trainable; partials / touched / header are the composite's)
         ++n;
     }
     if (n == 0) return 0;
@@ -324,6 +335,7 @@ int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32
         if (sum_shared) {
             const ExaRasterBackwardJob &a = jobs[0], &b = jobs[k];
             if (b.grad_first != 0) return fail(EXA_RASTER_E_INVALID, "sum_shared and grad_first cannot be combined");
+            if (b.compose_geom_a) return fail(EXA_RASTER_E_INVALID, "sum_shared and composite jobs cannot be combined");
             if (a.P != b.P || a.sh_M != b.sh_M || a.means3D != b.means3D || a.shs != b.shs || a.opacities != b.opacities ||
                 a.colors_precomp != b.colors_precomp || a.scales != b.scales || a.rotations != b.rotations ||
                 a.cov3D_precomp != b.cov3D_precomp || a.settings->sh_degree != b.settings->sh_degree ||
@@ -378,7 +390,7 @@ static ExaRasterForwardJob one_job(const ExaRasterSettings* s, int32_t P, int32_
     j.opacities = opacities; j.scales = scales; j.rotations = rotations; j.cov3D_precomp = cov3D_precomp;
     j.radii = radii; j.geom_ws = geom_ws; j.tile_ws = tile_ws; j.bin_ws = bin_ws; j.capacity = capacity;
     j.out_color = out_color; j.out_depth = out_depth; j.out_alpha = out_alpha;
-    j.host_header = nullptr; j.header_tag = 0u;
+    j.host_header = nullptr; j.header_tag = 0u; j.keep_sorted_keys = 0;
     return j;
 }
 
@@ -427,7 +439,65 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
     j.dL_dscales = dL_dscales; j.dL_drotations = dL_drotations; j.dL_dsh = dL_dsh; j.dL_dcov3D = dL_dcov3D;
     j.densify_grad_accum = nullptr; j.densify_track_cnt = nullptr; j.densify_radius_max = nullptr;
     j.grad_first = 0;
+    j.compose_geom_a = nullptr; j.compose_P_a = 0; j.compose_capacity_b = 0;
     return exa_raster_backward_batch(&j, 1, 0, stream);
+}
+
+int exa_raster_compose_sizes(int32_t W, int32_t H, uint64_t capacity, uint64_t capacity_b, ExaRasterWorkspaceSizes* out) {
+    if (!out) return fail(EXA_RASTER_E_NULLPTR, "out is NULL");
+    if (W < 0 || H < 0) return fail(EXA_RASTER_E_INVALID, "negative size");
+    if (capacity % BATCH || capacity_b % BATCH) return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
+    out->geom_bytes = 0;
+    out->tile_bytes = tile_ws_bytes(make_grid(W, H).cells, 0);
+    out->bin_bytes = compose_bin_bytes(capacity, capacity_b);
+    out->grad_bytes = grad_ws_bytes(capacity_b);
+    return 0;
+}
+
+int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K, int32_t store_ctx, void* stream) {
+    if (K < 0 || (K > 0 && !jobs)) return fail(EXA_RASTER_E_INVALID, "bad job list");
+    for (int k = 0; k < K; ++k) {
+        const ExaRasterComposeJob& j = jobs[k];
+        const int rc = check_settings(j.settings);
+        if (rc) return rc;
+        if (j.P_a <= 0 || j.P_b <= 0) return fail(EXA_RASTER_E_INVALID, "composite: both sources need Gaussians");
+        if (!j.geom_a || !j.tile_a || !j.bin_a || !j.geom_b || !j.tile_b || !j.bin_b || !j.tile_ws || !j.bin_ws)
+            return fail(EXA_RASTER_E_WORKSPACE, "composite: workspace is NULL");
+        if (j.capacity % BATCH || j.capacity_a % BATCH || j.capacity_b % BATCH)
+            return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
+        if (!j.out_color || !j.out_depth || !j.out_alpha) return fail(EXA_RASTER_E_NULLPTR, "output image is NULL");
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
+        const int n = K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH;
+        ComposeArgs ca[MAX_BATCH];
+        RenderFwdArgs ra[MAX_BATCH];
+        for (int k = 0; k < n; ++k) {
+            const ExaRasterComposeJob& j = jobs[k0 + k];
+            const Grid g = make_grid(j.settings->image_width, j.settings->image_height);
+            ComposeArgs& c = ca[k];
+            c.grid = g;
+            c.tw_a = carve_tile_ws(const_cast<void*>(j.tile_a), g.cells, num_chunks(j.P_a));
+            c.tw_b = carve_tile_ws(const_cast<void*>(j.tile_b), g.cells, num_chunks(j.P_b));
+            c.bw_a = carve_bin_ws(const_cast<void*>(j.bin_a), j.capacity_a);
+            c.bw_b = carve_bin_ws(const_cast<void*>(j.bin_b), j.capacity_b);
+            c.tw = carve_tile_ws(j.tile_ws, g.cells, 0);
+            c.bw = carve_compose_ws(j.bin_ws, j.capacity, j.capacity_b);
+            c.capacity = j.capacity; c.capacity_b = j.capacity_b;
+            c.host_hdr = static_cast<uint32_t*>(j.host_header); c.hdr_tag = j.header_tag;
+            RenderFwdArgs& r = ra[k];
+            r.grid = g; r.splats = static_cast<const Splat*>(j.geom_a); r.splats2 = static_cast<const Splat*>(j.geom_b);
+            r.tw = c.tw; r.bw = c.bw; r.capacity = j.capacity;
+            r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
+            r.store_ctx = store_ctx; r.keep_sorted_keys = 0;
+        }
+        int rc;
+        EXA_TIMED(K_CELL_SCATTER, launch_compose(ca, n, st), "compose");
+        if ((rc = debug_sync(jobs[k0].settings, st, "compose"))) return rc;
+        EXA_TIMED(K_RENDER_FWD, launch_render_fwd(ra, n, st), "render_fwd (composite)");
+        if ((rc = debug_sync(jobs[k0].settings, st, "render_fwd (composite)"))) return rc;
+    }
+    return 0;
 }
 
 int exa_raster_read_header_async(const void* tile_ws, void* host_dst16, void* stream) {

@@ -271,12 +271,44 @@ hipError_t launch_cell_scan(const BinArgs* a, int K, hipStream_t s);
 hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s);
 hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s);
 
+// Composite renders (compose.hip): the sorted list of a sub-tile is the MERGE of the sorted lists of two finished renders
+// A and B of the same camera; an id carries its source in bit 31 (set = B).  `splats2` != nullptr selects that decoding.
+constexpr uint32_t SRC_B = 0x80000000u;
 struct RenderFwdArgs {
     Grid grid;
     const Splat* splats; TileWs tw; BinWs bw; uint64_t capacity;
     const float* bg; float* out_color; float* out_depth; float* out_alpha; int store_ctx;
+    int keep_sorted_keys;      // sort_subtiles: also write the sorted 64-bit keys back over bw.keys (merge source)
+    const Splat* splats2;      // composite: records of source B (ids with SRC_B); `splats` = source A
 };
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s);
+// Composite of two finished renders (compose.hip): ranges / header / launch order / zero-fill, then the merged id lists
+struct ComposeArgs {
+    Grid grid;
+    TileWs tw_a, tw_b; BinWs bw_a, bw_b;       // sources (sorted keys in bw.keys: forward with keep_sorted_keys)
+    TileWs tw; BinWs bw; uint64_t capacity, capacity_b;   // the composite's own: bw.touched holds capacity_b bytes
+    uint32_t* host_hdr; uint32_t hdr_tag;
+};
+hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s);
+// bin workspace of a composite: merged ids [cap] | zero-filled: owner [cap / 64 + 1], blended mask [cap / 64 + 1], touched
+// [capacity_b] (B's Gaussian-major instance numbering) | checkpoints [cap / 64 + 1][5][64]
+__host__ __device__ inline uint64_t compose_zero_bytes(uint64_t cap, uint64_t cap_b) {
+    return align256((cap / BATCH + 1) * 16) + align256((cap / BATCH + 1) * 8) + align256(cap_b);
+}
+__host__ __device__ inline uint64_t compose_bin_bytes(uint64_t cap, uint64_t cap_b) {
+    return align256(cap * 4) + compose_zero_bytes(cap, cap_b) + align256((cap / BATCH + 1) * 5 * 64 * 4);
+}
+__host__ __device__ inline BinWs carve_compose_ws(void* base, uint64_t cap, uint64_t cap_b) {
+    BinWs b;
+    char* p = static_cast<char*>(base);
+    b.keys = nullptr; b.bucket = nullptr;
+    b.sorted = reinterpret_cast<uint32_t*>(p); p += align256(cap * 4);
+    b.owner = reinterpret_cast<uint4*>(p); p += align256((cap / BATCH + 1) * 16);
+    b.bmask = reinterpret_cast<unsigned long long*>(p); p += align256((cap / BATCH + 1) * 8);
+    b.touched = reinterpret_cast<uint8_t*>(p); p += align256(cap_b);
+    b.ckpt = reinterpret_cast<float*>(p);
+    return b;
+}
 hipError_t launch_render_fwd(const RenderFwdArgs* a, int K, hipStream_t s);
 
 struct RenderBwdArgs {
@@ -285,6 +317,8 @@ struct RenderBwdArgs {
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
     PartialWs partials;
     int grad_first;        // Gaussians below this index are constants (ExaRasterBackwardJob.grad_first)
+    const Splat* splats2;  // composite (PREFIX instantiation): records of source B = the trainable Gaussians (ids with SRC_B),
+    int P2;                // `splats` / `P` = source A = constants; partial slots in B's Gaussian-major numbering
 };
 hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s);
 

@@ -1,0 +1,189 @@
+// Composite renders for gfx950: the per-sub-tile list of "A and B rendered together" as the MERGE of the sorted lists of two
+// renders A and B that already exist -- no preprocess, no cell scatter, no sub-tile binning, no sort for the composite.
+//
+// Why: ExAvatar renders five images per training sample with ONE camera (reference avatar/main/model.py:119-167):
+//     scene, human, cat(scene.detach(), human), human_refined, cat(scene.detach(), human_refined)
+// ("shared preprocess / sort for the 5 renders ... biggest real-world lever on ExAvatar iters/s").  The two
+// composites contain exactly the Gaussians of two renders of the same batch, seen by the same camera: their splat records
+// are the sources' records, and the depth-sorted list of a sub-tile is the merge of the sources' two sorted lists (order of
+// the concatenated render: ascending depth bits, ties by index -- every A (scene) index precedes every B (human) index, so A
+// wins ties).  Two small launches replace five:
+//   compose_kernel   block 0: list lengths nA + nB -> 64-aligned ranges of the composite's own instance space, header;
+//                    blocks 1..16: length-sorted launch order of the blend (per-class bases from a second histogram over the
+//                    sub-tiles in front of the block's share: no atomics, nothing to zero); remaining blocks: zero-fill of the
+//                    composite's owner / blended-mask / touched arrays
+//   merge_kernel     one wave per sub-tile: 64 candidates of each source per trip (sorted 64-bit keys, kept by the sources'
+//                    sort: RenderFwdArgs.keep_sorted_keys), each candidate's output position = its own index + its rank in
+//                    the other window (binary search in LDS: lower bound for A, upper bound for B), ids written with the
+//                    source in bit 31 (SRC_B), batch owners written alongside
+// then render_fwd_kernel<STORE, TWO = true> / render_bwd_kernel<.., PREFIX = true> (two record arrays) and the unchanged
+// preprocess_bwd_kernel on B's records with the composite's partial sums: A is a constant of the backward pass (the detached
+// scene), like ExaRasterBackwardJob.grad_first.  Images are bit-identical to rendering the concatenation.
+#include "common.h"
+
+namespace exa {
+
+constexpr int CBLOCK = 256;
+constexpr int C_ORDER_WGS = 16;
+constexpr int C_ZERO_WGS = 48;
+
+__device__ __forceinline__ uint32_t list_slots(uint32_t n) { return n ? (n + BATCH - 1) / BATCH + 1 : 0u; }   // batches + end slot
+
+__global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batch) {
+    __shared__ uint32_t s_wave[CBLOCK / 64];
+    __shared__ uint32_t s_all[ORDER_CLASSES], s_before[ORDER_CLASSES], s_off[ORDER_CLASSES], s_rank[ORDER_CLASSES];
+    const ComposeArgs& a = batch.v[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int subtiles = a.grid.subtiles;
+    const uint2* __restrict__ ra = a.tw_a.ranges;
+    const uint2* __restrict__ rb = a.tw_b.ranges;
+    const bool src_overflow = a.tw_a.header->overflow != 0u || a.tw_b.header->overflow != 0u;
+    auto length = [&](int st) -> uint32_t {
+        const uint2 x = ra[st], y = rb[st];
+        return (x.y - x.x) + (y.y - y.x);
+    };
+    if (blockIdx.x == 0) {
+        // ---- ranges: exclusive prefix of the slot counts over the sub-tiles (cell-major order, like the sources) ----------
+        const int per = (subtiles + CBLOCK - 1) / CBLOCK;
+        const int lo = min(subtiles, tid * per), hi = min(subtiles, lo + per);
+        uint32_t mine = 0;
+        for (int st = lo; st < hi; ++st) mine += list_slots(length(st));
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t base = incl - mine, total = 0;
+        for (int i = 0; i < CBLOCK / 64; ++i) {
+            if (i < wave) base += s_wave[i];
+            total += s_wave[i];
+        }
+        const bool overflow = src_overflow || (uint64_t)total * BATCH > a.capacity;
+        uint32_t run = base;
+        for (int st = lo; st < hi; ++st) {
+            const uint32_t n = length(st);
+            a.tw.ranges[st] = overflow ? make_uint2(0u, 0u) : make_uint2(run * BATCH, run * BATCH + n);
+            run += list_slots(n);
+        }
+        if (tid == 0) {
+            ExaRasterHeader* h = a.tw.header;
+            h->num_rendered = total * BATCH; h->overflow = overflow ? 1u : 0u; h->max_tile_list = 0u;
+            h->num_visible = a.tw_a.header->num_visible + a.tw_b.header->num_visible;
+            h->num_instances = a.tw_a.header->num_instances + a.tw_b.header->num_instances;
+            h->active_cells = 0u;
+            h->num_tile_instances = a.tw_a.header->num_tile_instances + a.tw_b.header->num_tile_instances;
+            if (a.host_hdr) {
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v4u v = {total * BATCH, overflow ? 1u : 0u, h->num_visible, a.hdr_tag};
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a.host_hdr), "v"(v) : "memory");
+            }
+        }
+        return;
+    }
+    if ((int)blockIdx.x <= C_ORDER_WGS) {
+        // ---- launch order of the blend: sub-tiles by descending list length class, empty ones last (common.h) ---------------
+        // Every ordering block histograms ALL sub-tiles and, separately, those in front of its own share: its first record of
+        // every class lands at (class offset) + (records of that class before its share) -- no cursor, no atomics across blocks.
+        const int part = (int)blockIdx.x - 1;
+        const int per = (subtiles + C_ORDER_WGS - 1) / C_ORDER_WGS;
+        const int lo = min(subtiles, part * per), hi = min(subtiles, lo + per);
+        if (tid < ORDER_CLASSES) { s_all[tid] = 0u; s_before[tid] = 0u; s_rank[tid] = 0u; }
+        __syncthreads();
+        for (int st = tid; st < subtiles; st += CBLOCK) {
+            const int cls = length_class(src_overflow ? 0u : length(st));
+            atomicAdd(&s_all[cls], 1u);
+            if (st < lo) atomicAdd(&s_before[cls], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
+            const int cls = tid == 63 ? 0 : 63 - tid;
+            const uint32_t v = s_all[cls];
+            uint32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            s_off[cls] = incl - v + s_before[cls];
+        }
+        __syncthreads();
+        // ranks inside the share in sub-tile order would need a scan per class; the order INSIDE a class does not matter
+        // (same length class), so LDS atomics hand the slots out
+        for (int st = lo + tid; st < hi; st += CBLOCK) {
+            const uint32_t n = src_overflow ? 0u : length(st);
+            const int cls = length_class(n);
+            const uint32_t r = atomicAdd(&s_rank[cls], 1u);
+            a.tw.slots[s_off[cls] + r] = make_uint4(0u, n, (uint32_t)st, 0u);     // (the blend reads its range from tw.ranges[st])
+        }
+        return;
+    }
+    {   // ---- zero-filled section of the composite's workspace: owners (merge_kernel), blended masks (render_fwd), touched (render_bwd)
+        const size_t n16 = compose_zero_bytes(a.capacity, a.capacity_b) / 16;
+        uint4* p = a.bw.owner;
+        const size_t first = (size_t)((int)blockIdx.x - 1 - C_ORDER_WGS) * CBLOCK + tid, stride = (size_t)C_ZERO_WGS * CBLOCK;
+        for (size_t i = first; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+
+// One wave per sub-tile, four per workgroup.
+__global__ __launch_bounds__(CBLOCK) void merge_kernel(Batch<ComposeArgs> batch) {
+    __shared__ uint32_t s_da[CBLOCK / 64][64], s_db[CBLOCK / 64][64], s_out[CBLOCK / 64][64];
+    const ComposeArgs& a = batch.v[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int st = (int)blockIdx.x * (CBLOCK / 64) + wave;
+    if (st >= a.grid.subtiles) return;
+    const uint2 rc = a.tw.ranges[st];
+    const int n = (int)(rc.y - rc.x);
+    if (n == 0) return;                                          // empty list (or overflow: every range is empty)
+    const uint2 xa = a.tw_a.ranges[st], xb = a.tw_b.ranges[st];
+    const int nA = (int)(xa.y - xa.x), nB = (int)(xb.y - xb.x);
+    const unsigned long long* __restrict__ ka = a.bw_a.keys + xa.x;
+    const unsigned long long* __restrict__ kb = a.bw_b.keys + xb.x;
+    uint32_t* __restrict__ out = a.bw.sorted + rc.x;
+    for (int bq = lane; bq * BATCH < n; bq += 64)               // batch owners: what a backward wave needs to find its work
+        a.bw.owner[rc.x / BATCH + bq] = make_uint4((uint32_t)st + 1u, rc.x, (uint32_t)n, 0u);
+    uint32_t* da = s_da[wave];
+    uint32_t* db = s_db[wave];
+    uint32_t* so = s_out[wave];
+    int ia = 0, ib = 0;
+    for (int base = 0; base < n; base += 64) {
+        const bool va = ia + lane < nA, vb = ib + lane < nB;
+        const unsigned long long ca = va ? ka[ia + lane] : ~0ull, cb = vb ? kb[ib + lane] : ~0ull;
+        const uint32_t dA = (uint32_t)(ca >> 32), dB = (uint32_t)(cb >> 32);       // depth bits (positive floats: bit order = value order)
+        da[lane] = dA; db[lane] = dB;
+        wave_lds_fence();
+        // A candidate: in front of it go its predecessors in A and the B candidates with a strictly smaller depth
+        uint32_t cA = 0, cB = 0;
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) {
+            if (db[cA + s2 - 1] < dA) cA += s2;
+            if (da[cB + s2 - 1] <= dB) cB += s2;                 // B candidate: A candidates with depth <= its own go first
+        }
+        if (db[cA] < dA) cA += 1;                                // (the loops stop at 63)
+        if (da[cB] <= dB) cB += 1;
+        const uint32_t pA = (uint32_t)lane + cA, pB = (uint32_t)lane + cB;
+        const bool tA = va && pA < 64u, tB = vb && pB < 64u;
+        if (tA) so[pA] = (uint32_t)ca;
+        if (tB) so[pB] = (uint32_t)cb | SRC_B;
+        wave_lds_fence();
+        if (base + lane < n) out[base + lane] = so[lane];
+        ia += __popcll(__ballot(tA));
+        ib += __popcll(__ballot(tB));
+        wave_lds_fence();                                        // the next trip overwrites the windows
+    }
+}
+
+hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s) {
+    int subtiles = 0;
+    for (int k = 0; k < K; ++k) subtiles = subtiles > a[k].grid.subtiles ? subtiles : a[k].grid.subtiles;
+    if (subtiles == 0) return hipSuccess;
+    const Batch<ComposeArgs> b = make_batch(a, K);
+    compose_kernel<<<dim3(1 + C_ORDER_WGS + C_ZERO_WGS, K), CBLOCK, 0, s>>>(b);
+    merge_kernel<<<dim3((subtiles + CBLOCK / 64 - 1) / (CBLOCK / 64), K), CBLOCK, 0, s>>>(b);
+    return hipGetLastError();
+}
+
+}  // namespace exa

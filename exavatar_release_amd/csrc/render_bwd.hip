@@ -151,10 +151,13 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         return h;
     };
     const uint32_t grad_first = PREFIX ? (uint32_t)a.grad_first : 0u;
+    // composite render (compose.hip): ids of two sources, bit 31 = source B = the trainable Gaussians; A is constant
+    const bool two = PREFIX && a.splats2 != nullptr;
+    auto trainable = [&](uint32_t id) -> bool { return two ? (id & SRC_B) != 0u : id >= grad_first; };
     auto is_active = [&](const BwdHdr& h) -> bool {              // wave-uniform
         uint32_t lo = __builtin_amdgcn_readfirstlane(h.bm_lo), hi = __builtin_amdgcn_readfirstlane(h.bm_hi);
         if (PREFIX) {                                            // blended AND trainable (lanes past the list end hold
-            const unsigned long long tr = __ballot(h.id >= grad_first);     // garbage ids, but their mask bits are clear)
+            const unsigned long long tr = __ballot(trainable(h.id));        // garbage ids, but their mask bits are clear)
             lo &= (uint32_t)tr; hi &= (uint32_t)(tr >> 32);
         }
         return __builtin_amdgcn_readfirstlane(h.st1) != 0u && (lo | hi) != 0u;
@@ -174,12 +177,18 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         const SubTile sub = decode_subtile(st, a.grid);
         const bool flagged = (((lane < 32 ? bm_lo : bm_hi) >> (lane & 31)) & 1u) != 0u;
         if (flagged) {
-            const float4* rec = reinterpret_cast<const float4*>(a.splats + min(h.id, (uint32_t)(a.P - 1)));
+            const Splat* base = a.splats;
+            uint32_t idx = h.id, last = (uint32_t)(a.P - 1);
+            if (two) {
+                idx = h.id & ~SRC_B;
+                if (h.id & SRC_B) { base = a.splats2; last = (uint32_t)(a.P2 - 1); }
+            }
+            const float4* rec = reinterpret_cast<const float4*>(base + min(idx, last));
             p.r0 = rec[0]; p.r1 = rec[1]; p.r2 = rec[2];
             const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
             const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
             p.pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
-            if (PREFIX && h.id < grad_first) p.pslot = NO_SLOT;
+            if (PREFIX && !trainable(h.id)) p.pslot = NO_SLOT;
         }
         // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
         const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;

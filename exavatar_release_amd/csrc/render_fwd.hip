@@ -42,8 +42,8 @@ constexpr int SPLIT_SORT_SUBTILES = 65536;   // from this many sub-tiles on the 
 //            the Gaussian id is the low word).  All searches of a level finish (barrier) before any write,
 //            so the levels run IN PLACE.
 template <int E>      // E = keys per thread: lists of up to 256 * E keys
-__device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restrict__ gkeys, int n,
-                                               uint32_t* __restrict__ sorted, unsigned long long* buf, int tid) {
+__device__ __forceinline__ void lds_merge_sort(const unsigned long long* gkeys, int n, uint32_t* __restrict__ sorted,
+                                               unsigned long long* keys_out, unsigned long long* buf, int tid) {
     constexpr int NPAD = SBLOCK * E;
     const int lane = tid & 63;
     unsigned long long key[E];
@@ -118,7 +118,10 @@ __device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restr
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = e * SBLOCK + tid;
-        if (i < n) sorted[i] = (uint32_t)buf[i];
+        if (i < n) {
+            sorted[i] = (uint32_t)buf[i];
+            if (keys_out) keys_out[i] = buf[i];               // (every input key was read before the first barrier)
+        }
     }
 }
 
@@ -138,8 +141,8 @@ __device__ __forceinline__ void lds_merge_sort(const unsigned long long* __restr
 // one depth) is left to the merge sort: returns false before anything was written.
 constexpr int BUCKET_MAX = 48;
 template <int E>      // E = keys per thread: lists of up to 256 * E keys, 256 * E buckets
-__device__ __forceinline__ bool lds_bucket_sort(const unsigned long long* __restrict__ gkeys, int n,
-                                                uint32_t* __restrict__ sorted, unsigned long long* buf, uint32_t* cnt,
+__device__ __forceinline__ bool lds_bucket_sort(const unsigned long long* gkeys, int n, uint32_t* __restrict__ sorted,
+                                                unsigned long long* keys_out, unsigned long long* buf, uint32_t* cnt,
                                                 uint32_t* s_misc, int tid) {
     constexpr int NB = SBLOCK * E;
     const int lane = tid & 63, wave = tid >> 6;
@@ -211,14 +214,15 @@ __device__ __forceinline__ bool lds_bucket_sort(const unsigned long long* __rest
             uint32_t rank = s0;
             for (uint32_t j = s0; j < s1; ++j) rank += buf[j] < key[e] ? 1u : 0u;
             sorted[rank] = (uint32_t)key[e];
+            if (keys_out) keys_out[rank] = key[e];            // in place over the input: all keys sit in registers by now
         }
     }
     return true;
 }
 
 // Single-wave variant for short lists (<= 64 keys): one rank-sort pass, no barriers.
-__device__ __forceinline__ void wave_rank_sort64(const unsigned long long* __restrict__ gkeys, int n,
-                                                 uint32_t* __restrict__ sorted, unsigned long long* buf, int lane) {
+__device__ __forceinline__ void wave_rank_sort64(const unsigned long long* gkeys, int n, uint32_t* __restrict__ sorted,
+                                                 unsigned long long* keys_out, unsigned long long* buf, int lane) {
     const unsigned long long mine = lane < n ? gkeys[lane] : ~0ull;
     buf[lane] = mine;
     wave_lds_fence();
@@ -230,7 +234,10 @@ __device__ __forceinline__ void wave_rank_sort64(const unsigned long long* __res
         rank += (kk.x < mine) ? 1u : 0u;
         rank += (kk.y < mine) ? 1u : 0u;
     }
-    if (lane < n) sorted[rank] = (uint32_t)mine;
+    if (lane < n) {
+        sorted[rank] = (uint32_t)mine;
+        if (keys_out) keys_out[rank] = mine;                  // (the wave's loads are complete: rank depends on all of them)
+    }
 }
 
 // ---- lists longer than SORT_TILE: rank sort, R own keys per thread in registers per pass, comparands staged
@@ -273,7 +280,8 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
 // L2-resident ranges), then ranks its own share inside LDS, reserves one contiguous range per class with a
 // single device atomic, and writes the records.
 constexpr int ORDER_WGS = 16;
-__device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int part, int tid) {
+template <typename RangeOf>       // RangeOf(st) -> [begin, end) of sub-tile st's list; the records hold what it returns
+__device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int part, int tid, RangeOf range_of) {
     __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
     const int lane = tid & 63;
     if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
@@ -283,7 +291,7 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int st = base + i * SBLOCK + tid;
-            r[i] = st < subtiles ? w.ranges[st] : make_uint2(0u, 0u);
+            r[i] = st < subtiles ? range_of(st) : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -314,7 +322,7 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int st = base + i * SBLOCK + tid;
-            r[i] = st < hi ? w.ranges[st] : make_uint2(0u, 0u);
+            r[i] = st < hi ? range_of(st) : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -366,7 +374,9 @@ __global__ __launch_bounds__(SBLOCK) void sort_short_kernel(Batch<RenderFwdArgs>
     const int st = (int)a.tw.cell_desc[idx >> 6].x * SUBS_PER_CELL + (idx & 63);
     const uint2 range = a.tw.ranges[st];
     const int n = (int)(range.y - range.x);
-    if (n > 0 && n <= 64) wave_rank_sort64(a.bw.keys + range.x, n, a.bw.sorted + range.x, s_buf + wave * 64, lane);
+    if (n > 0 && n <= 64)
+        wave_rank_sort64(a.bw.keys + range.x, n, a.bw.sorted + range.x, a.keep_sorted_keys ? a.bw.keys + range.x : nullptr,
+                         s_buf + wave * 64, lane);
 }
 
 template <bool SPLIT>
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     if ((int)blockIdx.x >= a.grid.subtiles + ORDER_WGS) return;   // a job with a smaller image than the largest of the batch
     const int tid = threadIdx.x;
     if (blockIdx.x < ORDER_WGS) {
-        order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid);
+        order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid, [&](int st) { return a.tw.ranges[st]; });
         return;
     }
 #ifdef EXA_PROBE_SORT
@@ -396,28 +406,38 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     const uint2 range = a.tw.ranges[st];
     const int n = (int)(range.y - range.x);                     // workgroup-uniform; empty on overflow
     if (n == 0) return;
-    const unsigned long long* gkeys = a.bw.keys + range.x;
+    unsigned long long* gkeys = a.bw.keys + range.x;
     uint32_t* sorted = a.bw.sorted + range.x;
+    // merge source of a composite render (compose): the sorted 64-bit keys replace the unsorted ones, in place
+    unsigned long long* keys_out = a.keep_sorted_keys ? gkeys : nullptr;
     if (n <= 64) {
-        if (!SPLIT && tid < 64) wave_rank_sort64(gkeys, n, sorted, s_buf, tid);      // (SPLIT: sort_short_kernel did it)
+        if (!SPLIT && tid < 64) wave_rank_sort64(gkeys, n, sorted, keys_out, s_buf, tid);      // (SPLIT: sort_short_kernel did it)
         return;
     }
     if (n > SORT_TILE) {   // longer lists: 2048 own keys at a time against the whole list (any length)
         for (int first = 0; first < n; first += 8 * SBLOCK) rank_sort_list<8>(gkeys, n, first, sorted, s_buf, tid);
+        if (keys_out) {    // the passes re-read the unsorted keys, so the sorted ones are rebuilt afterwards: depth bits of the record
+            __threadfence_block();
+            __syncthreads();
+            for (int i = tid; i < n; i += SBLOCK) {
+                const uint32_t id = sorted[i];
+                keys_out[i] = ((unsigned long long)__float_as_uint(a.splats[id].depth) << 32) | id;
+            }
+        }
         return;
     }
     // distribution sort first; the merge sort takes the (rare) lists whose depths pile up in one bucket
     bool done;
-    if (n <= 256) done = lds_bucket_sort<1>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
-    else if (n <= 512) done = lds_bucket_sort<2>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
-    else if (n <= 1024) done = lds_bucket_sort<4>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
-    else done = lds_bucket_sort<8>(gkeys, n, sorted, s_buf, s_cnt, s_misc, tid);
+    if (n <= 256) done = lds_bucket_sort<1>(gkeys, n, sorted, keys_out, s_buf, s_cnt, s_misc, tid);
+    else if (n <= 512) done = lds_bucket_sort<2>(gkeys, n, sorted, keys_out, s_buf, s_cnt, s_misc, tid);
+    else if (n <= 1024) done = lds_bucket_sort<4>(gkeys, n, sorted, keys_out, s_buf, s_cnt, s_misc, tid);
+    else done = lds_bucket_sort<8>(gkeys, n, sorted, keys_out, s_buf, s_cnt, s_misc, tid);
     if (done) return;
     __syncthreads();
-    if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, s_buf, tid);             // (a plain O(n^2) rank sort of the whole
-    else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, s_buf, tid);        //  list was 40 % slower: LDS-pipe bound)
-    else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, s_buf, tid);
-    else lds_merge_sort<8>(gkeys, n, sorted, s_buf, tid);
+    if (n <= 256) lds_merge_sort<1>(gkeys, n, sorted, keys_out, s_buf, tid);             // (a plain O(n^2) rank sort of the whole
+    else if (n <= 512) lds_merge_sort<2>(gkeys, n, sorted, keys_out, s_buf, tid);        //  list was 40 % slower: LDS-pipe bound)
+    else if (n <= 1024) lds_merge_sort<4>(gkeys, n, sorted, keys_out, s_buf, tid);
+    else lds_merge_sort<8>(gkeys, n, sorted, keys_out, s_buf, tid);
 #ifdef EXA_PROBE_SORT
     __syncthreads();
     if (tid == 0) a.tw.part_cnt[st] = (uint32_t)(__builtin_readcyclecounter() - t0);      // probe build only
@@ -425,7 +445,10 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
 }
 
 // ---- blend ---------------------------------------------------------------------------------------------
-template <bool STORE>
+// TWO = true: composite render (compose.hip).  The sorted list holds ids of TWO finished renders of this camera (bit 31 =
+// source B) and the launch records carry the sub-tile only (its range is read from tw.ranges); everything else -- batches,
+// checkpoints, blended masks -- is the plain kernel, its own instantiation so that the headline path carries no test.
+template <bool STORE, bool TWO>
 __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ BatchLds s_b;
 
@@ -443,13 +466,17 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
     const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
     const bool inside = pxi < a.grid.W && pyi < a.grid.H;
     const float fx = (float)pxi, fy = (float)pyi;
-    const uint2 range = make_uint2(slot.x, slot.y);
+    const uint2 range = TWO ? a.tw.ranges[slot.z] : make_uint2(slot.x, slot.y);
     const int n = (int)(range.y - range.x);
 
     float T = 1.0f, live = inside ? 1.0f : 0.0f;
     v2f Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};                     // (r, g) and (b, depth) accumulators
     const Splat* __restrict__ splats = a.splats;
     const uint32_t* __restrict__ sorted = a.bw.sorted + range.x;
+    auto record = [&](uint32_t id) -> const float4* {
+        if (TWO) return reinterpret_cast<const float4*>(((id & SRC_B) ? a.splats2 : splats) + (id & ~SRC_B));
+        return reinterpret_cast<const float4*>(splats + id);
+    };
 
     // software pipeline: ids two batches ahead, records one batch ahead
     uint32_t id_next = 0;
@@ -458,7 +485,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         const uint32_t id0 = lane < n ? sorted[lane] : 0u;
         if (64 + lane < n) id_next = sorted[64 + lane];
         if (lane < n) {
-            const float4* rec = reinterpret_cast<const float4*>(splats + id0);
+            const float4* rec = record(id0);
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
         }
     }
@@ -483,7 +510,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             const int jn = base + 64 + lane;
             r0 = make_float4(0.f, 0.f, 0.f, 0.f); r1 = r0; r2 = r0;
             if (jn < n) {
-                const float4* rec = reinterpret_cast<const float4*>(splats + id_next);
+                const float4* rec = record(id_next);
                 r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
             }
             if (jn + 64 < n) id_next = sorted[jn + 64];
@@ -599,10 +626,13 @@ hipError_t launch_render_fwd(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
     static const int pad = [] { const char* e = getenv("EXA_FWD_LDS_PAD"); return e ? atoi(e) : 0; }();
-    if (a[0].store_ctx)
-        render_fwd_kernel<true><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
+    if (a[0].splats2) {                 // composite renders (all jobs of such a call are composites)
+        if (a[0].store_ctx) render_fwd_kernel<true, true><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
+        else render_fwd_kernel<false, true><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
+    } else if (a[0].store_ctx)
+        render_fwd_kernel<true, false><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
     else
-        render_fwd_kernel<false><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
+        render_fwd_kernel<false, false><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
     return hipGetLastError();
 }
 

@@ -94,6 +94,7 @@ _verified = {}    # same key -> number of calls whose report was looked at befor
 _pending = []     # header reports nobody has consumed yet: _Pending records
 overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
 _capture_report = None   # (slot, tag): header-report slot baked into the call being CAPTURED (set by GraphedRenderer)
+_last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
 
 
 def _ptr(t):
@@ -417,7 +418,7 @@ class _Job:
     """Host-side record of one render of a batch."""
     __slots__ = ('rs', 'P', 'nF', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
                  'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
-                 'gb', 'tb')
+                 'gb', 'tb', 'keep_keys', 'rec', 'device')
 
 
 _F32 = torch.float32
@@ -433,6 +434,7 @@ def _fill_forward_job(a, j, report=None):
     a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = j.geom_ptr, j.tile_ptr, j.bin_ptr, j.capacity
     base = j.planes.data_ptr()
     a.out_color, a.out_depth, a.out_alpha = base, base + 12 * j.H * j.W, base + 16 * j.H * j.W
+    a.keep_sorted_keys = 1 if j.keep_keys else 0
     if report is not None and report.event is None:
         a.host_header, a.header_tag = _hdr_pool.dev_base + 16 * report.slot, report.tag
     else:
@@ -453,7 +455,9 @@ N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, 
 
 
 class _Rasterize(torch.autograd.Function):
-    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, densify, frozen, *tensors[8 K]).
+    """K renders, one launch per pipeline stage.  apply(K, settings, grad_enabled, shared, densify, frozen, opts, *tensors[8 K]).
+    ``opts``: None or a dict -- ``keep_keys``: the renders will be sources of composite renders (:class:`_Compose`): their
+    sorts keep the sorted 64-bit keys, and the host records of the jobs are published in ``_last_handles``.
     ``densify``: None or a K-list of None / (xyz_grad_accum, track_cnt, radius_max) tensors updated IN PLACE by that
     render's backward (fused densification statistics, include/exa_raster.h).
     ``frozen``: None or a K-list of None / 8-tuples in the order of ``_IN_NAMES``: a CONSTANT prefix of Gaussians that
@@ -462,8 +466,10 @@ class _Rasterize(torch.autograd.Function):
     rows only and skips all work on the prefix (``ExaRasterBackwardJob.grad_first``)."""
 
     @staticmethod
-    def forward(ctx, K, settings, grad_enabled, shared, densify, frozen, *tensors):
+    def forward(ctx, K, settings, grad_enabled, shared, densify, frozen, opts, *tensors):
+        global _last_handles
         lib = _lib.load()
+        keep_keys = bool(opts and opts.get('keep_keys'))
         device = tensors[0].device
         if device.type != 'cuda':
             raise RuntimeError('exavatar_release_amd: the rasterizer runs on a ROCm device only '
@@ -503,6 +509,7 @@ class _Rasterize(torch.autograd.Function):
             j.cov = inp(cov, 7, 'cov3D_precomp')
             j.sh_M = int(j.sh.shape[1]) if j.sh is not None else 0
             j.key = (device.index, j.P, j.H, j.W)
+            j.keep_keys, j.rec, j.device = keep_keys, None, device
             jobs.append(j)
         if shared and K > 1:
             # "K views of the same Gaussians" is decided on what the kernels will see: the converted tensors
@@ -606,12 +613,16 @@ class _Rasterize(torch.autograd.Function):
                     rec.jobs, rec.reports, rec.store_ctx, rec.device = jobs, reports, need_ctx, device
                     rec.done = rec.backward_done = False
                     _pending.append(rec)
+                    for j in jobs:
+                        j.rec = rec
 
         if config.keep_debug:
             j = jobs[-1]
             _debug_last['tile'] = j.ws[j.gb:j.gb + j.tb]
             _debug_last['geom'] = j.ws[:j.gb]
             _debug_last['capacity'] = j.capacity
+        if keep_keys:
+            _last_handles = jobs
         ctx.need_ctx = need_ctx
         outs = []
         for j in jobs:
@@ -649,9 +660,9 @@ class _Rasterize(torch.autograd.Function):
         K = ctx.K
         saved = ctx.saved_tensors
         device = saved[0].device
-        need = ctx.needs_input_grad[6:]
+        need = ctx.needs_input_grad[7:]
         arr = (_lib.ExaRasterBackwardJob * K)()
-        keep, ret = [], [None, None, None, None, None, None]
+        keep, ret = [], [None, None, None, None, None, None, None]
         rec = ctx.rec
         with _on_device(device):
             if rec is not None and not rec.done:
@@ -739,6 +750,198 @@ class _Rasterize(torch.autograd.Function):
         return tuple(ret)
 
 
+class _CJob:
+    """Host-side record of one composite render."""
+    __slots__ = ('a', 'b', 'rs', 'settings', 'keep', 'planes', 'radii', 'ws', 'tile_ptr', 'bin_ptr', 'capacity', 'tb',
+                 'src_ptrs', 'report', 'key')
+
+
+def _compose_launch(cjobs, store_ctx, device, capturing):
+    """(Re-)run the forward of the composite jobs against the CURRENT workspaces of their sources."""
+    lib = _lib.load()
+    K = len(cjobs)
+    arr = (_lib.ExaRasterComposeJob * K)()
+    stream_obj = torch.cuda.current_stream(device)
+    pool = None if capturing else _pool()
+    for k, c in enumerate(cjobs):
+        ja, jb = c.a, c.b
+        c.capacity = ja.capacity + jb.capacity
+        sz = _lib.ExaRasterWorkspaceSizes()
+        _lib.check(lib.exa_raster_compose_sizes(c.rs.image_width, c.rs.image_height, c.capacity, jb.capacity, ctypes.byref(sz)))
+        c.tb = int(sz.tile_bytes)
+        c.ws = torch.empty(c.tb + int(sz.bin_bytes), dtype=torch.uint8, device=device)
+        c.tile_ptr = c.ws.data_ptr()
+        c.bin_ptr = c.tile_ptr + c.tb
+        c.src_ptrs = (ja.geom_ptr, jb.geom_ptr, ja.bin_ptr, jb.bin_ptr)
+        a = arr[k]
+        a.settings = ctypes.pointer(c.settings)
+        a.P_a, a.P_b = ja.P, jb.P
+        a.geom_a, a.tile_a, a.bin_a, a.capacity_a = ja.geom_ptr, ja.tile_ptr, ja.bin_ptr, ja.capacity
+        a.geom_b, a.tile_b, a.bin_b, a.capacity_b = jb.geom_ptr, jb.tile_ptr, jb.bin_ptr, jb.capacity
+        a.tile_ws, a.bin_ws, a.capacity = c.tile_ptr, c.bin_ptr, c.capacity
+        base = c.planes.data_ptr()
+        H, W = int(c.rs.image_height), int(c.rs.image_width)
+        a.out_color, a.out_depth, a.out_alpha = base, base + 12 * H * W, base + 16 * H * W
+        c.report = None
+        a.host_header, a.header_tag = None, 0
+        if pool is not None:
+            r = _Report()
+            r.stream, r.event, r.host, r.row = stream_obj, None, None, None
+            r.slot, r.tag, dev_addr = pool.take()
+            r.tile_ptr = c.tile_ptr
+            a.host_header, a.header_tag = dev_addr, r.tag
+            c.report = r
+    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx), ctypes.c_void_p(stream_obj.cuda_stream)))
+
+
+class _Compose(torch.autograd.Function):
+    """K composite renders of pairs of finished renders (``exa_raster_forward_compose_batch``): render k shows source A
+    (a constant: the detached scene) and source B (trainable: the human) together, from the sources' own splat records and
+    sorted lists -- no preprocess, binning or sort of its own.  apply(K, sources, settings, grad_enabled, *tensors[8 K]):
+    ``sources[k] = (handle_a, handle_b)`` from ``rasterize_gaussians_batch(..., keep_keys=True)``; the tensors are B's inputs
+    (the same objects its own render got), they receive this render's gradients."""
+
+    @staticmethod
+    def forward(ctx, K, sources, settings, grad_enabled, *tensors):
+        device = tensors[0].device
+        need_ctx = bool(grad_enabled) and any(ctx.needs_input_grad)
+        capturing = torch.cuda.is_current_stream_capturing()
+        cjobs = []
+        with _on_device(device):
+            for k in range(K):
+                ja, jb = sources[k]
+                rs = settings[k]
+                if ja.device != device or jb.device != device:
+                    raise ValueError('composite render: sources live on another device')
+                if (ja.H, ja.W) != (jb.H, jb.W) or (int(rs.image_height), int(rs.image_width)) != (ja.H, ja.W):
+                    raise ValueError('composite render: the sources and the composite must share one image size')
+                for name in ('viewmatrix', 'projmatrix'):
+                    if getattr(ja.settings, name) != getattr(jb.settings, name):
+                        raise ValueError('composite render: the two sources were rendered with different cameras')
+                if ja.nF or jb.nF:
+                    raise ValueError('composite render: sources with a constant prefix are not supported')
+                if not (ja.keep_keys and jb.keep_keys):
+                    raise ValueError('composite render: sources must come from rasterize_gaussians_batch(..., keep_keys=True)')
+                if tensors[N_IN * k].shape[0] != jb.P:
+                    raise ValueError('composite render: the tensors must be source B\'s inputs')
+                c = _CJob()
+                c.a, c.b, c.rs = ja, jb, rs
+                c.keep = []
+                c.settings = _make_settings(rs, device, c.keep)
+                if c.settings.viewmatrix != ja.settings.viewmatrix:
+                    raise ValueError('composite render: its camera differs from the sources\'')
+                c.planes = torch.empty((5, ja.H, ja.W), dtype=_F32, device=device)
+                c.radii = torch.cat((ja.radii, jb.radii))
+                c.key = ('compose', device.index, ja.P, jb.P, ja.H, ja.W)
+                cjobs.append(c)
+            _compose_launch(cjobs, need_ctx, device, capturing)
+        ctx.need_ctx = need_ctx
+        outs = []
+        for c in cjobs:
+            col, d, al = c.planes.split((3, 1, 1))
+            outs += [col, c.radii, d, al]
+        if need_ctx:
+            ctx.K, ctx.cjobs, ctx.device = K, cjobs, device
+        ctx.mark_non_differentiable(*[outs[4 * k + 1] for k in range(K)])
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if not ctx.need_ctx:
+            raise RuntimeError('exavatar_release_amd: backward called on a composite that stored no context')
+        lib = _lib.load()
+        K, cjobs, device = ctx.K, ctx.cjobs, ctx.device
+        need = ctx.needs_input_grad[4:]
+        arr = (_lib.ExaRasterBackwardJob * K)()
+        keep, ret = [], [None, None, None, None]
+        with _on_device(device):
+            # A composite cannot overflow by itself (its buffer holds both sources' capacities); it is incomplete exactly
+            # when a source overflowed.  The sources' reports are older than this render's, so they are looked at first;
+            # a source that gets re-rendered (config.on_overflow == 'retry') moves its workspaces, and the composite is
+            # then rendered again from the repaired lists before its backward kernels are queued.
+            redo = False
+            for c in cjobs:
+                for j in (c.a, c.b):
+                    rec = j.rec
+                    if rec is not None and not rec.done:
+                        block = config.overflow_check == 'always' or config.fixed_capacity is not None or \
+                            _verified.get(j.key, 0) < config.verify_calls or _seen_D.get(j.key, 0) > config.danger_fill * j.capacity
+                        if _consume(rec, block, from_backward=True):
+                            for jj in rec.jobs:
+                                _verified[jj.key] = _verified.get(jj.key, 0) + 1
+                            try:
+                                _pending.remove(rec)
+                            except ValueError:
+                                pass
+                if c.src_ptrs != (c.a.geom_ptr, c.b.geom_ptr, c.a.bin_ptr, c.b.bin_ptr):
+                    redo = True
+            if redo:
+                _compose_launch(cjobs, True, device, False)
+            for k, c in enumerate(cjobs):
+                ja, jb = c.a, c.b
+                P, H, W, sh_M = jb.P, jb.H, jb.W, jb.sh_M
+                has_sh, has_col, has_sc, has_rot, has_cov = [t is not None for t in (jb.sh, jb.colors, jb.scales, jb.rot, jb.cov)]
+                g_color = _grad_in(grads[4 * k], (3, H, W), device)
+                if g_color is None:
+                    g_color = torch.zeros((3, H, W), dtype=_F32, device=device)
+                g_depth = _grad_in(grads[4 * k + 2], (1, H, W), device)
+                g_alpha = _grad_in(grads[4 * k + 3], (1, H, W), device)
+                nd = need[N_IN * k: N_IN * (k + 1)]
+                want = ((nd[0], 3), (nd[1], 3), (has_col and nd[3], 3), (nd[4], 1), (has_sc and nd[5], 3), (has_rot and nd[6], 4),
+                        (has_cov and nd[7], 6))
+                widths = [w for on, w in want if on]
+                pieces = iter(torch.empty(P * sum(widths), dtype=_F32, device=device).split([P * w for w in widths])) \
+                    if widths else iter(())
+                d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
+                    [next(pieces).view(P, w) if on else None for on, w in want]
+                d_sh = torch.empty((P, sh_M, 3), dtype=_F32, device=device) if has_sh and nd[2] else None
+                grad_ws = torch.empty(48 * jb.capacity + 256, dtype=torch.uint8, device=device)
+                keep += [g_color, g_depth, g_alpha, grad_ws]
+                a = arr[k]
+                a.settings = ctypes.pointer(c.settings)
+                a.P, a.sh_M = P, sh_M
+                a.means3D, a.shs, a.colors_precomp = _addr(jb.means3D), _addr(jb.sh), _addr(jb.colors)
+                a.opacities, a.scales, a.rotations = _addr(jb.opac), _addr(jb.scales), _addr(jb.rot)
+                a.cov3D_precomp = _addr(jb.cov)
+                a.radii = jb.radii.data_ptr()
+                a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = jb.geom_ptr, c.tile_ptr, c.bin_ptr, c.capacity
+                a.dL_dcolor, a.dL_ddepth, a.dL_dalpha = g_color.data_ptr(), _addr(g_depth), _addr(g_alpha)
+                a.grad_ws = grad_ws.data_ptr()
+                a.dL_dmeans2D, a.dL_dmeans3D, a.dL_dcolors = _addr(d_means2D), _addr(d_means3D), _addr(d_colors)
+                a.dL_dopacity, a.dL_dscales, a.dL_drotations = _addr(d_opac), _addr(d_scales), _addr(d_rot)
+                a.dL_dsh, a.dL_dcov3D = _addr(d_sh), _addr(d_cov)
+                a.grad_first = 0
+                a.compose_geom_a, a.compose_P_a, a.compose_capacity_b = ja.geom_ptr, ja.P, jb.capacity
+                ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
+            _lib.check(lib.exa_raster_backward_batch(arr, K, 0, _stream_ptr(device)))
+        return tuple(ret)
+
+
+def rasterize_composites(sources, jobs):
+    """K composite renders -- "source A and source B rendered together" -- from renders that already exist.
+
+    ``sources``: K pairs ``(handle_a, handle_b)`` of handles returned by ``rasterize_gaussians_batch(..., keep_keys=True)``
+    (same camera, same image size, same stream); A is treated as a constant (ExAvatar's detached scene,
+    ``avatar/main/model.py:119-126``), B is trainable.  ``jobs``: K dicts with B's keyword tensors (the very tensors its own
+    render got; they receive this render's gradients), a fresh ``means2D`` probe of B's length and ``raster_settings`` (the
+    composite's background).  The composite reuses the sources' splat records and MERGES their sorted per-sub-tile lists:
+    no preprocess, binning or sort of its own, bit-identical to rendering ``cat(A, B)``.  Returns K ``(color, radii, depth,
+    alpha)`` tuples; ``radii`` = ``cat(radii_a, radii_b)``."""
+    jobs = list(jobs)
+    K = len(jobs)
+    if K == 0:
+        return []
+    if len(sources) != K:
+        raise ValueError('rasterize_composites: one (handle_a, handle_b) pair per job')
+    flat = []
+    for j in jobs:
+        flat += [j.get(n) for n in _IN_NAMES]
+    outs = _Compose.apply(K, tuple(tuple(s) for s in sources), tuple(j['raster_settings'] for j in jobs),
+                          torch.is_grad_enabled(), *flat)
+    return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
+
+
 def _check_densify(dens, P, device):
     if dens is None:
         return None
@@ -778,14 +981,14 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     """``densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` float32 tensors of P elements that THIS
     render's backward updates in place (fused densification statistics, see ``densify.track_densify_stats``)."""
     dens = None if densify_stats is None else [_check_densify(densify_stats, int(means3D.shape[0]), means3D.device)]
-    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, dens, None, means3D, means2D, sh,
+    return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, dens, None, None, means3D, means2D, sh,
                             colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
 
 
 _IN_NAMES = ('means3D', 'means2D', 'shs', 'colors_precomp', 'opacities', 'scales', 'rotations', 'cov3D_precomp')
 
 
-def rasterize_gaussians_batch(jobs):
+def rasterize_gaussians_batch(jobs, keep_keys=False):
     """K renders in one launch per pipeline stage.
 
     ``jobs``: sequence of dicts with the keyword arguments of ``GaussianRasterizer.forward`` plus
@@ -796,6 +999,8 @@ def rasterize_gaussians_batch(jobs):
     calls.  When every job passes the SAME tensor objects for the Gaussians (K views of one model), the backward
     sums the K views' gradients inside the per-Gaussian kernel (one thread walks the K views) instead of letting
     autograd add K gradient tensors; such a batch may also share ONE set of ``densify_stats`` tensors.
+    ``keep_keys=True``: the renders will be sources of composite renders (:func:`rasterize_composites`); returns
+    ``(outputs, handles)`` with one opaque handle per job.
     """
     jobs = list(jobs)
     K = len(jobs)
@@ -823,9 +1028,15 @@ def rasterize_gaussians_batch(jobs):
     if any(j.get('densify_stats') is not None for j in jobs):
         dens = [_check_densify(j.get('densify_stats'), int(j['means3D'].shape[0]), j['means3D'].device) for j in jobs]
         _check_densify_aliasing(dens, shared)
+    global _last_handles
+    _last_handles = None
     outs = _Rasterize.apply(K, tuple(j['raster_settings'] for j in jobs), torch.is_grad_enabled(), shared, dens, frozen,
-                            *flat)
-    return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
+                            {'keep_keys': True} if keep_keys else None, *flat)
+    res = [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
+    if keep_keys:
+        handles, _last_handles = _last_handles, None
+        return res, handles
+    return res
 
 
 def _check_combo(shs, colors_precomp, scales, rotations, cov3D_precomp):

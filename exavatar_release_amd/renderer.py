@@ -15,7 +15,8 @@ import torch
 import torch.nn as nn
 
 from .camera import make_raster_matrices
-from .rasterizer import GaussianRasterizationSettings, rasterize_gaussians, rasterize_gaussians_batch
+from .rasterizer import (GaussianRasterizationSettings, rasterize_composites, rasterize_gaussians,
+                         rasterize_gaussians_batch)
 
 
 _CAM_KEYS = ('focal', 'princpt', 'R', 't')
@@ -259,7 +260,7 @@ ITERATION_RENDERS = ('scene', 'human', 'scene_human', 'human_refined', 'scene_hu
 
 
 def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, img_shape, cam_param, bg,
-                     scene_densify_stats=None):
+                     scene_densify_stats=None, merge=True):
     """The five same-camera renders of one ExAvatar training sample (``avatar/main/model.py:119-167``) as ONE batched
     call with the Gaussian SETS shared between them:
 
@@ -280,7 +281,30 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
     kernels are separate instantiations: ~1e-7 relative).
     ``scene_densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` updated by the scene render's backward
     (``model.py:279-285``).  Returns a dict of the five output dicts keyed by :data:`ITERATION_RENDERS`.
+
+    ``merge=True`` (default): the two composites are not binned at all.  ``scene``, ``human`` and ``human_refined`` are
+    three jobs of one batched call whose sorts keep their keys; ``scene_human`` / ``scene_human_refined`` are COMPOSITE
+    renders (``exa_raster_forward_compose_batch``, csrc/compose.hip) that reuse those renders' splat records and MERGE their
+    sorted per-sub-tile lists -- no preprocess, cell scatter, sub-tile binning or sort for two of the five renders, no
+    ``torch.cat`` of the Gaussian tensors either.  Same images bit for bit.  ``merge=False``: the round-2 formulation (five
+    jobs, the scene as a constant prefix of the composites).
     """
+    device = scene_asset['mean_3d'].device
+    if device.type != 'cuda':
+        raise RuntimeError('exavatar_release_amd: render_iteration runs on a ROCm device only')
+    if merge and (_sh_degree(scene_asset) is None) == (_sh_degree(human_asset) is None) and scene_asset['mean_3d'].shape[0] > 0 \
+            and human_asset['mean_3d'].shape[0] > 0 and human_asset_refined['mean_3d'].shape[0] > 0:
+        # three plain renders whose sorts keep their keys ...
+        plain = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats),
+                 _raster_job(human_asset, img_shape, cam_param, bg),
+                 _raster_job(human_asset_refined, img_shape, cam_param, bg)]
+        outs, handles = rasterize_gaussians_batch(plain, keep_keys=True)
+        # ... and the two composites as MERGES of their sorted lists (white background, as the reference renders them)
+        comp = [_raster_job(human_asset, img_shape, cam_param, None), _raster_job(human_asset_refined, img_shape, cam_param, None)]
+        couts = rasterize_composites([(handles[0], handles[1]), (handles[0], handles[2])], comp)
+        res = [_output_dict(plain[0], outs[0]), _output_dict(plain[1], outs[1]), _output_dict(comp[0], couts[0]),
+               _output_dict(plain[2], outs[2]), _output_dict(comp[1], couts[1])]
+        return dict(zip(ITERATION_RENDERS, res))
     jobs = [(scene_asset, img_shape, cam_param, None, scene_densify_stats),
             (human_asset, img_shape, cam_param, bg),
             (human_asset, img_shape, cam_param, None, None, scene_asset),

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 130          /* 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 131          /* 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -189,6 +189,8 @@ typedef struct ExaRasterForwardJob {
     void* geom_ws; void* tile_ws;   /* sized by exa_raster_workspace_sizes(P, W, H, capacity)          */
     void* bin_ws; uint64_t capacity;                     /* ignored by exa_raster_forward_bin_batch    */
     float* out_color; float* out_depth; float* out_alpha; /* ignored by exa_raster_forward_bin_batch   */
+    int32_t keep_sorted_keys;       /* != 0: this render will be a SOURCE of a composite (exa_raster_forward_compose_batch):
+                                       the sort keeps the sorted 64-bit keys (in place, no extra memory)      */
     /* Optional zero-copy header report (NULL = off): a DEVICE-VISIBLE address of 16 bytes of pinned host memory
      * (exa_raster_host_device_pointer).  As soon as the instance count of this job is known -- in the scatter stage,
      * long before the blend finishes -- ONE thread stores {num_rendered, overflow, num_visible, header_tag} there
@@ -222,7 +224,36 @@ typedef struct ExaRasterBackwardJob {
      * dL_dcov3D, densify_*) holds P - grad_first rows: row r belongs to Gaussian grad_first + r.  0 = all trainable.
      * Not combinable with sum_shared. */
     int32_t grad_first;
+    /* Composite render (exa_raster_forward_compose_batch): compose_geom_a != NULL makes this the backward of a composite.
+     * Then P, the input tensors, radii and every gradient array describe source B (the trainable Gaussians), geom_ws is B's
+     * splat workspace, tile_ws / bin_ws / capacity are the COMPOSITE's workspaces, grad_ws holds 48 B x compose_capacity_b,
+     * compose_geom_a / compose_P_a name source A's records (constants: no gradient) and grad_first must be 0. */
+    const void* compose_geom_a; int32_t compose_P_a; uint64_t compose_capacity_b;
 } ExaRasterBackwardJob;
+
+/*
+ * Composite renders: "A and B rendered together" from two renders of the SAME camera and image size that already exist,
+ * without preprocessing, binning or sorting anything again -- the sorted list of every sub-tile is the merge of the two
+ * sources' sorted lists (order of the concatenation cat(A, B): ascending depth, ties by index, so A wins ties).
+ * This is what ExAvatar's scene + human renders are (torch.cat((scene.detach(), human)), avatar/main/model.py:119-126,
+ * next to plain renders of `scene` and `human` in the same iteration).  A is a constant of the backward
+ * pass (the detached scene), B is trainable.  Results are bit-identical to rendering the concatenation.
+ * Both sources must be finished forward calls on the same stream with keep_sorted_keys != 0 whose workspaces are still
+ * alive; the composite owns tile_ws / bin_ws (exa_raster_compose_sizes) and its output images.  radii of the composite =
+ * the sources' radii, A's first.
+ */
+typedef struct ExaRasterComposeJob {
+    const ExaRasterSettings* settings;          /* image size as the sources'; bg of the composite                      */
+    int32_t P_a, P_b;
+    const void* geom_a; const void* tile_a; const void* bin_a; uint64_t capacity_a;
+    const void* geom_b; const void* tile_b; const void* bin_b; uint64_t capacity_b;
+    void* tile_ws; void* bin_ws; uint64_t capacity;      /* capacity_a + capacity_b always suffices                     */
+    float* out_color; float* out_depth; float* out_alpha;
+    void* host_header; uint32_t header_tag;             /* as in ExaRasterForwardJob                                    */
+} ExaRasterComposeJob;
+/* tile_bytes / bin_bytes of a composite's workspaces, grad_bytes of its backward scratch (geom_bytes = 0) */
+int exa_raster_compose_sizes(int32_t W, int32_t H, uint64_t capacity, uint64_t capacity_b, ExaRasterWorkspaceSizes* out);
+int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K, int32_t store_ctx, void* stream);
 
 int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream);
 int exa_raster_forward_render_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);

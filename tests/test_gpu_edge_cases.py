@@ -370,3 +370,115 @@ def test_two_rank_reduced_gradient_equals_single_process_sum(tmp_path):
     for k, v in res['rel_err'].items():
         assert v <= 1e-6, (k, v)
     record_stats('two_rank_gradient', res)
+
+
+# ---- composite renders: merged lists instead of binning the concatenation -------------------------------------------
+def _iteration_case(dev, scene, human, refined, H, W, f, bg, seed, cam=None):
+    """render_iteration three ways: merge (composites from the sources' sorted lists), constant prefix (round 2) and the
+    reference's own formulation (five renders of torch.cat((scene.detach(), human)))."""
+    cam = cam or scenes.neutral_camera(H, W, focal=f)
+    camd = {k: t.to(dev) for k, t in cam.items()}
+    g = torch.Generator().manual_seed(seed)
+    G = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(5)]
+    Gd = [torch.randn(1, H, W, generator=g).to(dev) for _ in range(5)]
+    rend = exa.GaussianRenderer()
+    res = {}
+    for how in ('merge', 'prefix', 'reference'):
+        s, h, r = _to(scene, dev), _to(human, dev), _to(refined, dev)
+        if how == 'reference':
+            cat = lambda a_, b_: {k: torch.cat((a_[k].detach(), b_[k])) for k in KEYS}      # noqa: E731
+            jobs = [(s, (H, W), camd), (h, (H, W), camd, bg), (cat(s, h), (H, W), camd), (r, (H, W), camd, bg), (cat(s, r), (H, W), camd)]
+            outs = [rend(*j) for j in jobs]
+        else:
+            out = exa.render_iteration(rend, s, h, r, (H, W), camd, bg, merge=(how == 'merge'))
+            outs = [out[k] for k in exa.ITERATION_RENDERS]
+        sum((o['img'] * Gi).sum() + (o['depthmap'] * Gdi).sum() + o['mask'].sum() for o, Gi, Gdi in zip(outs, G, Gd)).backward()
+        torch.cuda.synchronize()
+        m2 = [o['mean_2d'].grad.clone() for o in outs]
+        if how == 'reference':                       # the composites' probes cover cat(scene, human): keep the human rows
+            nS = scene['mean_3d'].shape[0]
+            m2[2], m2[4] = m2[2][nS:], m2[4][nS:]
+        res[how] = dict(imgs=[o[k].detach().clone() for o in outs for k in ('img', 'depthmap', 'mask')],
+                        radii=[o['radius'].clone() for o in outs], m2=m2,
+                        grads=[t[k].grad.clone() for t in (s, h, r) for k in KEYS])
+    return res
+
+
+def _assert_iteration_agrees(res):
+    ref = res['reference']
+    for how in ('merge', 'prefix'):
+        got = res[how]
+        for i, (x, y) in enumerate(zip(got['imgs'], ref['imgs'])):
+            assert torch.equal(x, y), '%s image %d' % (how, i)
+        for x, y in zip(got['radii'], ref['radii']):
+            assert torch.equal(x, y)
+        for i, (x, y) in enumerate(zip(got['grads'] + got['m2'], ref['grads'] + ref['m2'])):
+            scale = float(y.abs().max())
+            assert float((x - y).abs().max()) <= 1e-5 * scale + 1e-30, '%s grad %d: %g of %g' % (how, i, float((x - y).abs().max()), scale)
+
+
+def test_composite_renders_merge_the_sorted_lists_of_their_sources(dev):
+    """exa_raster_forward_compose_batch (csrc/compose.hip): scene + human without binning the concatenation -- the composite
+    reuses the sources' splat records and merges their sorted per-sub-tile lists.  Images, depth, alpha and radii equal the
+    reference's five renders (torch.cat((scene.detach(), human))) bit for bit, every gradient to rounding."""
+    H, W, f = 128, 160, 170.0
+    scene = scenes.dist_a_random(3000, H, W, seed=51, focal=f)
+    human = scenes.dist_a_random(1500, H, W, seed=52, focal=f, z_range=(2.0, 4.0))
+    refined = {k: (v + 0.01 * torch.randn(v.shape, generator=torch.Generator().manual_seed(53)) if k == 'mean_3d' else v.clone())
+               for k, v in human.items()}
+    res = _iteration_case(dev, scene, human, refined, H, W, f, torch.tensor([0.1, 0.2, 0.3], device=dev), 54)
+    _assert_iteration_agrees(res)
+
+
+def test_composite_renders_depth_ties_long_lists_and_ragged_images(dev):
+    """The merge rule under stress: scene and human Gaussians at EXACTLY the same depths (the scene wins ties, as its indices
+    precede the human's in the concatenation), lists of several hundred entries per sub-tile (many 64-entry windows per
+    merge, one source running out first), sub-tiles with only one source, a 75 x 100 image, huge splats over all cells."""
+    H, W, f = 75, 100, 130.0
+    g = torch.Generator().manual_seed(71)
+    scene = scenes.dist_a_random(4000, H, W, seed=72, focal=f, z_range=(2.0, 5.0))
+    human = scenes.dist_a_random(2500, H, W, seed=73, focal=f, z_range=(2.0, 5.0))
+    # depth ties: the camera looks down +z from the origin, so equal z = equal depth bits
+    zs = torch.linspace(2.2, 4.8, 40)
+    scene['mean_3d'][:1200, 2] = zs[torch.randint(0, 40, (1200,), generator=g)]
+    human['mean_3d'][:900, 2] = zs[torch.randint(0, 40, (900,), generator=g)]
+    # deep lists: semi-transparent, fairly large
+    scene['opacity'][:] = 0.02 + 0.1 * torch.rand(4000, 1, generator=g)
+    human['opacity'][:] = 0.02 + 0.1 * torch.rand(2500, 1, generator=g)
+    scene['scale'][:2000] *= 3.0
+    human['scale'][:600] *= 4.0
+    human['mean_3d'][600:, 0] = human['mean_3d'][600:, 0].abs() * 0.5 + 0.1        # the rest of the human on the right half only
+    scene['scale'][-3:] = torch.tensor([0.6, 0.5, 0.4])                              # splats over every cell
+    refined = {k: v.clone() for k, v in human.items()}
+    refined['rgb'] = torch.rand(2500, 3, generator=g)
+    res = _iteration_case(dev, scene, human, refined, H, W, f, torch.rand(3, generator=g).to(dev), 74)
+    _assert_iteration_agrees(res)
+
+
+def test_composite_render_agrees_with_the_oracle(dev):
+    """The composite against the CPU oracle on the concatenation (not only against the HIP path's own concatenated render)."""
+    H, W, f = 96, 128, 150.0
+    scene = scenes.dist_a_random(1500, H, W, seed=81, focal=f)
+    human = scenes.dist_a_random(800, H, W, seed=82, focal=f, z_range=(2.0, 4.0))
+    cam = scenes.ring_camera(H, W, 2, 9, radius=3.0, center=(0.0, 0.0, 3.0), focal=f)
+    camd = {k: t.to(dev) for k, t in cam.items()}
+    g = torch.Generator().manual_seed(83)
+    G = torch.randn(3, H, W, generator=g)
+    s, h, r = _to(scene, dev), _to(human, dev), _to(human, dev)
+    out = exa.render_iteration(exa.GaussianRenderer(), s, h, r, (H, W), camd, torch.ones(3, device=dev))
+    o = out['scene_human']
+    (o['img'] * G.to(dev)).sum().backward()
+    h3 = {k: v.clone().requires_grad_(True) for k, v in human.items()}
+    ref = ro.render({k: torch.cat((scene[k], h3[k])) for k in KEYS}, (H, W), cam, torch.ones(3), return_aux=True)
+    (ref['img'] * G).sum().backward()
+    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W)
+    assert_image_close(o['img'], ref['img'], amb, 'img')
+    assert_image_close(o['depthmap'], ref['depthmap'], amb, 'depth')
+    assert torch.equal(o['radius'].cpu(), ref['radius'])
+    nS = scene['mean_3d'].shape[0]
+    near = gaussians_near_pixels(ref['aux']['pre'], amb)[nS:]
+    for k in KEYS:
+        assert_grads_close(h[k].grad, h3[k].grad, k, near,
+                           abs_scale=rotation_grad_scale(h3['scale'], h3['scale'].grad) if k == 'rotation' else 0.0)
+    assert_grads_close(o['mean_2d'].grad, ref['mean_2d'].grad[nS:], 'mean_2d', near)
+    assert all(s[k].grad is None for k in KEYS)          # only the composite was differentiated: the scene is a constant of it

@@ -14,7 +14,8 @@ else
   git -C $ROOT show $REV:include/exa_raster.h > $T/include/exa_raster.h
 fi
 OBJS=""
-for src in preprocess_fwd binning render_fwd render_bwd preprocess_bwd ssim api; do
+for src in preprocess_fwd binning render_fwd render_bwd compose preprocess_bwd ssim api; do
+  [ -f $T/exavatar_release_amd/csrc/$src.hip ] || continue
   X=""; [ $src = preprocess_fwd ] && X="-ffp-contract=off"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -w $X "$@" -c $T/exavatar_release_amd/csrc/$src.hip -o $T/$src.o
   OBJS="$OBJS $T/$src.o"
