@@ -23,9 +23,11 @@
 
 namespace exa {
 
-constexpr int CBLOCK = 256;
+constexpr int CBLOCK = 1024;             // compose_kernel (one workgroup scans every sub-tile: all loads of a thread in flight at once)
+constexpr int MBLOCK = 256;              // merge_kernel: four independent waves
 constexpr int C_ORDER_WGS = 16;
-constexpr int C_ZERO_WGS = 48;
+constexpr int C_ZERO_WGS = 32;
+constexpr int C_PER = 16;                // sub-tiles per thread and trip of the scan
 
 __device__ __forceinline__ uint32_t list_slots(uint32_t n) { return n ? (n + BATCH - 1) / BATCH + 1 : 0u; }   // batches + end slot
 
@@ -44,29 +46,48 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
     };
     if (blockIdx.x == 0) {
         // ---- ranges: exclusive prefix of the slot counts over the sub-tiles (cell-major order, like the sources) ----------
-        const int per = (subtiles + CBLOCK - 1) / CBLOCK;
-        const int lo = min(subtiles, tid * per), hi = min(subtiles, lo + per);
-        uint32_t mine = 0;
-        for (int st = lo; st < hi; ++st) mine += list_slots(length(st));
-        uint32_t incl = mine;
+        // thread t owns sub-tiles [trip * 1024 * 16 + t * 16, + 16): its 32 range loads are independent and issued together
+        uint32_t carry = 0;
+        bool overflow = src_overflow;
+        for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
+            const int lo = trip0 + tid * C_PER;
+            uint32_t len[C_PER];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
+            for (int i = 0; i < C_PER; ++i) len[i] = lo + i < subtiles ? length(lo + i) : 0u;
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i < C_PER; ++i) mine += list_slots(len[i]);
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            __syncthreads();                                     // (s_wave of the previous trip has been read)
+            if (lane == 63) s_wave[wave] = incl;
+            __syncthreads();
+            uint32_t base = carry + incl - mine, total = 0;
+            for (int i = 0; i < CBLOCK / 64; ++i) {
+                if (i < wave) base += s_wave[i];
+                total += s_wave[i];
+            }
+            carry += total;
+            // (an overflow can only come from the sources -- capacity = capacity_a + capacity_b always suffices -- or from a
+            //  caller that passed less; the latter is latched below and every range of the later trips stays valid but unused)
+            uint32_t run = base;
+#pragma unroll
+            for (int i = 0; i < C_PER; ++i) {
+                if (lo + i < subtiles)
+                    a.tw.ranges[lo + i] = overflow ? make_uint2(0u, 0u) : make_uint2(run * BATCH, run * BATCH + len[i]);
+                run += list_slots(len[i]);
+            }
         }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t base = incl - mine, total = 0;
-        for (int i = 0; i < CBLOCK / 64; ++i) {
-            if (i < wave) base += s_wave[i];
-            total += s_wave[i];
-        }
-        const bool overflow = src_overflow || (uint64_t)total * BATCH > a.capacity;
-        uint32_t run = base;
-        for (int st = lo; st < hi; ++st) {
-            const uint32_t n = length(st);
-            a.tw.ranges[st] = overflow ? make_uint2(0u, 0u) : make_uint2(run * BATCH, run * BATCH + n);
-            run += list_slots(n);
+        const uint32_t total = carry;
+        if ((uint64_t)total * BATCH > a.capacity && !overflow) {
+            // the composite's own buffer is too small (never with capacity_a + capacity_b): empty every list again
+            overflow = true;
+            __syncthreads();
+            for (int st = tid; st < subtiles; st += CBLOCK) a.tw.ranges[st] = make_uint2(0u, 0u);
         }
         if (tid == 0) {
             ExaRasterHeader* h = a.tw.header;
@@ -92,10 +113,21 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         const int lo = min(subtiles, part * per), hi = min(subtiles, lo + per);
         if (tid < ORDER_CLASSES) { s_all[tid] = 0u; s_before[tid] = 0u; s_rank[tid] = 0u; }
         __syncthreads();
-        for (int st = tid; st < subtiles; st += CBLOCK) {
-            const int cls = length_class(src_overflow ? 0u : length(st));
-            atomicAdd(&s_all[cls], 1u);
-            if (st < lo) atomicAdd(&s_before[cls], 1u);
+        for (int st0 = 0; st0 < subtiles; st0 += CBLOCK * 4) {
+            uint32_t n4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int st = st0 + i * CBLOCK + tid;
+                n4[i] = st < subtiles && !src_overflow ? length(st) : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int st = st0 + i * CBLOCK + tid;
+                if (st >= subtiles) continue;
+                const int cls = length_class(n4[i]);
+                atomicAdd(&s_all[cls], 1u);
+                if (st < lo) atomicAdd(&s_before[cls], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
@@ -129,11 +161,11 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
 }
 
 // One wave per sub-tile, four per workgroup.
-__global__ __launch_bounds__(CBLOCK) void merge_kernel(Batch<ComposeArgs> batch) {
-    __shared__ uint32_t s_da[CBLOCK / 64][64], s_db[CBLOCK / 64][64], s_out[CBLOCK / 64][64];
+__global__ __launch_bounds__(MBLOCK) void merge_kernel(Batch<ComposeArgs> batch) {
+    __shared__ uint32_t s_da[MBLOCK / 64][64], s_db[MBLOCK / 64][64], s_out[MBLOCK / 64][64];
     const ComposeArgs& a = batch.v[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int st = (int)blockIdx.x * (CBLOCK / 64) + wave;
+    const int st = (int)blockIdx.x * (MBLOCK / 64) + wave;
     if (st >= a.grid.subtiles) return;
     const uint2 rc = a.tw.ranges[st];
     const int n = (int)(rc.y - rc.x);
@@ -182,7 +214,7 @@ hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s) {
     if (subtiles == 0) return hipSuccess;
     const Batch<ComposeArgs> b = make_batch(a, K);
     compose_kernel<<<dim3(1 + C_ORDER_WGS + C_ZERO_WGS, K), CBLOCK, 0, s>>>(b);
-    merge_kernel<<<dim3((subtiles + CBLOCK / 64 - 1) / (CBLOCK / 64), K), CBLOCK, 0, s>>>(b);
+    merge_kernel<<<dim3((subtiles + MBLOCK / 64 - 1) / (MBLOCK / 64), K), MBLOCK, 0, s>>>(b);
     return hipGetLastError();
 }
 
