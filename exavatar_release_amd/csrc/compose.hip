@@ -113,6 +113,8 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         const int lo = min(subtiles, part * per), hi = min(subtiles, lo + per);
         if (tid < ORDER_CLASSES) { s_all[tid] = 0u; s_before[tid] = 0u; s_rank[tid] = 0u; }
         __syncthreads();
+        // (empty sub-tiles are the majority of an avatar view: they are counted per wave -- one LDS atomic for all of them --
+        //  instead of thousands of atomics on the one counter of class 0)
         for (int st0 = 0; st0 < subtiles; st0 += CBLOCK * 4) {
             uint32_t n4[4];
 #pragma unroll
@@ -123,10 +125,17 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int st = st0 + i * CBLOCK + tid;
-                if (st >= subtiles) continue;
+                const bool valid = st < subtiles;
                 const int cls = length_class(n4[i]);
-                atomicAdd(&s_all[cls], 1u);
-                if (st < lo) atomicAdd(&s_before[cls], 1u);
+                const unsigned long long e_all = __ballot(valid && cls == 0), e_bef = __ballot(valid && cls == 0 && st < lo);
+                if (valid && cls) {
+                    atomicAdd(&s_all[cls], 1u);
+                    if (st < lo) atomicAdd(&s_before[cls], 1u);
+                }
+                if (lane == 0) {
+                    if (e_all) atomicAdd(&s_all[0], (uint32_t)__popcll(e_all));
+                    if (e_bef) atomicAdd(&s_before[0], (uint32_t)__popcll(e_bef));
+                }
             }
         }
         __syncthreads();
@@ -142,13 +151,24 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
             s_off[cls] = incl - v + s_before[cls];
         }
         __syncthreads();
-        // ranks inside the share in sub-tile order would need a scan per class; the order INSIDE a class does not matter
-        // (same length class), so LDS atomics hand the slots out
-        for (int st = lo + tid; st < hi; st += CBLOCK) {
-            const uint32_t n = src_overflow ? 0u : length(st);
+        // the order INSIDE a class does not matter (same length class): LDS atomics hand the slots out, one per wave for the
+        // empty sub-tiles
+        for (int st0 = lo; st0 < hi; st0 += CBLOCK) {
+            const int st = st0 + tid;
+            const bool valid = st < hi;
+            const uint32_t n = valid && !src_overflow ? length(st) : 0u;
             const int cls = length_class(n);
-            const uint32_t r = atomicAdd(&s_rank[cls], 1u);
-            a.tw.slots[s_off[cls] + r] = make_uint4(0u, n, (uint32_t)st, 0u);     // (the blend reads its range from tw.ranges[st])
+            const unsigned long long empty = __ballot(valid && cls == 0);
+            uint32_t r = 0;
+            if (valid && cls) r = atomicAdd(&s_rank[cls], 1u);
+            if (empty) {
+                const int leader = __ffsll((long long)empty) - 1;
+                uint32_t b0 = 0;
+                if (lane == leader) b0 = atomicAdd(&s_rank[0], (uint32_t)__popcll(empty));
+                b0 = (uint32_t)__shfl((int)b0, leader, 64);
+                if (valid && cls == 0) r = b0 + (uint32_t)__popcll(empty & ((1ull << lane) - 1ull));
+            }
+            if (valid) a.tw.slots[s_off[cls] + r] = make_uint4(0u, n, (uint32_t)st, 0u);     // (the blend reads its range from tw.ranges[st])
         }
         return;
     }

@@ -49,6 +49,7 @@ can only be recorded -- the capacity memo grows -- and warned about).
 import ctypes
 import time
 import warnings
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -270,7 +271,7 @@ class _Report:
 
 class _Pending:
     """One capacity-mode call whose reports have not all been consumed: enough to re-render an overflowed job."""
-    __slots__ = ('jobs', 'reports', 'store_ctx', 'device', 'done', 'backward_done')
+    __slots__ = ('jobs', 'reports', 'store_ctx', 'device', 'done', 'backward_done', '__weakref__')
 
 
 def _record_overflow(key, need, cap, how):
@@ -613,8 +614,10 @@ class _Rasterize(torch.autograd.Function):
                     rec.jobs, rec.reports, rec.store_ctx, rec.device = jobs, reports, need_ctx, device
                     rec.done = rec.backward_done = False
                     _pending.append(rec)
-                    for j in jobs:
-                        j.rec = rec
+                    if keep_keys:                 # (weak: rec.jobs -> job -> rec would be a cycle that keeps ~100 MB of
+                        wr = weakref.ref(rec)     #  workspaces alive until the cyclic collector runs)
+                        for j in jobs:
+                            j.rec = wr
 
         if config.keep_debug:
             j = jobs[-1]
@@ -863,7 +866,7 @@ class _Compose(torch.autograd.Function):
             redo = False
             for c in cjobs:
                 for j in (c.a, c.b):
-                    rec = j.rec
+                    rec = j.rec() if j.rec is not None else None
                     if rec is not None and not rec.done:
                         block = config.overflow_check == 'always' or config.fixed_capacity is not None or \
                             _verified.get(j.key, 0) < config.verify_calls or _seen_D.get(j.key, 0) > config.danger_fill * j.capacity
