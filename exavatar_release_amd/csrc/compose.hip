@@ -8,10 +8,10 @@
 // are the sources' records, and the depth-sorted list of a sub-tile is the merge of the sources' two sorted lists (order of
 // the concatenated render: ascending depth bits, ties by index -- every A (scene) index precedes every B (human) index, so A
 // wins ties).  Two small launches replace five:
-//   compose_kernel   block 0: list lengths nA + nB -> 64-aligned ranges of the composite's own instance space, header;
-//                    blocks 1..16: length-sorted launch order of the blend (per-class bases from a second histogram over the
-//                    sub-tiles in front of the block's share: no atomics, nothing to zero); remaining blocks: zero-fill of the
-//                    composite's owner / blended-mask / touched arrays
+//   compose_kernel   block 0 (one workgroup sweeps every sub-tile twice, all loads of a thread in flight at once): list
+//                    lengths nA + nB -> histogram of the length classes -> 64-aligned ranges of the composite's own instance
+//                    space, header, and the length-sorted launch order of the blend (wave-aggregated LDS atomics); the other
+//                    blocks zero-fill the composite's owner / blended-mask / touched arrays
 //   merge_kernel     one wave per sub-tile: 64 candidates of each source per trip (sorted 64-bit keys, kept by the sources'
 //                    sort: RenderFwdArgs.keep_sorted_keys), each candidate's output position = its own index + its rank in
 //                    the other window (binary search in LDS: lower bound for A, upper bound for B), ids written with the
@@ -25,158 +25,139 @@ namespace exa {
 
 constexpr int CBLOCK = 1024;             // compose_kernel (one workgroup scans every sub-tile: all loads of a thread in flight at once)
 constexpr int MBLOCK = 256;              // merge_kernel: four independent waves
-constexpr int C_ORDER_WGS = 16;
 constexpr int C_ZERO_WGS = 32;
 constexpr int C_PER = 16;                // sub-tiles per thread and trip of the scan
 
 __device__ __forceinline__ uint32_t list_slots(uint32_t n) { return n ? (n + BATCH - 1) / BATCH + 1 : 0u; }   // batches + end slot
 
+// Add `n` ones to LDS counter c[cls] for every lane with `valid`, ONE atomic per distinct class of the wave (the lists of a
+// view fall into a handful of length classes: per-lane atomics on those few counters serialise); returns this lane's rank
+// inside the counter (only meaningful when WANT_RANK).
+template <bool WANT_RANK>
+__device__ __forceinline__ uint32_t wave_class_add(uint32_t* c, int cls, bool valid, int lane) {
+    uint32_t rank = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {                                               // wave-uniform loop
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(cls, leader, 64);
+        const unsigned long long m = __ballot(valid && cls == k);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&c[k], (uint32_t)__popcll(m));
+        if (WANT_RANK) {
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (valid && cls == k) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        }
+        todo &= ~m;
+    }
+    return rank;
+}
+
 __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batch) {
     __shared__ uint32_t s_wave[CBLOCK / 64];
-    __shared__ uint32_t s_all[ORDER_CLASSES], s_before[ORDER_CLASSES], s_off[ORDER_CLASSES], s_rank[ORDER_CLASSES];
+    __shared__ uint32_t s_all[ORDER_CLASSES], s_off[ORDER_CLASSES], s_rank[ORDER_CLASSES];
     const ComposeArgs& a = batch.v[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int subtiles = a.grid.subtiles;
+    if (blockIdx.x > 0) {
+        // ---- zero-filled section of the composite's workspace: owners (merge_kernel), blended masks (render_fwd), touched (render_bwd)
+        const size_t n16 = compose_zero_bytes(a.capacity, a.capacity_b) / 16;
+        uint4* p = a.bw.owner;
+        const size_t first = (size_t)((int)blockIdx.x - 1) * CBLOCK + tid, stride = (size_t)C_ZERO_WGS * CBLOCK;
+        for (size_t i = first; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const uint2* __restrict__ ra = a.tw_a.ranges;
     const uint2* __restrict__ rb = a.tw_b.ranges;
     const bool src_overflow = a.tw_a.header->overflow != 0u || a.tw_b.header->overflow != 0u;
-    auto length = [&](int st) -> uint32_t {
-        const uint2 x = ra[st], y = rb[st];
-        return (x.y - x.x) + (y.y - y.x);
+    auto lengths = [&](int lo, uint32_t (&len)[C_PER]) {         // 32 independent loads per thread, issued together
+        uint2 x[C_PER], y[C_PER];
+#pragma unroll
+        for (int i = 0; i < C_PER; ++i) {
+            const int st = min(lo + i, subtiles - 1);
+            x[i] = ra[st]; y[i] = rb[st];
+        }
+#pragma unroll
+        for (int i = 0; i < C_PER; ++i) len[i] = (lo + i < subtiles && !src_overflow) ? (x[i].y - x[i].x) + (y[i].y - y[i].x) : 0u;
     };
-    if (blockIdx.x == 0) {
-        // ---- ranges: exclusive prefix of the slot counts over the sub-tiles (cell-major order, like the sources) ----------
-        // thread t owns sub-tiles [trip * 1024 * 16 + t * 16, + 16): its 32 range loads are independent and issued together
-        uint32_t carry = 0;
-        bool overflow = src_overflow;
-        for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
-            const int lo = trip0 + tid * C_PER;
-            uint32_t len[C_PER];
-#pragma unroll
-            for (int i = 0; i < C_PER; ++i) len[i] = lo + i < subtiles ? length(lo + i) : 0u;
-            uint32_t mine = 0;
-#pragma unroll
-            for (int i = 0; i < C_PER; ++i) mine += list_slots(len[i]);
-            uint32_t incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            __syncthreads();                                     // (s_wave of the previous trip has been read)
-            if (lane == 63) s_wave[wave] = incl;
-            __syncthreads();
-            uint32_t base = carry + incl - mine, total = 0;
-            for (int i = 0; i < CBLOCK / 64; ++i) {
-                if (i < wave) base += s_wave[i];
-                total += s_wave[i];
-            }
-            carry += total;
-            // (an overflow can only come from the sources -- capacity = capacity_a + capacity_b always suffices -- or from a
-            //  caller that passed less; the latter is latched below and every range of the later trips stays valid but unused)
-            uint32_t run = base;
-#pragma unroll
-            for (int i = 0; i < C_PER; ++i) {
-                if (lo + i < subtiles)
-                    a.tw.ranges[lo + i] = overflow ? make_uint2(0u, 0u) : make_uint2(run * BATCH, run * BATCH + len[i]);
-                run += list_slots(len[i]);
-            }
-        }
-        const uint32_t total = carry;
-        if ((uint64_t)total * BATCH > a.capacity && !overflow) {
-            // the composite's own buffer is too small (never with capacity_a + capacity_b): empty every list again
-            overflow = true;
-            __syncthreads();
-            for (int st = tid; st < subtiles; st += CBLOCK) a.tw.ranges[st] = make_uint2(0u, 0u);
-        }
-        if (tid == 0) {
-            ExaRasterHeader* h = a.tw.header;
-            h->num_rendered = total * BATCH; h->overflow = overflow ? 1u : 0u; h->max_tile_list = 0u;
-            h->num_visible = a.tw_a.header->num_visible + a.tw_b.header->num_visible;
-            h->num_instances = a.tw_a.header->num_instances + a.tw_b.header->num_instances;
-            h->active_cells = 0u;
-            h->num_tile_instances = a.tw_a.header->num_tile_instances + a.tw_b.header->num_tile_instances;
-            if (a.host_hdr) {
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u v = {total * BATCH, overflow ? 1u : 0u, h->num_visible, a.hdr_tag};
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a.host_hdr), "v"(v) : "memory");
-            }
-        }
-        return;
+    if (tid < ORDER_CLASSES) { s_all[tid] = 0u; s_rank[tid] = 0u; }
+    __syncthreads();
+    // ---- sweep 1: histogram of the list-length classes (launch order of the blend, common.h) ------------------------------
+    // thread t owns sub-tiles [trip * 1024 * 16 + t * 16, + 16)
+    for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
+        const int lo = trip0 + tid * C_PER;
+        uint32_t len[C_PER];
+        lengths(lo, len);
+#pragma unroll 1
+        for (int i = 0; i < C_PER; ++i) wave_class_add<false>(s_all, length_class(len[i]), lo + i < subtiles, lane);
     }
-    if ((int)blockIdx.x <= C_ORDER_WGS) {
-        // ---- launch order of the blend: sub-tiles by descending list length class, empty ones last (common.h) ---------------
-        // Every ordering block histograms ALL sub-tiles and, separately, those in front of its own share: its first record of
-        // every class lands at (class offset) + (records of that class before its share) -- no cursor, no atomics across blocks.
-        const int part = (int)blockIdx.x - 1;
-        const int per = (subtiles + C_ORDER_WGS - 1) / C_ORDER_WGS;
-        const int lo = min(subtiles, part * per), hi = min(subtiles, lo + per);
-        if (tid < ORDER_CLASSES) { s_all[tid] = 0u; s_before[tid] = 0u; s_rank[tid] = 0u; }
-        __syncthreads();
-        // (empty sub-tiles are the majority of an avatar view: they are counted per wave -- one LDS atomic for all of them --
-        //  instead of thousands of atomics on the one counter of class 0)
-        for (int st0 = 0; st0 < subtiles; st0 += CBLOCK * 4) {
-            uint32_t n4[4];
+    __syncthreads();
+    if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
+        const int cls = tid == 63 ? 0 : 63 - tid;
+        const uint32_t v = s_all[cls];
+        uint32_t incl = v;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int st = st0 + i * CBLOCK + tid;
-                n4[i] = st < subtiles && !src_overflow ? length(st) : 0u;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int st = st0 + i * CBLOCK + tid;
-                const bool valid = st < subtiles;
-                const int cls = length_class(n4[i]);
-                const unsigned long long e_all = __ballot(valid && cls == 0), e_bef = __ballot(valid && cls == 0 && st < lo);
-                if (valid && cls) {
-                    atomicAdd(&s_all[cls], 1u);
-                    if (st < lo) atomicAdd(&s_before[cls], 1u);
-                }
-                if (lane == 0) {
-                    if (e_all) atomicAdd(&s_all[0], (uint32_t)__popcll(e_all));
-                    if (e_bef) atomicAdd(&s_before[0], (uint32_t)__popcll(e_bef));
-                }
-            }
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
         }
-        __syncthreads();
-        if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
-            const int cls = tid == 63 ? 0 : 63 - tid;
-            const uint32_t v = s_all[cls];
-            uint32_t incl = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += o;
-            }
-            s_off[cls] = incl - v + s_before[cls];
-        }
-        __syncthreads();
-        // the order INSIDE a class does not matter (same length class): LDS atomics hand the slots out, one per wave for the
-        // empty sub-tiles
-        for (int st0 = lo; st0 < hi; st0 += CBLOCK) {
-            const int st = st0 + tid;
-            const bool valid = st < hi;
-            const uint32_t n = valid && !src_overflow ? length(st) : 0u;
-            const int cls = length_class(n);
-            const unsigned long long empty = __ballot(valid && cls == 0);
-            uint32_t r = 0;
-            if (valid && cls) r = atomicAdd(&s_rank[cls], 1u);
-            if (empty) {
-                const int leader = __ffsll((long long)empty) - 1;
-                uint32_t b0 = 0;
-                if (lane == leader) b0 = atomicAdd(&s_rank[0], (uint32_t)__popcll(empty));
-                b0 = (uint32_t)__shfl((int)b0, leader, 64);
-                if (valid && cls == 0) r = b0 + (uint32_t)__popcll(empty & ((1ull << lane) - 1ull));
-            }
-            if (valid) a.tw.slots[s_off[cls] + r] = make_uint4(0u, n, (uint32_t)st, 0u);     // (the blend reads its range from tw.ranges[st])
-        }
-        return;
+        s_off[cls] = incl - v;
     }
-    {   // ---- zero-filled section of the composite's workspace: owners (merge_kernel), blended masks (render_fwd), touched (render_bwd)
-        const size_t n16 = compose_zero_bytes(a.capacity, a.capacity_b) / 16;
-        uint4* p = a.bw.owner;
-        const size_t first = (size_t)((int)blockIdx.x - 1 - C_ORDER_WGS) * CBLOCK + tid, stride = (size_t)C_ZERO_WGS * CBLOCK;
-        for (size_t i = first; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // ---- sweep 2: 64-aligned ranges (exclusive prefix of the slot counts, cell-major order like the sources) + launch records
+    uint32_t carry = 0;
+    for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
+        const int lo = trip0 + tid * C_PER;
+        uint32_t len[C_PER];
+        lengths(lo, len);
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < C_PER; ++i) mine += list_slots(len[i]);
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        __syncthreads();                                         // (s_wave of the previous trip has been read)
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t base = carry + incl - mine, total = 0;
+        for (int i = 0; i < CBLOCK / 64; ++i) {
+            if (i < wave) base += s_wave[i];
+            total += s_wave[i];
+        }
+        carry += total;
+        uint32_t run = base;
+#pragma unroll 1
+        for (int i = 0; i < C_PER; ++i) {
+            const bool valid = lo + i < subtiles;
+            if (valid) a.tw.ranges[lo + i] = make_uint2(run * BATCH, run * BATCH + len[i]);
+            run += list_slots(len[i]);
+            const int cls = length_class(len[i]);
+            const uint32_t r = wave_class_add<true>(s_rank, cls, valid, lane);
+            if (valid) a.tw.slots[s_off[cls] + r] = make_uint4(0u, len[i], (uint32_t)(lo + i), 0u);   // (the blend reads tw.ranges[st])
+        }
+    }
+    const uint32_t total = carry;
+    // an overflow can only come from the sources (their lists are empty then: every length above is 0) or from a caller that
+    // passed less than capacity_a + capacity_b: empty every list again
+    const bool overflow = src_overflow || (uint64_t)total * BATCH > a.capacity;
+    if (overflow && !src_overflow) {
+        __syncthreads();
+        for (int st = tid; st < subtiles; st += CBLOCK) a.tw.ranges[st] = make_uint2(0u, 0u);
+    }
+    if (tid == 0) {
+        ExaRasterHeader* h = a.tw.header;
+        h->num_rendered = total * BATCH; h->overflow = overflow ? 1u : 0u; h->max_tile_list = 0u;
+        h->num_visible = a.tw_a.header->num_visible + a.tw_b.header->num_visible;
+        h->num_instances = a.tw_a.header->num_instances + a.tw_b.header->num_instances;
+        h->active_cells = 0u;
+        h->num_tile_instances = a.tw_a.header->num_tile_instances + a.tw_b.header->num_tile_instances;
+        if (a.host_hdr) {
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const v4u v = {total * BATCH, overflow ? 1u : 0u, h->num_visible, a.hdr_tag};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(a.host_hdr), "v"(v) : "memory");
+        }
     }
 }
 
@@ -233,7 +214,7 @@ hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s) {
     for (int k = 0; k < K; ++k) subtiles = subtiles > a[k].grid.subtiles ? subtiles : a[k].grid.subtiles;
     if (subtiles == 0) return hipSuccess;
     const Batch<ComposeArgs> b = make_batch(a, K);
-    compose_kernel<<<dim3(1 + C_ORDER_WGS + C_ZERO_WGS, K), CBLOCK, 0, s>>>(b);
+    compose_kernel<<<dim3(1 + C_ZERO_WGS, K), CBLOCK, 0, s>>>(b);
     merge_kernel<<<dim3((subtiles + MBLOCK / 64 - 1) / (MBLOCK / 64), K), MBLOCK, 0, s>>>(b);
     return hipGetLastError();
 }
