@@ -8,10 +8,9 @@
 // are the sources' records, and the depth-sorted list of a sub-tile is the merge of the sources' two sorted lists (order of
 // the concatenated render: ascending depth bits, ties by index -- every A (scene) index precedes every B (human) index, so A
 // wins ties).  Two small launches replace five:
-//   compose_kernel   block 0 (one workgroup sweeps every sub-tile twice, all loads of a thread in flight at once): list
-//                    lengths nA + nB -> histogram of the length classes -> 64-aligned ranges of the composite's own instance
-//                    space, header, and the length-sorted launch order of the blend (wave-aggregated LDS atomics); the other
-//                    blocks zero-fill the composite's owner / blended-mask / touched arrays
+//   compose_kernel   block 0 (one workgroup, all range loads of a thread in flight at once): list lengths nA + nB -> 64-aligned
+//                    ranges of the composite's own instance space, header; the other blocks zero-fill the composite's owner /
+//                    blended-mask / touched arrays and copy the launch order of the blend from the heavier source
 //   merge_kernel     one wave per sub-tile: 64 candidates of each source per trip (sorted 64-bit keys, kept by the sources'
 //                    sort: RenderFwdArgs.keep_sorted_keys), each candidate's output position = its own index + its rank in
 //                    the other window (binary search in LDS: lower bound for A, upper bound for B), ids written with the
@@ -30,31 +29,8 @@ constexpr int C_PER = 16;                // sub-tiles per thread and trip of the
 
 __device__ __forceinline__ uint32_t list_slots(uint32_t n) { return n ? (n + BATCH - 1) / BATCH + 1 : 0u; }   // batches + end slot
 
-// Add `n` ones to LDS counter c[cls] for every lane with `valid`, ONE atomic per distinct class of the wave (the lists of a
-// view fall into a handful of length classes: per-lane atomics on those few counters serialise); returns this lane's rank
-// inside the counter (only meaningful when WANT_RANK).
-template <bool WANT_RANK>
-__device__ __forceinline__ uint32_t wave_class_add(uint32_t* c, int cls, bool valid, int lane) {
-    uint32_t rank = 0;
-    unsigned long long todo = __ballot(valid);
-    while (todo) {                                               // wave-uniform loop
-        const int leader = __ffsll((long long)todo) - 1;
-        const int k = __shfl(cls, leader, 64);
-        const unsigned long long m = __ballot(valid && cls == k);
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&c[k], (uint32_t)__popcll(m));
-        if (WANT_RANK) {
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (valid && cls == k) rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        }
-        todo &= ~m;
-    }
-    return rank;
-}
-
 __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batch) {
     __shared__ uint32_t s_wave[CBLOCK / 64];
-    __shared__ uint32_t s_all[ORDER_CLASSES], s_off[ORDER_CLASSES], s_rank[ORDER_CLASSES];
     const ComposeArgs& a = batch.v[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int subtiles = a.grid.subtiles;
@@ -64,54 +40,35 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         uint4* p = a.bw.owner;
         const size_t first = (size_t)((int)blockIdx.x - 1) * CBLOCK + tid, stride = (size_t)C_ZERO_WGS * CBLOCK;
         for (size_t i = first; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        // ---- launch order of the blend (heavy lists first, common.h): the order of the source with more instances.  In
+        // ExAvatar's composites that is the scene, whose lists dominate the merged ones; a histogram of the exact merged
+        // lengths cost a 27-88 us single-workgroup pass (two variants measured) for a launch that queues ~16 waves per SIMD
+        // anyway.  The records carry the sub-tile only: the blend reads its range from tw.ranges.
+        const uint4* __restrict__ src = a.tw_a.header->num_instances >= a.tw_b.header->num_instances ? a.tw_a.slots : a.tw_b.slots;
+        for (size_t i = first; i < (size_t)subtiles; i += stride) a.tw.slots[i] = make_uint4(0u, 0u, src[i].z, 0u);
         return;
     }
     const uint2* __restrict__ ra = a.tw_a.ranges;
     const uint2* __restrict__ rb = a.tw_b.ranges;
     const bool src_overflow = a.tw_a.header->overflow != 0u || a.tw_b.header->overflow != 0u;
-    auto lengths = [&](int lo, uint32_t (&len)[C_PER]) {         // 32 independent loads per thread, issued together
+    // ---- 64-aligned ranges: exclusive prefix of the slot counts over the sub-tiles (cell-major order, like the sources) ------
+    // thread t owns sub-tiles [trip * 1024 * 16 + t * 16, + 16): its 32 range loads are independent and issued together
+    uint32_t carry = 0;
+    for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
+        const int lo = trip0 + tid * C_PER;
         uint2 x[C_PER], y[C_PER];
+        uint32_t len[C_PER];
 #pragma unroll
         for (int i = 0; i < C_PER; ++i) {
             const int st = min(lo + i, subtiles - 1);
             x[i] = ra[st]; y[i] = rb[st];
         }
-#pragma unroll
-        for (int i = 0; i < C_PER; ++i) len[i] = (lo + i < subtiles && !src_overflow) ? (x[i].y - x[i].x) + (y[i].y - y[i].x) : 0u;
-    };
-    if (tid < ORDER_CLASSES) { s_all[tid] = 0u; s_rank[tid] = 0u; }
-    __syncthreads();
-    // ---- sweep 1: histogram of the list-length classes (launch order of the blend, common.h) ------------------------------
-    // thread t owns sub-tiles [trip * 1024 * 16 + t * 16, + 16)
-    for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
-        const int lo = trip0 + tid * C_PER;
-        uint32_t len[C_PER];
-        lengths(lo, len);
-#pragma unroll 1
-        for (int i = 0; i < C_PER; ++i) wave_class_add<false>(s_all, length_class(len[i]), lo + i < subtiles, lane);
-    }
-    __syncthreads();
-    if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
-        const int cls = tid == 63 ? 0 : 63 - tid;
-        const uint32_t v = s_all[cls];
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        s_off[cls] = incl - v;
-    }
-    __syncthreads();
-    // ---- sweep 2: 64-aligned ranges (exclusive prefix of the slot counts, cell-major order like the sources) + launch records
-    uint32_t carry = 0;
-    for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
-        const int lo = trip0 + tid * C_PER;
-        uint32_t len[C_PER];
-        lengths(lo, len);
         uint32_t mine = 0;
 #pragma unroll
-        for (int i = 0; i < C_PER; ++i) mine += list_slots(len[i]);
+        for (int i = 0; i < C_PER; ++i) {
+            len[i] = (lo + i < subtiles && !src_overflow) ? (x[i].y - x[i].x) + (y[i].y - y[i].x) : 0u;
+            mine += list_slots(len[i]);
+        }
         uint32_t incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -128,14 +85,10 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         }
         carry += total;
         uint32_t run = base;
-#pragma unroll 1
+#pragma unroll
         for (int i = 0; i < C_PER; ++i) {
-            const bool valid = lo + i < subtiles;
-            if (valid) a.tw.ranges[lo + i] = make_uint2(run * BATCH, run * BATCH + len[i]);
+            if (lo + i < subtiles) a.tw.ranges[lo + i] = make_uint2(run * BATCH, run * BATCH + len[i]);
             run += list_slots(len[i]);
-            const int cls = length_class(len[i]);
-            const uint32_t r = wave_class_add<true>(s_rank, cls, valid, lane);
-            if (valid) a.tw.slots[s_off[cls] + r] = make_uint4(0u, len[i], (uint32_t)(lo + i), 0u);   // (the blend reads tw.ranges[st])
         }
     }
     const uint32_t total = carry;
