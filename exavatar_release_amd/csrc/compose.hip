@@ -52,44 +52,61 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
     const uint2* __restrict__ rb = a.tw_b.ranges;
     const bool src_overflow = a.tw_a.header->overflow != 0u || a.tw_b.header->overflow != 0u;
     // ---- 64-aligned ranges: exclusive prefix of the slot counts over the sub-tiles (cell-major order, like the sources) ------
-    // thread t owns sub-tiles [trip * 1024 * 16 + t * 16, + 16): its 32 range loads are independent and issued together
+    // A wave takes whole CELLS (lane = sub-tile of the cell: 512-byte coalesced loads and stores; a thread-major split of the
+    // sub-tiles touched 64 cache lines per load instruction and cost 25 us on this one CU): per trip 16 waves x 16 cells, the
+    // cells' totals meet in LDS, one wave scans them, every wave writes its cells' ranges.
+    __shared__ uint32_t s_cell[CBLOCK / 64 * C_PER];
+    const int cells = subtiles / SUBS_PER_CELL;
     uint32_t carry = 0;
-    for (int trip0 = 0; trip0 < subtiles; trip0 += CBLOCK * C_PER) {
-        const int lo = trip0 + tid * C_PER;
+    for (int cell0 = 0; cell0 < cells; cell0 += CBLOCK / 64 * C_PER) {
+        uint32_t len[C_PER], excl[C_PER];
         uint2 x[C_PER], y[C_PER];
-        uint32_t len[C_PER];
 #pragma unroll
         for (int i = 0; i < C_PER; ++i) {
-            const int st = min(lo + i, subtiles - 1);
+            const int st = min(cell0 + wave * C_PER + i, cells - 1) * SUBS_PER_CELL + lane;
             x[i] = ra[st]; y[i] = rb[st];
         }
-        uint32_t mine = 0;
 #pragma unroll
         for (int i = 0; i < C_PER; ++i) {
-            len[i] = (lo + i < subtiles && !src_overflow) ? (x[i].y - x[i].x) + (y[i].y - y[i].x) : 0u;
-            mine += list_slots(len[i]);
-        }
-        uint32_t incl = mine;
+            const bool valid = cell0 + wave * C_PER + i < cells && !src_overflow;
+            len[i] = valid ? (x[i].y - x[i].x) + (y[i].y - y[i].x) : 0u;
+            const uint32_t ns = list_slots(len[i]);
+            uint32_t incl = ns;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            excl[i] = incl - ns;
+            if (lane == 63) s_cell[wave * C_PER + i] = incl;
         }
-        __syncthreads();                                         // (s_wave of the previous trip has been read)
-        if (lane == 63) s_wave[wave] = incl;
         __syncthreads();
-        uint32_t base = carry + incl - mine, total = 0;
-        for (int i = 0; i < CBLOCK / 64; ++i) {
-            if (i < wave) base += s_wave[i];
-            total += s_wave[i];
+        if (wave == 0) {                                         // exclusive prefix of the 256 cell totals of this trip
+            uint32_t v[4], sum = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { v[q] = s_cell[lane * 4 + q]; sum += v[q]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += o;
+            }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { s_cell[lane * 4 + q] = run; run += v[q]; }
+            if (lane == 63) s_wave[0] = incl;                    // total of the trip
         }
-        carry += total;
-        uint32_t run = base;
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < C_PER; ++i) {
-            if (lo + i < subtiles) a.tw.ranges[lo + i] = make_uint2(run * BATCH, run * BATCH + len[i]);
-            run += list_slots(len[i]);
+            const int cell = cell0 + wave * C_PER + i;
+            if (cell < cells) {
+                const uint32_t begin = (carry + s_cell[wave * C_PER + i] + excl[i]) * BATCH;
+                a.tw.ranges[cell * SUBS_PER_CELL + lane] = make_uint2(begin, begin + len[i]);
+            }
         }
+        carry += s_wave[0];
+        __syncthreads();                                         // (s_cell / s_wave are rewritten by the next trip)
     }
     const uint32_t total = carry;
     // an overflow can only come from the sources (their lists are empty then: every length above is 0) or from a caller that
