@@ -379,7 +379,9 @@ __global__ __launch_bounds__(SBLOCK) void sort_short_kernel(Batch<RenderFwdArgs>
                          s_buf + wave * 64, lane);
 }
 
-template <bool SPLIT>
+// KEEP = true: merge source of a composite render (compose.hip): the sorted 64-bit keys replace the unsorted ones, in place.
+// Its own instantiation: as a run-time flag the extra stores cost the headline sort 1.4 us of 15.1 on C3.
+template <bool SPLIT, bool KEEP>
 __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
     __shared__ uint32_t s_cnt[SORT_TILE];                        // bucket counters / starts of the distribution sort
@@ -408,8 +410,7 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     if (n == 0) return;
     unsigned long long* gkeys = a.bw.keys + range.x;
     uint32_t* sorted = a.bw.sorted + range.x;
-    // merge source of a composite render (compose): the sorted 64-bit keys replace the unsorted ones, in place
-    unsigned long long* keys_out = a.keep_sorted_keys ? gkeys : nullptr;
+    unsigned long long* const keys_out = KEEP ? gkeys : nullptr;
     if (n <= 64) {
         if (!SPLIT && tid < 64) wave_rank_sort64(gkeys, n, sorted, keys_out, s_buf, tid);      // (SPLIT: sort_short_kernel did it)
         return;
@@ -610,11 +611,16 @@ hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
     static const int split_at = [] { const char* e = getenv("EXA_SORT_SPLIT_SUBTILES"); return e ? atoi(e) : SPLIT_SORT_SUBTILES; }();
+    bool keep = false;                   // (all jobs of a call share the flag: the binding sets it per call)
+    for (int k = 0; k < K; ++k) keep = keep || a[k].keep_sorted_keys != 0;
+    const dim3 grid(subtiles + ORDER_WGS, K);
     if (subtiles >= split_at) {
         sort_short_kernel<<<dim3((subtiles + SBLOCK / 64 - 1) / (SBLOCK / 64), K), SBLOCK, 0, s>>>(make_batch(a, K));
-        sort_subtiles_kernel<true><<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
+        if (keep) sort_subtiles_kernel<true, true><<<grid, SBLOCK, 0, s>>>(make_batch(a, K));
+        else sort_subtiles_kernel<true, false><<<grid, SBLOCK, 0, s>>>(make_batch(a, K));
     } else {
-        sort_subtiles_kernel<false><<<dim3(subtiles + ORDER_WGS, K), SBLOCK, 0, s>>>(make_batch(a, K));
+        if (keep) sort_subtiles_kernel<false, true><<<grid, SBLOCK, 0, s>>>(make_batch(a, K));
+        else sort_subtiles_kernel<false, false><<<grid, SBLOCK, 0, s>>>(make_batch(a, K));
     }
     return hipGetLastError();
 }
