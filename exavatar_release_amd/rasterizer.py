@@ -623,6 +623,7 @@ class _Rasterize(torch.autograd.Function):
             j = jobs[-1]
             _debug_last['tile'] = j.ws[j.gb:j.gb + j.tb]
             _debug_last['geom'] = j.ws[:j.gb]
+            _debug_last['bin'] = j.bins if getattr(j, 'bins', None) is not None else j.ws[j.gb + j.tb:]
             _debug_last['capacity'] = j.capacity
         if keep_keys:
             _last_handles = jobs
