@@ -426,7 +426,7 @@ constexpr int SINGLE_PART_CELLS = 1024;   // from this many cells on (2048 x 204
 // An avatar's instances sit in a few dozen cells, and both halves of this digit -- LDS counting atomics and the
 // scattered 8-byte key stores, one per instance -- are throughput limits of ONE CU.  Every cell is therefore
 // handled by BIN_PARTS workgroups in two launches:
-//   subtile_count_kernel  part p counts its quarter of the cell's entries per sub-tile -> part_cnt[rank of the cell][p][64]
+//   subtile_count_kernel  part p counts its quarter of the cell's entries per sub-tile -> part_cnt[cell][p][64]
 //   subtile_bin_kernel    reads the cell's BIN_PARTS x 64 counts (totals -> 64-aligned ranges; earlier parts ->
 //                         its own first slot in every sub-tile) and scatters its quarter of the keys.
 // Plain stores and a kernel boundary instead of any cross-workgroup atomics; part 0 publishes ranges and owners.
@@ -434,6 +434,12 @@ constexpr int SINGLE_PART_CELLS = 1024;   // from this many cells on (2048 x 204
 //  every part counting the whole cell itself.  Bitwise the same lists, but slower: the mask work is Gaussian-major there,
 //  one thread walks ALL cells of its splat -- C3 cell_scatter 18.4 -> 22.8 us for 19.7 -> 16.8 us here, C5 (scene splats
 //  over hundreds of cells) 20.7 -> 76 us.  Entry-parallel masks in their own launch stay.)
+// (Round 3 also tried to fuse the scatter below with the SORT of the lists (commit 10d6018, removed again): one 512-thread
+//  workgroup per row of eight sub-tiles scans the cell's entries, keeps the keys of its row in LDS and every wave sorts one
+//  list.  The keys never touch HBM and one launch goes, but it is slower -- count 11.6 + fused 30 us against bin 19.6 +
+//  sort 18.3 us: the dense rows make their CUs instruction-issue bound (eight-fold scan, eight lists per CU) while this
+//  version spreads the same work over the chip.  Keeping several entries in flight per thread changes nothing in any of
+//  these loops either: they are not load-latency bound.)
 struct CellPart { int cell, part; uint32_t e0, e1, lo, hi, slot0; bool overflow, active; };
 template <int PARTS>
 __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * PARTS
@@ -456,10 +462,11 @@ __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity
 
 // The sub-tiles of its cell (origin csx0, csy0 in sub-tiles) that the footprint of entry `en` = {id, depth, rect x, rect y}
 // really reaches, as a 64-bit mask (bit = y * 8 + x).  It replaces the rect in the entry; the scatter walks the same bits.
-// (r0, r1 = the first 32 bytes of the splat's record; zeros = no test, the whole rect)
-constexpr int COUNT_U = 4;
 template <bool FOOTPRINT>
-__device__ __forceinline__ unsigned long long entry_mask(const uint4& r0, const uint4& r1, const uint4& en, int csx0, int csy0) {
+__device__ __forceinline__ unsigned long long entry_mask(const Splat* __restrict__ splats, const uint4& en, int csx0, int csy0) {
+    const uint4* rec = reinterpret_cast<const uint4*>(splats + en.x);
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;              // (A = 0: no test, the whole rect)
+    if (FOOTPRINT) { r0 = rec[0]; r1 = rec[1]; }
     const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
     const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
     const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
@@ -499,37 +506,14 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
     const int csx0 = (cp.cell % g.cx) * CELL_SUBS, csy0 = (cp.cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
-    // Entries and splat records were written on other XCDs one and two launches ago: every load is a trip to HBM, and the
-    // two dependent ones per entry, one entry at a time, were the duration of this kernel.  COUNT_U entries in flight.
-    for (uint32_t e0 = cp.lo + tid; e0 < cp.hi; e0 += BIN_THREADS * COUNT_U) {
-        uint4 en[COUNT_U], r0[COUNT_U], r1[COUNT_U];
-#pragma unroll
-        for (int u = 0; u < COUNT_U; ++u) {
-            const uint32_t e = e0 + u * BIN_THREADS;
-            en[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (e < cp.hi) en[u] = b.bucket[e];
-        }
-#pragma unroll
-        for (int u = 0; u < COUNT_U; ++u) {
-            r0[u] = r1[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (FOOTPRINT && e0 + u * BIN_THREADS < cp.hi) {
-                const uint4* rec = reinterpret_cast<const uint4*>(a.splats + en[u].x);
-                r0[u] = rec[0]; r1[u] = rec[1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < COUNT_U; ++u) {
-            const uint32_t e = e0 + u * BIN_THREADS;
-            if (e < cp.hi) {
-                const unsigned long long mask = entry_mask<FOOTPRINT>(r0[u], r1[u], en[u], csx0, csy0);
-                for (unsigned long long m = mask; m; m &= m - 1)
-                    __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
-            }
-        }
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        for (unsigned long long m = mask; m; m &= m - 1)
+            __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
     }
     __syncthreads();
-    if (tid < SUBS_PER_CELL) w.part_cnt[(size_t)blockIdx.x * SUBS_PER_CELL + tid] = s_cnt[tid];     // by RANK of the cell in cell_desc
+    if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
 }
 
 template <int PARTS>
@@ -552,7 +536,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         uint32_t n = 0, before = 0;
 #pragma unroll
         for (int p = 0; p < PARTS; ++p) {
-            const uint32_t v = w.part_cnt[((size_t)(blockIdx.x / PARTS) * PARTS + p) * SUBS_PER_CELL + tid];
+            const uint32_t v = w.part_cnt[((size_t)cell * PARTS + p) * SUBS_PER_CELL + tid];
             before += p < cp.part ? v : 0u;
             n += v;
         }
@@ -570,22 +554,13 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         }
     }
     __syncthreads();
-    for (uint32_t e0 = cp.lo + tid; e0 < cp.hi; e0 += BIN_THREADS * COUNT_U) {
-        uint4 ens[COUNT_U];                                      // (several entries in flight, see subtile_count_kernel)
-#pragma unroll
-        for (int u = 0; u < COUNT_U; ++u) {
-            ens[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (e0 + u * BIN_THREADS < cp.hi) ens[u] = b.bucket[e0 + u * BIN_THREADS];
-        }
-#pragma unroll
-        for (int u = 0; u < COUNT_U; ++u) {
-            const uint4 en = ens[u];
-            const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
-            for (unsigned long long m = ((unsigned long long)en.w << 32) | en.z; m; m &= m - 1) {
-                const int s = __builtin_ctzll(m);
-                const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                b.keys[s_off[s] + r] = key;
-            }
+    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
+        const uint4 en = b.bucket[e];
+        const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
+        for (unsigned long long m = ((unsigned long long)en.w << 32) | en.z; m; m &= m - 1) {
+            const int s = __builtin_ctzll(m);
+            const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            b.keys[s_off[s] + r] = key;
         }
     }
 }
@@ -611,10 +586,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
     __syncthreads();
     const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
-        const uint4 en = b.bucket[e];
-        uint4 r0 = make_uint4(0u, 0u, 0u, 0u), r1 = r0;
-        if (FOOTPRINT) { const uint4* rec = reinterpret_cast<const uint4*>(a.splats + en.x); r0 = rec[0]; r1 = rec[1]; }
-        const unsigned long long mask = entry_mask<FOOTPRINT>(r0, r1, en, csx0, csy0);
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
         for (unsigned long long m = mask; m; m &= m - 1)
             __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));   // read back by this thread
@@ -689,8 +661,7 @@ hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
     } else {
         if (footprint) subtile_count_kernel<true, BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
         else subtile_count_kernel<false, BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
-        // (the scatter of the keys is fused with their sort in the next launch: binsort_kernel, render_fwd.hip)
-        if (!use_fused_binsort(cells)) subtile_bin_kernel<BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
+        subtile_bin_kernel<BIN_PARTS><<<dim3(cells * BIN_PARTS, K), BIN_THREADS, 0, s>>>(b);
     }
     return hipGetLastError();
 }

@@ -282,7 +282,6 @@ struct RenderFwdArgs {
     const Splat* splats2;      // composite: records of source B (ids with SRC_B); `splats` = source A
 };
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s);
-bool use_fused_binsort(int cells);      // render_fwd.hip: scatter + sort of the sub-tile lists in one launch (binsort_kernel)
 // Composite of two finished renders (compose.hip): ranges / header / launch order / zero-fill, then the merged id lists
 struct ComposeArgs {
     Grid grid;

@@ -359,97 +359,6 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
     }
 }
 
-// The same for the fused launch (binsort_kernel), where the ranges do not exist yet.  It walks the cells by their RANK in
-// cell_desc: only the first `active` hold lists, their lengths come from the counts of the previous launch
-// (`len_of(rank, sub-tile)`, any thread) and the ranges of the workgroup's own share of ranks from a wave per cell
-// (`cell_ranges(rank, first slot, n, begin)`, lane = sub-tile).  Any number of whole waves.
-template <typename LenOf, typename CellRanges>
-__device__ __forceinline__ void order_slots_cells(const TileWs& w, int cells, int active, int part, int tid, LenOf len_of,
-                                                  CellRanges cell_ranges) {
-    __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
-    const int lane = tid & 63, wave = tid >> 6, threads = (int)blockDim.x, waves = threads >> 6;
-    if (tid < ORDER_CLASSES) s_cnt[tid] = tid == 0 ? (uint32_t)(cells - active) * SUBS_PER_CELL : 0u;
-    __syncthreads();
-    const int total = active * SUBS_PER_CELL;
-    for (int base = 0; base < total; base += threads * 8) {
-        uint32_t n[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = base + i * threads + tid;
-            n[i] = idx < total ? len_of(idx >> 6, idx & 63) : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int cls = length_class(n[i]);
-            const unsigned long long empty = __ballot(base + i * threads + tid < total && cls == 0);
-            if (cls) atomicAdd(&s_cnt[cls], 1u);
-            else if (empty && lane == __ffsll((long long)empty) - 1) atomicAdd(&s_cnt[0], (uint32_t)__popcll(empty));
-        }
-    }
-    __syncthreads();
-    if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
-        const int cls = tid == 63 ? 0 : 63 - tid;
-        uint32_t v = s_cnt[cls], incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        s_off[cls] = incl - v;
-        s_cnt[cls] = 0u;
-    }
-    __syncthreads();
-    const int per = (cells + ORDER_WGS - 1) / ORDER_WGS;
-    const int lo = part * per, hi = min(cells, lo + per);
-    for (int base = lo; base < hi; base += waves * 2) {
-        uint2 r[2];
-        uint32_t rank[2], st[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rk = base + i * waves + wave;              // wave-uniform
-            uint32_t n = 0, begin = 0;
-            st[i] = 0u;
-            if (rk < hi) {
-                const uint4 d = w.cell_desc[rk];
-                st[i] = d.x * SUBS_PER_CELL + (uint32_t)lane;
-                if (rk < active) cell_ranges(rk, d.w, n, begin);
-            }
-            r[i] = make_uint2(begin, begin + n);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool valid = base + i * waves + wave < hi;
-            const int cls = length_class(r[i].y - r[i].x);
-            const unsigned long long empty = __ballot(valid && cls == 0);
-            rank[i] = 0;
-            if (cls) rank[i] = atomicAdd(&s_cnt[cls], 1u);
-            else if (empty) {
-                const int leader = __ffsll((long long)empty) - 1;
-                uint32_t b0 = 0;
-                if (lane == leader) b0 = atomicAdd(&s_cnt[0], (uint32_t)__popcll(empty));
-                b0 = (uint32_t)__shfl((int)b0, leader, 64);
-                rank[i] = b0 + (uint32_t)__popcll(empty & ((1ull << lane) - 1ull));
-            }
-        }
-        __syncthreads();
-        if (tid < ORDER_CLASSES) {
-            const uint32_t c = s_cnt[tid];
-            s_base[tid] = s_off[tid] + (c ? atomicAdd(&w.cls_cur[tid], c) : 0u);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (base + i * waves + wave < hi) {
-                const int cls = length_class(r[i].y - r[i].x);
-                w.slots[s_base[cls] + rank[i]] = make_uint4(r[i].x, r[i].y, st[i], 0u);
-            }
-        }
-        __syncthreads();
-        if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
-        __syncthreads();
-    }
-}
-
 // Short lists of a LARGE image (>= SPLIT_SORT_SUBTILES sub-tiles, e.g. 2048 x 2048 px): one wave per sub-tile, four
 // independent sub-tiles per workgroup, 512 B of LDS per wave.  With content everywhere (C5: a background scene behind the
 // avatar) most of the 65 536 lists hold a few dozen keys, and one 256-thread workgroup with 24 KiB of LDS per list -- six
@@ -534,406 +443,6 @@ __global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdAr
     __syncthreads();
     if (tid == 0) a.tw.part_cnt[st] = (uint32_t)(__builtin_readcyclecounter() - t0);      // probe build only
 #endif
-}
-
-// ---- fused sub-tile scatter + sort (round 3) ---------------------------------------------------------------
-// One launch instead of two (subtile_bin_kernel + sort_subtiles_kernel) for images whose cells are split over several
-// workgroups (fewer than SINGLE_PART_CELLS cells: C2 / C3): the sort keys never travel through HBM.  One 512-thread
-// workgroup per ROW of eight sub-tiles of a cell (eight per cell): it derives the 64-aligned ranges of the whole cell from
-// the part_cnt matrix subtile_count_kernel left behind (publishing those of its own row, with their batch owners), scans
-// ALL entries of the cell for mask bits of its row and drops the keys into LDS grouped by sub-tile (one LDS atomic per wave
-// and trip: eight lanes reserve for the eight lists), then wave j sorts the list of sub-tile j on its own -- a wave-level
-// distribution sort, up to 16 keys per lane in registers, buckets in LDS, no workgroup barrier -- and writes the sorted ids.
-// Lists of more than 1024 keys are sorted by the whole workgroup afterwards, rows that do not fit the LDS go through the key
-// array in HBM like before.  The launch order of the blend comes from extra workgroups of the same launch that recompute
-// the ranges from part_cnt, so nothing in the launch reads what another workgroup of it writes.
-constexpr int BS_THREADS = 512, BS_WAVES = BS_THREADS / 64, BS_ROWS = CELL_SUBS;
-constexpr int BS_CAP = 6144;          // keys of a row that fit the LDS (48 KiB, + 26 KiB of bucket counters: two rows per CU)
-constexpr int BS_WAVE_E = 16;         // keys per lane of the longest list one wave sorts alone
-constexpr int BS_WAVE_MAX = 64 * BS_WAVE_E;
-constexpr int BS_BLOCK_E = BS_CAP / BS_THREADS;
-
-// Distribution sort of n <= T E keys that sit in LDS at K, by T threads (T = 64: one wave on its own, barriers are wave
-// fences; T = BS_THREADS: the workgroup).  One bucket per key on average (nq T buckets, nq = ceil(n / T) <= E, counters C),
-// uniform in the depth range of the list; every thread keeps its keys in registers, ranks them inside their buckets -- all
-// its keys at once, so the LDS latency is paid once per step and not once per key -- and writes the sorted ids (and keys).
-// Returns false, with K untouched, when the depths pile up in one bucket (> BUCKET_MAX keys).
-template <int E, int T>
-__device__ __forceinline__ bool bucket_sort_lds(unsigned long long* K, int n, uint32_t* C, uint32_t* s_misc,
-                                                uint32_t* __restrict__ sorted, unsigned long long* keys_out, int t) {
-    constexpr bool WAVE = T == 64;
-    const int lane = t & 63, wave = t >> 6;
-    const int nq = (n + T - 1) / T, NB = nq * T;
-    auto barrier = [&] { if (WAVE) wave_lds_fence(); else __syncthreads(); };
-    unsigned long long key[E];
-    uint32_t dmin = 0xffffffffu, dmax = 0u;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int i = e * T + t;
-        key[e] = i < n ? K[i] : ~0ull;
-        if (i < n) {
-            const uint32_t d = (uint32_t)(key[e] >> 32);
-            dmin = min(dmin, d); dmax = max(dmax, d);
-        }
-        if (e < nq) C[i] = 0u;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        dmin = min(dmin, (uint32_t)__shfl_xor((int)dmin, d, 64));
-        dmax = max(dmax, (uint32_t)__shfl_xor((int)dmax, d, 64));
-    }
-    if (!WAVE) {
-        if (lane == 0) { s_misc[wave] = dmin; s_misc[8 + wave] = dmax; }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < T / 64; ++w) { dmin = min(dmin, s_misc[w]); dmax = max(dmax, s_misc[8 + w]); }
-    } else {
-        wave_lds_fence();
-    }
-    const float fmin = __uint_as_float(dmin);
-    const float scale = (float)(NB - 1) / fmaxf(__uint_as_float(dmax) - fmin, 1e-30f);
-    uint32_t bkt[E], slot[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        bkt[e] = 0u; slot[e] = 0u;
-        if (e * T + t < n) {
-            const float f = (__uint_as_float((uint32_t)(key[e] >> 32)) - fmin) * scale;
-            bkt[e] = (uint32_t)min(NB - 1, (int)f);
-            slot[e] = __hip_atomic_fetch_add(&C[bkt[e]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    barrier();
-    uint32_t c[E], sum = 0u, mx = 0u;                            // thread t owns the nq buckets [t nq, (t + 1) nq)
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        c[e] = e < nq ? C[t * nq + e] : 0u;
-        sum += c[e]; mx = max(mx, c[e]);
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += o;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, d, 64));
-    uint32_t run = incl - sum;
-    if (!WAVE) {
-        if (lane == 63) s_misc[16 + wave] = incl;
-        if (lane == 0) s_misc[24 + wave] = mx;
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < T / 64; ++w) {
-            mx = max(mx, s_misc[24 + w]);
-            run += w < wave ? s_misc[16 + w] : 0u;
-        }
-    }
-    if (mx > (uint32_t)BUCKET_MAX) return false;                 // uniform over the T threads; K as it was
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (e < nq) { C[t * nq + e] = run; run += c[e]; }
-    barrier();
-    uint32_t s0[E], len[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        s0[e] = 0u; len[e] = 0u;
-        if (e * T + t < n) {
-            s0[e] = C[bkt[e]];
-            len[e] = (bkt[e] + 1u < (uint32_t)NB ? C[bkt[e] + 1u] : (uint32_t)n) - s0[e];
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e)
-        if (e * T + t < n) K[s0[e] + slot[e]] = key[e];
-    barrier();
-    uint32_t longest = 0u;
-#pragma unroll
-    for (int e = 0; e < E; ++e) longest = max(longest, len[e]);
-    uint32_t rank[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) rank[e] = s0[e];
-    for (uint32_t j = 0; j < longest; ++j) {
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-            if (j < len[e]) rank[e] += K[s0[e] + j] < key[e] ? 1u : 0u;
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (e * T + t < n) {
-            sorted[rank[e]] = (uint32_t)key[e];
-            if (keys_out) keys_out[rank[e]] = key[e];
-        }
-    }
-    return true;
-}
-
-// Rank sort of n <= T E keys in LDS by T threads: exact for any key distribution, O(n^2 / T).  K is only read.
-template <int E, int T>
-__device__ __forceinline__ void rank_sort_lds(const unsigned long long* K, int n, uint32_t* __restrict__ sorted,
-                                              unsigned long long* keys_out, int t) {
-    unsigned long long key[E];
-    uint32_t rank[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) { key[e] = e * T + t < n ? K[e * T + t] : ~0ull; rank[e] = 0u; }
-    for (int j = 0; j < n; ++j) {
-        const unsigned long long kk = K[j];                      // uniform address: broadcast
-#pragma unroll
-        for (int e = 0; e < E; ++e) rank[e] += kk < key[e] ? 1u : 0u;
-    }
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (e * T + t < n) {
-            sorted[rank[e]] = (uint32_t)key[e];
-            if (keys_out) keys_out[rank[e]] = key[e];
-        }
-    }
-}
-
-template <int E>
-__device__ __forceinline__ void wave_sort_e(unsigned long long* K, int n, uint32_t* C, uint32_t* sorted,
-                                            unsigned long long* keys_out, int lane) {
-    if (bucket_sort_lds<E, 64>(K, n, C, nullptr, sorted, keys_out, lane)) return;
-    wave_lds_fence();
-    rank_sort_lds<E, 64>(K, n, sorted, keys_out, lane);
-}
-__device__ __forceinline__ void wave_sort_lds(unsigned long long* K, int n, uint32_t* C, uint32_t* sorted,
-                                              unsigned long long* keys_out, int lane) {       // n <= BS_WAVE_MAX, wave-uniform
-    if (n <= 64) rank_sort_lds<1, 64>(K, n, sorted, keys_out, lane);
-    else if (n <= 128) wave_sort_e<2>(K, n, C, sorted, keys_out, lane);
-    else if (n <= 256) wave_sort_e<4>(K, n, C, sorted, keys_out, lane);
-    else if (n <= 512) wave_sort_e<8>(K, n, C, sorted, keys_out, lane);
-    else wave_sort_e<BS_WAVE_E>(K, n, C, sorted, keys_out, lane);
-}
-__device__ __forceinline__ void block_sort_lds(unsigned long long* K, int n, uint32_t* C, uint32_t* s_misc, uint32_t* sorted,
-                                               unsigned long long* keys_out, int tid) {       // n <= BS_CAP, workgroup-uniform
-    bool done;
-    if (n <= 4 * BS_THREADS) done = bucket_sort_lds<4, BS_THREADS>(K, n, C, s_misc, sorted, keys_out, tid);
-    else done = bucket_sort_lds<BS_BLOCK_E, BS_THREADS>(K, n, C, s_misc, sorted, keys_out, tid);
-    if (!done) {
-        if (n <= 4 * BS_THREADS) rank_sort_lds<4, BS_THREADS>(K, n, sorted, keys_out, tid);
-        else rank_sort_lds<BS_BLOCK_E, BS_THREADS>(K, n, sorted, keys_out, tid);
-    }
-    __syncthreads();
-}
-
-// Lists that do not even fit the LDS alone: every thread ranks its keys against the whole list, read from HBM / L2 in tiles.
-__device__ __forceinline__ void block_rank_sort_global(const unsigned long long* gkeys, int n, uint32_t* __restrict__ sorted,
-                                                       unsigned long long* s_tile, int tid) {
-    for (int first = 0; first < n; first += BS_THREADS * 4) {
-        unsigned long long mine[4];
-        uint32_t rank[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = first + r * BS_THREADS + tid;
-            mine[r] = i < n ? gkeys[i] : ~0ull;
-            rank[r] = 0u;
-        }
-        for (int tile = 0; tile < n; tile += BS_CAP) {
-            const int tn = min(BS_CAP, n - tile);
-            __syncthreads();
-            for (int i = tid; i < tn; i += BS_THREADS) s_tile[i] = gkeys[tile + i];
-            __syncthreads();
-            for (int j = 0; j < tn; ++j) {
-                const unsigned long long kk = s_tile[j];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) rank[r] += kk < mine[r] ? 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (first + r * BS_THREADS + tid < n) sorted[rank[r]] = (uint32_t)mine[r];
-    }
-    __syncthreads();
-}
-
-template <bool KEEP>
-__global__ __launch_bounds__(BS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void binsort_kernel(Batch<RenderFwdArgs> batch) {
-    __shared__ __attribute__((aligned(16))) unsigned long long s_keys[BS_CAP];
-    __shared__ uint32_t s_cntb[BS_CAP + BS_ROWS * 64];
-    __shared__ uint32_t s_n[SUBS_PER_CELL], s_begin[SUBS_PER_CELL];
-    __shared__ uint32_t s_loff[BS_ROWS + 1], s_coff[BS_ROWS], s_fill[BS_ROWS], s_misc[32];
-    const RenderFwdArgs& a = batch.v[blockIdx.y];
-    const TileWs& w = a.tw;
-    const BinWs& b = a.bw;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cells = a.grid.cells;
-    if ((int)blockIdx.x >= cells * BS_ROWS + ORDER_WGS) return;  // a job with a smaller image than the largest of the batch
-#ifdef EXA_PROBE_SORT        // probe build only: cycles of the phases of every workgroup, at the unused end of the key array
-    uint32_t* const probe = reinterpret_cast<uint32_t*>(b.keys + a.capacity) - 4 * (blockIdx.x + 1);
-    const unsigned long long t0 = __builtin_readcyclecounter();
-#define BS_PROBE(i) do { __syncthreads(); if (tid == 0) probe[i] = (uint32_t)(__builtin_readcyclecounter() - t0); } while (0)
-#else
-#define BS_PROBE(i) do { } while (0)
-#endif
-    // header, cell record and counts are independent loads (part_cnt is indexed by the cell's RANK in cell_desc): one trip
-    const int wg = (int)blockIdx.x - ORDER_WGS, rank = wg >= 0 ? wg / BS_ROWS : 0, row = wg >= 0 ? wg % BS_ROWS : 0;
-    const uint32_t need = w.header->num_rendered, active = w.header->active_cells;
-    const bool overflow = (uint64_t)need > a.capacity;
-    // ranges of the 64 sub-tiles of the cell at `rk` from the counts of the previous launch: lane = sub-tile, all 64 lanes
-    auto cell_ranges = [&](int rk, uint32_t slot0, uint32_t& n, uint32_t& begin) {
-        n = 0;
-#pragma unroll
-        for (int p = 0; p < BIN_PARTS; ++p) n += w.part_cnt[((size_t)rk * BIN_PARTS + p) * SUBS_PER_CELL + lane];
-        if (overflow) n = 0;
-        const uint32_t nslot = n ? (n + BATCH - 1) / BATCH + 1 : 0u;        // real batches + one end slot
-        uint32_t incl = nslot;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        begin = overflow ? 0u : slot0 + (incl - nslot) * BATCH;
-    };
-    if (blockIdx.x < ORDER_WGS) {
-        order_slots_cells(w, cells, (int)(overflow ? 0u : active), (int)blockIdx.x, tid,
-            [&](int rk, int sub) -> uint32_t {
-                uint32_t n = 0;
-#pragma unroll
-                for (int p = 0; p < BIN_PARTS; ++p) n += w.part_cnt[((size_t)rk * BIN_PARTS + p) * SUBS_PER_CELL + sub];
-                return n;
-            },
-            [&](int rk, uint32_t slot0, uint32_t& n, uint32_t& begin) { cell_ranges(rk, slot0, n, begin); });
-        BS_PROBE(3);
-        return;
-    }
-    const uint4 d = w.cell_desc[rank];
-    if (blockIdx.x == ORDER_WGS && tid == 0 && overflow) w.header->overflow = 1u;
-    const int cell = (int)d.x;
-    if (rank >= (int)active) {                                   // empty cell: its row of empty ranges
-        if (tid < CELL_SUBS) w.ranges[cell * SUBS_PER_CELL + row * CELL_SUBS + tid] = make_uint2(0u, 0u);
-        if (row == 0 && tid == 0) w.cell_long[rank] = 0u;
-        return;
-    }
-    const uint32_t e0 = d.y, e1 = overflow ? d.y : d.z;
-    if (wave == 0) {
-        uint32_t n, begin;
-        cell_ranges(rank, d.w, n, begin);
-        s_n[lane] = n; s_begin[lane] = begin;
-        if ((lane >> 3) == row) {
-            w.ranges[cell * SUBS_PER_CELL + lane] = make_uint2(begin, begin + n);
-            for (uint32_t bq = 0; bq * BATCH < n; ++bq)
-                b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + lane) + 1u, begin, n, 0u);
-        }
-        if (row == 0) {
-            const unsigned long long longer = __ballot(n > (uint32_t)BATCH);
-            if (lane == 0) w.cell_long[rank] = (uint32_t)__popcll(longer);
-        }
-        // key and counter space of the row's eight lists (lanes row * 8 + j): exclusive prefixes over j
-        const uint32_t cw = n <= (uint32_t)BS_WAVE_MAX ? ((n + 63u) & ~63u) : 0u;
-        uint32_t kin = n, cin = cw;
-#pragma unroll
-        for (int dd = 1; dd < 8; dd <<= 1) {
-            const uint32_t ok = __shfl_up(kin, dd, 64), oc = __shfl_up(cin, dd, 64);
-            if ((lane & 7) >= dd) { kin += ok; cin += oc; }
-        }
-        if ((lane >> 3) == row) {
-            s_loff[lane & 7] = kin - n; s_coff[lane & 7] = cin - cw;
-            if ((lane & 7) == 7) s_loff[BS_ROWS] = kin;
-            s_fill[lane & 7] = 0u;
-        }
-    }
-    __syncthreads();
-    const uint32_t total = s_loff[BS_ROWS];
-    if (total == 0) return;
-    BS_PROBE(0);
-    const bool in_lds = total <= (uint32_t)BS_CAP;
-    // ---- scatter: the keys of this row's eight sub-tiles, grouped by sub-tile (LDS, or the key array in HBM) --------------
-    // Wave-aggregated: per trip a wave counts the lanes with bit j in eight ballots and lanes 0..7 reserve the eight runs
-    // with ONE LDS atomic instruction (as single atomics per key the eight counters serialised the whole workgroup).
-    {
-        uint32_t dst[BS_ROWS];                                   // first slot of list j: LDS index, or index into b.keys
-#pragma unroll
-        for (int j = 0; j < BS_ROWS; ++j) dst[j] = in_lds ? s_loff[j] : s_begin[row * CELL_SUBS + j];
-        // Eight entries per thread are requested before the first is used: the entries were written on other XCDs two
-        // launches ago, every load is a trip to HBM (~1 us), and with one in flight the scan of a heavy cell (13 trips of
-        // the workgroup) was half of the kernel.
-        constexpr int U = 8;
-        const uint32_t e1r = e0 + ((e1 - e0 + 63u) & ~63u);      // whole waves take every trip
-        for (uint32_t base = e0 + tid; base < e1r; base += BS_THREADS * U) {
-            uint4 ens[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t e = base + u * BS_THREADS;
-                ens[u] = make_uint4(0u, 0u, 0u, 0u);
-                if (e < e1) ens[u] = b.bucket[e];
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (base + u * BS_THREADS >= e1r) break;         // wave-uniform
-                const uint4 en = ens[u];
-                const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
-                const uint32_t m = (uint32_t)((((unsigned long long)en.w << 32) | en.z) >> (row * CELL_SUBS)) & 0xffu;
-                if (__ballot(m != 0u) == 0ull) continue;         // no key of this row among the wave's 64 entries
-                unsigned long long bal[BS_ROWS];
-                uint32_t mine = 0u;
-#pragma unroll
-                for (int j = 0; j < BS_ROWS; ++j) {
-                    bal[j] = __ballot((m >> j) & 1u);
-                    if (lane == j) mine = (uint32_t)__popcll(bal[j]);
-                }
-                uint32_t rbase = 0u;
-                if (lane < BS_ROWS && mine) rbase = __hip_atomic_fetch_add(&s_fill[lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-                for (int j = 0; j < BS_ROWS; ++j) {
-                    const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)rbase, j);
-                    if ((m >> j) & 1u) {
-                        const uint32_t at = dst[j] + bj + (uint32_t)__popcll(bal[j] & ((1ull << lane) - 1ull));
-                        if (in_lds) s_keys[at] = key;
-                        else b.keys[at] = key;
-                    }
-                }
-            }
-        }
-    }
-    if (!in_lds) __threadfence_block();
-    __syncthreads();
-    BS_PROBE(1);
-    if (in_lds) {
-        // ---- every wave its own list (up to 1024 keys) ... --------------------------------------------------------------
-        const int st_local = row * CELL_SUBS + wave;
-        const int n = (int)s_n[st_local];
-        if (n > 0 && n <= BS_WAVE_MAX) {
-            const uint32_t at = s_begin[st_local];
-            wave_sort_lds(s_keys + s_loff[wave], n, s_cntb + s_coff[wave], b.sorted + at, KEEP ? b.keys + at : nullptr, lane);
-        }
-        __syncthreads();
-        BS_PROBE(2);
-        // ---- ... and the longer ones by the whole workgroup, one after the other -----------------------------------------
-        for (int j = 0; j < BS_ROWS; ++j) {
-            const int nj = (int)s_n[row * CELL_SUBS + j];
-            if (nj > BS_WAVE_MAX) {
-                const uint32_t bj = s_begin[row * CELL_SUBS + j];
-                block_sort_lds(s_keys + s_loff[j], nj, s_cntb, s_misc, b.sorted + bj, KEEP ? b.keys + bj : nullptr, tid);
-            }
-        }
-        BS_PROBE(3);
-        return;
-    }
-    // ---- the row does not fit the LDS: its lists one after the other, staged from the key array --------------------------
-    for (int j = 0; j < BS_ROWS; ++j) {
-        const int nj = (int)s_n[row * CELL_SUBS + j];
-        if (nj == 0) continue;
-        const uint32_t bj = s_begin[row * CELL_SUBS + j];
-        unsigned long long* gk = b.keys + bj;
-        if (nj <= BS_CAP) {
-            __syncthreads();
-            for (int i = tid; i < nj; i += BS_THREADS) s_keys[i] = gk[i];
-            __syncthreads();
-            block_sort_lds(s_keys, nj, s_cntb, s_misc, b.sorted + bj, KEEP ? gk : nullptr, tid);
-        } else {
-            block_rank_sort_global(gk, nj, b.sorted + bj, s_keys, tid);
-            if (KEEP) {
-                __threadfence_block();
-                __syncthreads();
-                for (int i = tid; i < nj; i += BS_THREADS) {
-                    const uint32_t id = b.sorted[bj + i];
-                    gk[i] = ((unsigned long long)__float_as_uint(a.splats[id].depth) << 32) | id;
-                }
-                __syncthreads();
-            }
-        }
-    }
-    BS_PROBE(3);
 }
 
 // ---- blend ---------------------------------------------------------------------------------------------
@@ -1098,29 +607,9 @@ static int max_subtiles(const RenderFwdArgs* a, int K) {
     return n;
 }
 
-// The fused scatter + sort applies to the images whose cells the sub-tile binning splits over several workgroups (binning.hip:
-// fewer than SINGLE_PART_CELLS cells); EXA_FUSED_BINSORT=0 keeps the two launches (developer knob, A/B).
-bool use_fused_binsort(int cells) {
-    static const int on = [] { const char* e = getenv("EXA_FUSED_BINSORT"); return e ? atoi(e) : 0; }();   // measured slower: off
-    static const int single_cells = [] { const char* e = getenv("EXA_BIN_SINGLE_CELLS"); return e ? atoi(e) : 1024; }();
-    return on != 0 && cells > 0 && cells < single_cells;
-}
-
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
-    {
-        int cells = 0;
-        for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
-        if (use_fused_binsort(cells)) {
-            bool keep = false;
-            for (int k = 0; k < K; ++k) keep = keep || a[k].keep_sorted_keys != 0;
-            const dim3 grid(cells * BS_ROWS + ORDER_WGS, K);
-            if (keep) binsort_kernel<true><<<grid, BS_THREADS, 0, s>>>(make_batch(a, K));
-            else binsort_kernel<false><<<grid, BS_THREADS, 0, s>>>(make_batch(a, K));
-            return hipGetLastError();
-        }
-    }
     static const int split_at = [] { const char* e = getenv("EXA_SORT_SPLIT_SUBTILES"); return e ? atoi(e) : SPLIT_SORT_SUBTILES; }();
     bool keep = false;                   // (all jobs of a call share the flag: the binding sets it per call)
     for (int k = 0; k < K; ++k) keep = keep || a[k].keep_sorted_keys != 0;
