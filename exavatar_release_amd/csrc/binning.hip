@@ -289,20 +289,12 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     }
     uint32_t* s_base = s_dyn;
     uint32_t* s_cnt2 = s_dyn + cells;
-    if ((int)blockIdx.x >= a.chunks) {                          // a job with fewer Gaussians than the largest of the batch
-        if (a.merged && a.chunks == 0 && blockIdx.x == 0) {     // no Gaussians at all: nobody else writes the tile state
-            for (int c = tid; c <= cells; c += SC_BLOCK) w.cell_off[c] = make_uint2(0u, 0u);
-            for (int c = tid; c < cells; c += SC_BLOCK) w.cell_desc[c] = make_uint4((uint32_t)c, 0u, 0u, 0u);
-            if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
-            if (tid == 0) {
-                w.header->num_rendered = 0u; w.header->overflow = 0u; w.header->max_tile_list = 0u;
-                w.header->num_visible = 0u; w.header->num_instances = 0u; w.header->active_cells = 0u;
-                w.header->num_tile_instances = 0u;
-                if (a.host_hdr) report_header(a.host_hdr, 0u, 0u, 0u, a.hdr_tag);
-            }
-        } else if (!a.merged && a.chunks == 0 && blockIdx.x == 0 && tid == 0 && a.host_hdr) {
+    // Merged scans: the workgroup AFTER the job's last chunk has no Gaussians to scatter; it is the one that publishes what
+    // the later kernels read (cell_off, header, cell order), off the critical path of the scattering workgroups.
+    const bool publisher = a.merged && (int)blockIdx.x == a.chunks;
+    if ((int)blockIdx.x >= a.chunks && !publisher) {            // a job with fewer Gaussians than the largest of the batch
+        if (!a.merged && a.chunks == 0 && blockIdx.x == 0 && tid == 0 && a.host_hdr)
             report_header(a.host_hdr, w.header->num_rendered, 0u, 0u, a.hdr_tag);     // (cell_scan wrote the header)
-        }
         return;
     }
     uint32_t D, chunk_off;
@@ -344,7 +336,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
         uint32_t inst_total;
         const uint32_t cx = block_excl_scan(ci, s_tmp, inst_total);
         if (tid == (int)blockIdx.x) s_bcast[0] = cx;
-        if (blockIdx.x == 0) {
+        if (publisher) {
             if (tid < cells) w.cell_off[tid] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
             unsigned long long vt;                               // tiles << 32 | visible (both sums stay < 2^32)
             block_excl_scan64(tid < a.chunks ? ((unsigned long long)w.chunk_tiles[tid] << 32) | w.chunk_vis[tid] : 0ull, s_tmp64, vt);
@@ -362,10 +354,11 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
             if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
             __syncthreads();                                     // cell_off (all of it) visible to the whole workgroup
             write_cell_order(w, cells, [&](int c) { return (uint32_t)(s_tot[c] >> 32); });
+            return;
         }
         __syncthreads();
         chunk_off = s_bcast[0];
-        if ((uint64_t)D > capacity) return;                      // overflow latched in the header by workgroup 0
+        if ((uint64_t)D > capacity) return;                      // overflow latched in the header by the publisher
         for (int c = tid; c < cells; c += SC_BLOCK) s_cnt2[c] = 0u;
     } else {
         D = w.header->num_rendered;
@@ -636,11 +629,14 @@ hipError_t launch_cell_scan(const BinArgs* a, int K, hipStream_t s) {
 
 hipError_t launch_cell_scatter(const BinArgs* a, int K, hipStream_t s) {
     const Batch<BinArgs> b = make_batch(a, K);
-    int chunks = 1, cells = 0;                  // at least one workgroup per job: it also clears the zero-filled section
+    int chunks = 0, cells = 0;
     for (int k = 0; k < K; ++k) {
         chunks = max(chunks, a[k].chunks);
         cells = max(cells, a[k].grid.cells);
     }
+    // one workgroup past the last chunk: the publisher of the merged scans; without them at least one workgroup per job,
+    // which clears the zero-filled section
+    chunks = a[0].merged ? chunks + 1 : max(chunks, 1);
     cell_scatter_kernel<<<dim3(chunks, K), SC_BLOCK, (size_t)cells * (a[0].merged ? 24 : 8), s>>>(b);
     return hipGetLastError();
 }
