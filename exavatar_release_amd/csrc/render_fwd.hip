@@ -276,29 +276,38 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
 
 // ---- launch order of the forward blend (see length_class in common.h) ------------------------------------
 // Runs as the first ORDER_WGS workgroups of the sort launch, i.e. concurrently with the sorting and off the
-// critical path.  Every ordering workgroup histograms the list-length classes of ALL sub-tiles (128 KiB of
-// L2-resident ranges), then ranks its own share inside LDS, reserves one contiguous range per class with a
-// single device atomic, and writes the records.
+// critical path.  Every ordering workgroup histograms the list-length classes of the sub-tiles of all active cells,
+// then ranks its own share inside LDS, reserves one contiguous range per class with a single device atomic, and
+// writes the records.
 constexpr int ORDER_WGS = 16;
 template <typename RangeOf>       // RangeOf(st) -> [begin, end) of sub-tile st's list; the records hold what it returns
 __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int part, int tid, RangeOf range_of) {
     __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
     const int lane = tid & 63;
+    // Histogram over the sub-tiles of the ACTIVE cells only (cell_desc lists them first; an avatar view: 70 of 256): the
+    // others are empty, the empty class comes last in the order and its count enters no offset.  Sixteen loads per thread
+    // in flight -- these workgroups walked all ranges of the image in eight dependent trips and were the longest of the
+    // launch.
     if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
     __syncthreads();
-    for (int base = 0; base < subtiles; base += SBLOCK * 8) {
-        uint2 r[8];
+    const int counted = min(subtiles, (int)w.header->active_cells * SUBS_PER_CELL);
+    for (int base = 0; base < counted; base += SBLOCK * 16) {
+        uint32_t cell[16];
+        uint2 r[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int st = base + i * SBLOCK + tid;
-            r[i] = st < subtiles ? range_of(st) : make_uint2(0u, 0u);
+        for (int i = 0; i < 16; ++i) {
+            const int idx = base + i * SBLOCK + tid;
+            cell[i] = idx < counted ? w.cell_desc[idx >> 6].x : 0u;
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 16; ++i) {
+            const int idx = base + i * SBLOCK + tid;
+            r[i] = idx < counted ? range_of((int)cell[i] * SUBS_PER_CELL + (idx & 63)) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
             const int cls = length_class(r[i].y - r[i].x);
-            const unsigned long long empty = __ballot(base + i * SBLOCK + tid < subtiles && cls == 0);
             if (cls) atomicAdd(&s_cnt[cls], 1u);
-            else if (empty && lane == __ffsll((long long)empty) - 1) atomicAdd(&s_cnt[0], (uint32_t)__popcll(empty));
         }
     }
     __syncthreads();
