@@ -23,8 +23,11 @@ import torch.distributed as dist
 
 
 def shard_views(n_views: int, rank: int, world_size: int, epoch: int = 0, shuffle: bool = True,
-                seed: int = 0, pad: bool = True) -> List[int]:
+                seed: int = 0, pad: bool = True, order: Optional[Sequence[int]] = None) -> List[int]:
     """Views of this rank for ``epoch``: a seed-synchronised permutation dealt round-robin.
+
+    ``order`` (a permutation of ``range(n_views)``, the same on every rank) replaces the seeded shuffle, e.g. a
+    stratified order in which every short window of steps covers the camera ring evenly (``bench.py``).
 
     Every rank computes the same permutation (seed + epoch), so the shards cover all views.  With ``pad`` (default)
     every rank gets exactly ``ceil(n_views / world_size)`` views -- the permutation is extended by wrapping around,
@@ -33,7 +36,11 @@ def shard_views(n_views: int, rank: int, world_size: int, epoch: int = 0, shuffl
     deals the ``ceil`` / ``floor`` shares of a plain partition; the caller must then call
     :meth:`FlatGradAllReducer.start` with ``None`` gradients for the missing steps.
     """
-    if shuffle:
+    if order is not None:
+        order = [int(v) for v in order]
+        if sorted(order) != list(range(n_views)):
+            raise ValueError('shard_views: order must be a permutation of range(n_views)')
+    elif shuffle:
         g = torch.Generator().manual_seed(seed + epoch)
         order = torch.randperm(n_views, generator=g).tolist()
     else:

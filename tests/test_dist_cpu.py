@@ -23,6 +23,12 @@ def test_shard_views_partition_and_reshuffle():
     assert shard_views(200, 0, 8, epoch=0) != shard_views(200, 0, 8, epoch=1)
     assert shard_views(10, 1, 2, shuffle=False) == [1, 3, 5, 7, 9]
     assert shard_views(10, 2, 3, shuffle=False) == [2, 5, 8, 1] and shard_views(10, 2, 3, shuffle=False, pad=False) == [2, 5, 8]
+    # an explicit order (bench.py's stratified ring order) is dealt like the seeded permutation
+    order = [(i * 123) % 200 for i in range(200)]
+    dealt = [shard_views(200, r, 8, order=order) for r in range(8)]
+    assert sorted(v for s_ in dealt for v in s_) == list(range(200)) and dealt[3][:3] == [order[3], order[11], order[19]]
+    with pytest.raises(ValueError):
+        shard_views(4, 0, 2, order=[0, 1, 1, 3])
     # fewer views than ranks: the permutation is repeated, no rank is left with an empty shard (it would hang the others)
     assert [shard_views(1, r, 4, shuffle=False) for r in range(4)] == [[0]] * 4
     assert [len(shard_views(3, r, 8)) for r in range(8)] == [1] * 8
