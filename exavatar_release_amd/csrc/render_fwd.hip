@@ -291,13 +291,15 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
     if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
     __syncthreads();
     const int counted = min(subtiles, (int)w.header->active_cells * SUBS_PER_CELL);
+    const bool every = counted == subtiles;                     // content everywhere (C5): no indirection through cell_desc
     for (int base = 0; base < counted; base += SBLOCK * 16) {
         uint32_t cell[16];
         uint2 r[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int idx = base + i * SBLOCK + tid;
-            cell[i] = idx < counted ? w.cell_desc[idx >> 6].x : 0u;
+            cell[i] = (uint32_t)(idx >> 6);
+            if (!every && idx < counted) cell[i] = w.cell_desc[idx >> 6].x;
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
