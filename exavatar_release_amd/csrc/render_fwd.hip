@@ -280,34 +280,34 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
 // then ranks its own share inside LDS, reserves one contiguous range per class with a single device atomic, and
 // writes the records.
 constexpr int ORDER_WGS = 16;
+constexpr int ORDER_U = 8;       // ranges in flight per thread while counting (16 cost the KEEP sort 32 VGPRs = a wave per SIMD)
 template <typename RangeOf>       // RangeOf(st) -> [begin, end) of sub-tile st's list; the records hold what it returns
 __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int part, int tid, RangeOf range_of) {
     __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
     const int lane = tid & 63;
     // Histogram over the sub-tiles of the ACTIVE cells only (cell_desc lists them first; an avatar view: 70 of 256): the
-    // others are empty, the empty class comes last in the order and its count enters no offset.  Sixteen loads per thread
-    // in flight -- these workgroups walked all ranges of the image in eight dependent trips and were the longest of the
+    // others are empty, the empty class comes last in the order and its count enters no offset.  These workgroups walked all ranges of the image in eight dependent trips and were the longest of the
     // launch.
     if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
     __syncthreads();
     const int counted = min(subtiles, (int)w.header->active_cells * SUBS_PER_CELL);
     const bool every = counted == subtiles;                     // content everywhere (C5): no indirection through cell_desc
-    for (int base = 0; base < counted; base += SBLOCK * 16) {
-        uint32_t cell[16];
-        uint2 r[16];
+    for (int base = 0; base < counted; base += SBLOCK * ORDER_U) {
+        uint32_t cell[ORDER_U];
+        uint2 r[ORDER_U];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < ORDER_U; ++i) {
             const int idx = base + i * SBLOCK + tid;
             cell[i] = (uint32_t)(idx >> 6);
             if (!every && idx < counted) cell[i] = w.cell_desc[idx >> 6].x;
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < ORDER_U; ++i) {
             const int idx = base + i * SBLOCK + tid;
             r[i] = idx < counted ? range_of((int)cell[i] * SUBS_PER_CELL + (idx & 63)) : make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < ORDER_U; ++i) {
             const int cls = length_class(r[i].y - r[i].x);
             if (cls) atomicAdd(&s_cnt[cls], 1u);
         }
