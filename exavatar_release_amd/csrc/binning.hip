@@ -127,6 +127,45 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
 // header.active_cells counts the others.  One workgroup; `inst_of(c)` returns the instance count of cell c.  Every
 // record carries the cell's entry range and first instance slot (cell_off, already written to global memory by this
 // workgroup), so that the per-cell workgroups of the next kernels need ONE load instead of a chain of three.
+// ADAPTIVE split of the cells over the BIN_PARTS * cells workgroups of the two-launch sub-tile binning (subtile_count /
+// subtile_bin below): a cell gets one workgroup per `per` entries (per >= 1024: one trip of their entry loop), at most
+// MAX_PARTS, at least one (an empty cell's workgroup publishes its empty ranges); the workgroups beyond the sum find
+// NO_PART and leave.  With a fixed four parts per cell those launches lasted as long as the parts of the heaviest cells --
+// three trips, 8-10 us against 5 us for a one-trip part (workgroup timeline) -- while a cell of
+// fifty entries still occupied four workgroups; eight fixed parts gained 2.5 us, twelve nothing, sixteen lost 4 (the
+// dispatch of 4 096 mostly idle 1024-thread workgroups).  Deriving the mapping in every binning workgroup (cell records
+// + one block scan) cost more than the balance gained (+1.8 us): the table is written HERE, once, by the one workgroup
+// that has just written the cell records.  Cells by rank (heavy first), a cell's parts consecutive.
+constexpr int MAX_PARTS = 16;
+constexpr uint32_t NO_PART = 0xffffffffu;
+#ifndef EXA_PART_ENTRIES
+#define EXA_PART_ENTRIES 1024           // = BIN_THREADS: one trip of the entry loops (512 / 768 / 1536 / 2048: A/B below)
+#endif
+constexpr int PART_ENTRIES = EXA_PART_ENTRIES;
+__device__ __forceinline__ void write_part_table(const TileWs& w, int cells) {
+    __shared__ uint32_t s_ptmp[32];
+    const int tid = threadIdx.x, nthreads = (int)blockDim.x;
+    const int slots = cells * BIN_PARTS;
+    if (cells > nthreads || cells >= (1 << 12)) return;         // (images that large take the one-workgroup-per-cell kernel)
+    __threadfence_block();
+    __syncthreads();                                             // cell_desc complete (written by this workgroup)
+    const uint32_t entries = w.cell_off[cells].x;
+    // sum of the parts <= entries / per + cells <= BIN_PARTS * cells
+    const uint32_t denom = (uint32_t)((BIN_PARTS - 1) * cells);
+    const uint32_t per = max((uint32_t)PART_ENTRIES, (entries + denom - 1u) / denom);
+    const uint4 d = tid < cells ? w.cell_desc[tid] : make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t e = d.z - d.y;
+    const uint32_t mine = tid < cells ? min((uint32_t)MAX_PARTS, max(1u, (e + per - 1u) / per)) : 0u;
+    uint32_t total;
+    const uint32_t first = block_excl_scan(mine, s_ptmp, total);
+    const uint32_t share = mine ? (e + mine - 1u) / mine : 0u;
+    for (uint32_t p = 0; p < mine; ++p) {
+        const uint32_t lo = min(d.z, d.y + p * share), hi = min(d.z, lo + share);
+        w.part_desc[first + p] = make_uint4(d.x | ((uint32_t)tid << 12) | (p << 24) | ((mine - 1u) << 28), lo, hi, d.w);
+    }
+    for (int i = (int)total + tid; i < slots; i += nthreads) w.part_desc[i] = make_uint4(NO_PART, 0u, 0u, 0u);
+}
+
 template <typename F>
 __device__ __forceinline__ void write_cell_order(const TileWs& w, int cells, F inst_of) {
     __shared__ uint32_t s_bucket[34];
@@ -151,6 +190,7 @@ __device__ __forceinline__ void write_cell_order(const TileWs& w, int cells, F i
         const uint2 o0 = w.cell_off[c], o1 = w.cell_off[c + 1];
         w.cell_desc[atomicAdd(&s_bucket[n ? 32 - __clz(n) : 0], 1u)] = make_uint4((uint32_t)c, o0.x, o1.x, o0.y);
     }
+    write_part_table(w, cells);
 }
 
 __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> batch) {
@@ -433,7 +473,21 @@ constexpr int SINGLE_PART_CELLS = 1024;   // from this many cells on (2048 x 204
 //  sort 18.3 us: the dense rows make their CUs instruction-issue bound (eight-fold scan, eight lists per CU) while this
 //  version spreads the same work over the chip.  Keeping several entries in flight per thread changes nothing in any of
 //  these loops either: they are not load-latency bound.)
-struct CellPart { int cell, part; uint32_t e0, e1, lo, hi, slot0; bool overflow, active; };
+struct CellPart { int cell, part; uint32_t e0, e1, lo, hi, slot0; bool overflow, active; int rank, nparts; };
+// the work record of this workgroup from the table write_part_table left (ONE load, next to the header's); false: no work
+__device__ __forceinline__ bool cell_part_of(const TileWs& w, uint64_t capacity, CellPart& c) {
+    const uint4 d = w.part_desc[blockIdx.x];
+    const uint32_t need = w.header->num_rendered;
+    if (d.x == NO_PART) return false;
+    c.cell = (int)(d.x & 0xfffu); c.rank = (int)((d.x >> 12) & 0xfffu);
+    c.part = (int)((d.x >> 24) & 0xfu); c.nparts = (int)(d.x >> 28) + 1;
+    c.overflow = (uint64_t)need > capacity;
+    c.lo = d.y; c.hi = c.overflow ? d.y : d.z;
+    c.e0 = c.e1 = 0u;                                           // (only the one-workgroup-per-cell kernel uses them)
+    c.slot0 = d.w;
+    c.active = d.z > d.y || c.nparts > 1 || c.part > 0;          // a cell without entries has ONE part with an empty share
+    return true;
+}
 template <int PARTS>
 __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity) {   // blockIdx.x < cells * PARTS
     CellPart c;
@@ -443,6 +497,7 @@ __device__ __forceinline__ CellPart cell_part(const TileWs& w, uint64_t capacity
     c.cell = (int)d.x;
     c.part = (int)(blockIdx.x % PARTS);
     c.active = blockIdx.x / PARTS < active;
+    c.rank = (int)(blockIdx.x / PARTS); c.nparts = PARTS;
     c.overflow = (uint64_t)need > capacity;
     c.e0 = d.y;
     c.e1 = c.overflow ? d.y : d.z;
@@ -493,8 +548,8 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     if ((int)blockIdx.x >= g.cells * PARTS) return;
-    const CellPart cp = cell_part<PARTS>(w, a.capacity);
-    if (!cp.active) return;                                             // empty cell: nothing to count
+    CellPart cp;
+    if (!cell_part_of(w, a.capacity, cp) || !cp.active) return;         // no work / empty cell: nothing to count
     const int tid = threadIdx.x;
     if (tid < SUBS_PER_CELL) s_cnt[tid] = 0u;
     __syncthreads();
@@ -506,7 +561,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
         reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
     }
     __syncthreads();
-    if (tid < SUBS_PER_CELL) w.part_cnt[((size_t)cp.cell * PARTS + cp.part) * SUBS_PER_CELL + tid] = s_cnt[tid];
+    if (tid < SUBS_PER_CELL) w.part_cnt[(size_t)blockIdx.x * SUBS_PER_CELL + tid] = s_cnt[tid];       // by workgroup
 }
 
 template <int PARTS>
@@ -518,18 +573,20 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     const Grid& g = a.grid;
     const BinWs& b = a.bw;
     if ((int)blockIdx.x >= g.cells * PARTS) return;
-    const CellPart cp = cell_part<PARTS>(w, a.capacity);
-    if (!cp.active) {                                                   // empty cell: part 0 publishes 64 empty ranges
-        if (cp.part == 0 && threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
-        if (cp.part == 0 && threadIdx.x == 0) w.cell_long[blockIdx.x / PARTS] = 0u;
+    CellPart cp;
+    if (!cell_part_of(w, a.capacity, cp)) return;
+    if (!cp.active) {                                                   // empty cell: its one workgroup publishes 64 empty ranges
+        if (threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+        if (threadIdx.x == 0) w.cell_long[cp.rank] = 0u;
         return;
     }
     const int cell = cp.cell, tid = threadIdx.x;
     if (tid < 64) {
         uint32_t n = 0, before = 0;
-#pragma unroll
-        for (int p = 0; p < PARTS; ++p) {
-            const uint32_t v = w.part_cnt[((size_t)cell * PARTS + p) * SUBS_PER_CELL + tid];
+        const size_t first = (size_t)blockIdx.x - (size_t)cp.part;      // the cell's parts are consecutive workgroups
+#pragma unroll 4
+        for (int p = 0; p < cp.nparts; ++p) {
+            const uint32_t v = w.part_cnt[(first + p) * SUBS_PER_CELL + tid];
             before += p < cp.part ? v : 0u;
             n += v;
         }
@@ -540,7 +597,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         s_cnt2[tid] = 0u;
         if (cp.part == 0) {
             const unsigned long long longer = __ballot(n > (uint32_t)BATCH);
-            if (tid == 0) w.cell_long[blockIdx.x / PARTS] = (uint32_t)__popcll(longer);
+            if (tid == 0) w.cell_long[cp.rank] = (uint32_t)__popcll(longer);
             w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
             for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
                 b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
@@ -651,7 +708,7 @@ hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
     // workgroups (two launches) to get the chip busy; a large image (C5: 1024 cells, content everywhere) has enough
     // cells already and takes one workgroup per cell that counts and scatters in ONE launch.
     static const int single_cells = [] { const char* e = getenv("EXA_BIN_SINGLE_CELLS"); return e ? atoi(e) : SINGLE_PART_CELLS; }();
-    if (cells >= single_cells) {
+    if (cells >= single_cells || cells > 1024) {                  // (the part table maps one thread to one cell)
         if (footprint) subtile_count_bin_kernel<true><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
         else subtile_count_bin_kernel<false><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
     } else {

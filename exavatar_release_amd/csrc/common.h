@@ -118,14 +118,19 @@ struct TileWs {
                                       //              per-pixel-kernel workgroup everything it needs
     uint2* fwd_exit;                  // [subtiles]   {list length, batches the forward entered}
     uint32_t* cell_long;              // [cells]      by rank in cell_desc: number of the cell's lists longer than 64 keys
-    uint32_t* part_cnt;               // [cells][BIN_PARTS][64]  entries per sub-tile counted by each part of a cell
+    uint32_t* part_cnt;               // [cells * BIN_PARTS][64]  entries per sub-tile counted by each workgroup of the
+                                      //              two-launch sub-tile binning (a cell's parts are consecutive)
+    uint4* part_desc;                 // [cells * BIN_PARTS]  work record of every such workgroup: {cell | rank << 12 |
+                                      //              part << 24 | (parts - 1) << 28, first entry, end entry, first slot of the
+                                      //              cell}; x = NO_PART for the workgroups beyond the sum (binning.hip)
 };
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return HEADER_BYTES + align256(uint64_t(chunks) * cells * 8) + align256(uint64_t(cells) * 8) +
            align256(uint64_t(cells + 1) * 8) + 4 * align256(uint64_t(chunks + 1) * 4) +
            align256(uint64_t(cells) * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
-           align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4) + align256(uint64_t(cells) * 4);
+           align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4) + align256(uint64_t(cells) * 4) +
+           align256(uint64_t(cells) * BIN_PARTS * 16);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -145,7 +150,8 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.slots = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 16);
     w.fwd_exit = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.part_cnt = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4);
-    w.cell_long = reinterpret_cast<uint32_t*>(p);
+    w.cell_long = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
+    w.part_desc = reinterpret_cast<uint4*>(p);
     return w;
 }
 

@@ -14,7 +14,8 @@ def tile_offsets(P, W, H):
                        ('chunk_inst', (chunks + 1) * 4), ('chunk_vis', (chunks + 1) * 4), ('chunk_tiles', (chunks + 1) * 4),
                        ('chunk_off', (chunks + 1) * 4),
                        ('cell_desc', cells * 16), ('ranges', cells * SUBS * 8), ('slots', cells * SUBS * 16),
-                       ('fwd_exit', cells * SUBS * 8), ('part_cnt', cells * BIN_PARTS * SUBS * 4), ('cell_long', cells * 4)):
+                       ('fwd_exit', cells * SUBS * 8), ('part_cnt', cells * BIN_PARTS * SUBS * 4), ('cell_long', cells * 4),
+                       ('part_desc', cells * BIN_PARTS * 16)):
         out[name] = (off, size)
         off += a256(size)
     out['cells'], out['chunks'], out['total'] = cells, chunks, off
