@@ -139,7 +139,7 @@ __device__ __forceinline__ unsigned long long block_excl_scan64(unsigned long lo
 constexpr int MAX_PARTS = 16;
 constexpr uint32_t NO_PART = 0xffffffffu;
 #ifndef EXA_PART_ENTRIES
-#define EXA_PART_ENTRIES 1024           // = BIN_THREADS: one trip of the entry loops (512 / 768 / 1536 / 2048: A/B below)
+#define EXA_PART_ENTRIES 1024           // = BIN_THREADS: one trip of the entry loops (A/B on C3: 512 the same, 768 / 1536 +0.8-1 us)
 #endif
 constexpr int PART_ENTRIES = EXA_PART_ENTRIES;
 __device__ __forceinline__ void write_part_table(const TileWs& w, int cells) {
