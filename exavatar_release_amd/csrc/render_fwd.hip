@@ -467,9 +467,8 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
     const RenderFwdArgs& a = batch.v[blockIdx.y];
     if ((int)blockIdx.x >= a.grid.subtiles) return;
     const int lane = threadIdx.x;
-#ifdef EXA_PROBE_FWD
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    unsigned long long t_first = t0;
+#ifdef EXA_PROBE_FWD       // probe build only (tools/gpu_fwd_timeline.py): start / end of every wave on the chip-wide 100 MHz clock
+    const unsigned long long t0 = wall_clock64();
 #endif
     const uint4 slot = a.tw.slots[blockIdx.x];                  // {begin, end, st, 0}; empty range on overflow
     const SubTile sub = decode_subtile((int)slot.z, a.grid);
@@ -513,9 +512,6 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         }
         ++entered;
         stage_splat(s_b, lane, r0, r1, r2);
-#ifdef EXA_PROBE_FWD
-        if (base == 0) t_first = __builtin_readcyclecounter();
-#endif
         // issue the next batch's gathers and the ids of the batch after it; lanes past the end of the list
         // stage an all-zero record (opacity 0 -> alpha 0), so the blend below always runs whole groups of four
         {
@@ -597,12 +593,12 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
     if (STORE) {
         if (lane == 0) a.tw.fwd_exit[st] = make_uint2((uint32_t)n, (uint32_t)entered);
 #ifdef EXA_PROBE_FWD
-        if (lane == 0) {
-            a.tw.slots[blockIdx.x].w = (uint32_t)(__builtin_readcyclecounter() - t0);
+        if (lane == 0) {       // part_cnt is dead once the lists exist
+            a.tw.part_cnt[4 * blockIdx.x] = (uint32_t)t0;
+            a.tw.part_cnt[4 * blockIdx.x + 1] = (uint32_t)wall_clock64();
             // placement: HW_ID[15:0] (wave 3:0, simd 5:4, pipe 7:6, cu 11:8, sh 12, se 15:13) | XCC_ID << 16
             const uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            a.tw.slots[blockIdx.x].z = (hw & 0xffffu) | ((xcc & 0xfu) << 16);   // probe build only!
-            (void)t_first;
+            a.tw.part_cnt[4 * blockIdx.x + 2] = (hw & 0xffffu) | ((xcc & 0xfu) << 16);
         }
 #endif
         if (n > 0) {   // exit state -> the sub-tile's END slot (a fixed place the backward finds without `entered`)
@@ -636,6 +632,15 @@ hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
     return hipGetLastError();
 }
 
+// (Round 3 measured where the waves of this launch go -- tools/gpu_fwd_timeline.py, probe build -- because an avatar view's
+//  ~3 700 one-wave workgroups are all resident within a microsecond, i.e. the launch order is a static assignment of
+//  lists to SIMDs made by the dispatcher: walked entries per SIMD mean 544, max 883; the last wave of a SIMD ends after
+//  30.6 us on average, 38.6 us on the worst (= the launch).  A schedule that takes the assignment into the kernel -- one
+//  16-wave workgroup per CU with a snake-dealt bundle of lists, its first sixteen dealt to the SIMDs the waves really sit
+//  on (HW_ID), the rest pulled through an LDS counter -- evened the entries out (max 685) and was bit-identical, but
+//  bought 0.4 us on C3 (the per-SIMD end times stopped following the entry counts: correlation 0.89 -> 0.61) and cost the
+//  batched modes 5-7 % (8 330 -> 7 880 it/s at K = 8: four resident waves per SIMD instead of five, no overlap between the
+//  jobs of a batch).  Snaking the launch order alone (periods 256 .. 2048): +-1 us.  Not kept.)
 // All jobs of a batch share store_ctx (checked by the C ABI).  EXA_FWD_LDS_PAD (bytes, developer knob) adds unused
 // dynamic LDS per workgroup: fewer resident waves per CU, so that the tail of the length-sorted launch is dealt out
 // dynamically as earlier waves retire instead of all sub-tiles being placed at once.

@@ -200,6 +200,56 @@ def test_scene_like_inputs_sigmoid_opacities_and_raw_quaternions(dev):
     assert_grads_close(out['mean_2d'].grad, ref['mean_2d'].grad, 'mean_2d', near)
 
 
+# ---- sub-tile binning: the adaptive split of the cells over its workgroups ---------------------------------------------
+@pytest.mark.parametrize('case', ['few_cells_many_entries', 'one_dense_cell'])
+def test_binning_split_extremes(dev, case):
+    """csrc/binning.hip write_part_table: a cell gets one workgroup per max(1024, entries / (3 cells)) entries, at most 16,
+    out of a fixed grid of 4 per cell.  (a) four cells holding > 20 k entries: the entries-per-part bound is what keeps
+    the sum inside the grid; (b) one 64 x 64-px cell holding nearly all of 20 k entries (clamped to 16 parts of more than
+    one loop trip each) between empty and nearly empty cells.  Against the PyTorch oracle, same bars as everywhere."""
+    H, W, f, P, a = _split_case(case)
+    g = torch.Generator().manual_seed(7)
+    cam = {'R': torch.eye(3), 't': torch.zeros(3), 'focal': torch.tensor([f, f]), 'princpt': torch.tensor([W / 2.0, H / 2.0])}
+    G = torch.randn(3, H, W, generator=g)
+    bg = torch.rand(3, generator=g)
+    ag = _to(a, dev)
+    out = exa.GaussianRenderer()(ag, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    (out['img'] * G.to(dev)).sum().backward()
+    t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+    ref = ro.render(t, (H, W), cam, bg, return_aux=True)
+    (ref['img'] * G).sum().backward()
+    amb = ro.ambiguous_pixel_mask(ref['aux'], H, W)
+    for k in ('img', 'depthmap', 'mask'):
+        assert_image_close(out[k], ref[k], amb, k)
+    assert torch.equal(out['radius'].cpu(), ref['radius'])
+    near = gaussians_near_pixels(ref['aux']['pre'], amb)
+    for k in KEYS:
+        assert_grads_close(ag[k].grad, t[k].grad, k, near,
+                           abs_scale=rotation_grad_scale(t['scale'], t['scale'].grad) if k == 'rotation' else 0.0)
+    assert_grads_close(out['mean_2d'].grad, ref['mean_2d'].grad, 'mean_2d', near)
+
+
+def _split_case(case):
+    g = torch.Generator().manual_seed(11)
+    if case == 'few_cells_many_entries':
+        H, W, f, P = 128, 128, 190.0, 20_000
+        a = scenes.dist_a_random(P, H, W, seed=51, focal=f)
+        a['scale'] = a['scale'] * 0.25
+    else:
+        H, W, f, P = 192, 256, 260.0, 20_000
+        a = scenes.dist_a_random(P, H, W, seed=52, focal=f)
+        a['scale'] = a['scale'] * 0.2
+        m = a['mean_3d']
+        dense = torch.arange(P) >= 300                         # all but 300 splats projected into the cell at (1, 1)
+        u = 64.0 + 8.0 + 48.0 * torch.rand(P, generator=g)
+        v = 64.0 + 8.0 + 48.0 * torch.rand(P, generator=g)
+        z = m[:, 2]
+        m[dense, 0] = ((u - W / 2.0) / f * z)[dense]
+        m[dense, 1] = ((v - H / 2.0) / f * z)[dense]
+    a['opacity'] = a['opacity'] * 0.25                         # long lists: no early saturation
+    return H, W, f, P, a
+
+
 # ---- overflow: transparent retry ---------------------------------------------------------------------------------
 def _reset_config():
     exa.config.mode = 'exact'
