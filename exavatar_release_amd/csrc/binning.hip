@@ -20,6 +20,7 @@
 namespace exa {
 
 constexpr int SCAN_THREADS = 1024;
+constexpr int SC_BLOCK_THREADS = 1024;   // = SC_BLOCK (cell_scatter_kernel), declared further down
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     const int lane = threadIdx.x & 63;
@@ -193,6 +194,30 @@ __device__ __forceinline__ void write_cell_order(const TileWs& w, int cells, F i
     write_part_table(w, cells);
 }
 
+// Two exclusive scans across a 1024-thread workgroup behind ONE pair of barriers (a packed u64 and a u32 per thread).
+__device__ __forceinline__ void block_excl_scan_pair(unsigned long long x, uint32_t y, unsigned long long* s64, uint32_t* s32,
+                                                     unsigned long long& x_excl, unsigned long long& x_total,
+                                                     uint32_t& y_excl, uint32_t& y_total) {
+    constexpr int NW = SC_BLOCK_THREADS / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long ix = wave_incl_scan64(x);
+    const uint32_t iy = wave_incl_scan(y);
+    if (lane == 63) { s64[wave] = ix; s32[wave] = iy; }
+    __syncthreads();
+    unsigned long long bx = 0ull, tx = 0ull;
+    uint32_t by = 0u, ty = 0u;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const unsigned long long wx = s64[i];
+        const uint32_t wy = s32[i];
+        bx += i < wave ? wx : 0ull; tx += wx;
+        by += i < wave ? wy : 0u; ty += wy;
+    }
+    __syncthreads();
+    x_excl = bx + ix - x; x_total = tx;
+    y_excl = by + iy - y; y_total = ty;
+}
+
 __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> batch) {
     __shared__ unsigned long long s_tmp[SCAN_THREADS / 64];
     const BinArgs& a = batch.v[blockIdx.y];
@@ -321,12 +346,20 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     const BinWs& b = a.bw;
     const uint64_t capacity = a.capacity;
     const int tid = threadIdx.x, cells = g.cells;
+#ifdef EXA_PROBE_SCATTER   // probe build only (tools/gpu_scatter_phases.py): phases of every workgroup on the 100 MHz clock
+    const unsigned long long ps_t0 = wall_clock64();
+#define SCATTER_PHASE(i) do { __syncthreads(); if (tid == 0) w.part_cnt[40000 + 8 * blockIdx.x + (i)] = (uint32_t)(wall_clock64() - ps_t0) | ((i) == 0 ? 0u : 0u); } while (0)
+    if (tid == 0) { w.part_cnt[40000 + 8 * blockIdx.x + 6] = (uint32_t)ps_t0; }
+#else
+#define SCATTER_PHASE(i) do { } while (0)
+#endif
     {   // this workgroup's slice of the zero-filled section of the bin workspace: batch owners (written by
         // subtile_bin_kernel, the next launch), blended masks (render_fwd), touched bytes (render_bwd)
         const size_t n16 = bin_zero_bytes(capacity) / 16, per = (n16 + gridDim.x - 1) / gridDim.x;
         const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
         for (size_t i = lo + threadIdx.x; i < hi; i += SC_BLOCK) b.owner[i] = make_uint4(0u, 0u, 0u, 0u);
     }
+    SCATTER_PHASE(0);                                            // zero-fill slice issued
     uint32_t* s_base = s_dyn;
     uint32_t* s_cnt2 = s_dyn + cells;
     // Merged scans: the workgroup AFTER the job's last chunk has no Gaussians to scatter; it is the one that publishes what
@@ -337,6 +370,26 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
             report_header(a.host_hdr, w.header->num_rendered, 0u, 0u, a.hdr_tag);     // (cell_scan wrote the header)
         return;
     }
+    // This chunk's splat rows depend on nothing but the chunk: they are requested right after the column walk, so that the
+    // trip overlaps the block scans (phase probe: 2.3 us between the scans and the scatter, 1.2 of them this trip; requested
+    // BEFORE the walk they only delayed it -- loads return in order).
+    constexpr int PER = CHUNK / SC_BLOCK;
+    uint4 r3[PER];
+    int ids[PER];
+    uint32_t depth_bits[PER];
+    uint32_t mine = 0;
+    auto load_rows = [&] {
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            ids[it] = blockIdx.x * CHUNK + it * SC_BLOCK + tid;
+            r3[it] = make_uint4(0, 0, 0, 0);
+            depth_bits[it] = 0;
+            if (ids[it] < P) {
+                r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
+                depth_bits[it] = reinterpret_cast<const uint4*>(splats + ids[it])[0].z;
+            }
+        }
+    };
     uint32_t D, chunk_off;
     if (a.merged) {
         // The scans of the (chunk, cell) count matrix, done redundantly by EVERY scatter workgroup instead of by two
@@ -346,9 +399,30 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
         // what the later kernels read (cell_off, header, cell order).
         unsigned long long* s_tot = reinterpret_cast<unsigned long long*>(s_dyn + 2 * cells);
         unsigned long long* s_bef = s_tot + cells;
+        // (requested before the column walk: between the two block scans this load was a dependent trip of ~1 us)
+        const uint32_t ci = tid < a.chunks ? w.chunk_inst[tid] : 0u;
         for (int c = tid; c < cells; c += SC_BLOCK) { s_tot[c] = 0ull; s_bef[c] = 0ull; }
         __syncthreads();
         {
+            if ((cells & 1) == 0) {                             // two cells per thread and row: 16-byte loads, twice the row groups
+                const int cp = cells >> 1, G2 = SC_BLOCK / cp;   // (5.2 -> 4.0 us of this kernel's 13.9 on C3; four cells per thread: the same)
+                const int c2 = tid % cp, q = tid / cp;
+                if (q < G2) {
+                    unsigned long long tot0 = 0ull, tot1 = 0ull, bef0 = 0ull, bef1 = 0ull;
+                    const ulonglong2* m = reinterpret_cast<const ulonglong2*>(w.chunk_cell) + c2;
+#pragma unroll 4
+                    for (int r = q; r < a.chunks; r += G2) {
+                        const ulonglong2 v = m[(size_t)r * cp];
+                        const unsigned long long lowmask = r < (int)blockIdx.x ? 0xffffffffull : 0ull;
+                        tot0 += v.x; tot1 += v.y;
+                        bef0 += v.x & lowmask; bef1 += v.y & lowmask;
+                    }
+                    __hip_atomic_fetch_add(&s_tot[2 * c2], tot0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_tot[2 * c2 + 1], tot1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_bef[2 * c2], bef0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&s_bef[2 * c2 + 1], bef1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
             const int G = SC_BLOCK / cells;                     // row groups (cells <= SC_BLOCK on this path)
             const int c = tid % cells, q = tid / cells;
             if (q < G) {
@@ -363,18 +437,20 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                 __hip_atomic_fetch_add(&s_tot[c], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(&s_bef[c], bef, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            }
         }
+        if (!publisher) load_rows();
         __syncthreads();
+        SCATTER_PHASE(1);                                        // column walk of the count matrix
         const unsigned long long v = tid < cells ? s_tot[tid] : 0ull;
         const unsigned long long packed = ((unsigned long long)(cell_slots((uint32_t)(v >> 32)) * BATCH) << 32) | (uint32_t)v;
-        unsigned long long tot_all;
-        const unsigned long long x = block_excl_scan64(packed, s_tmp64, tot_all);     // (slot space << 32 | entries) prefix
+        // (slot space << 32 | entries) prefix over the cells, and the instances of the chunks in front of this one
+        // (chunks <= SC_BLOCK on this path): both scans behind one pair of barriers
+        unsigned long long tot_all, x;
+        uint32_t inst_total, cx;
+        block_excl_scan_pair(packed, ci, s_tmp64, s_tmp, x, tot_all, cx, inst_total);
         if (tid < cells) s_base[tid] = (uint32_t)x + (uint32_t)s_bef[tid];
         D = (uint32_t)(tot_all >> 32);
-        // instances of the chunks in front of this one (chunks <= SC_BLOCK on this path)
-        const uint32_t ci = tid < a.chunks ? w.chunk_inst[tid] : 0u;
-        uint32_t inst_total;
-        const uint32_t cx = block_excl_scan(ci, s_tmp, inst_total);
         if (tid == (int)blockIdx.x) s_bcast[0] = cx;
         if (publisher) {
             if (tid < cells) w.cell_off[tid] = make_uint2((uint32_t)x, (uint32_t)(x >> 32));
@@ -394,13 +470,16 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
             if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
             __syncthreads();                                     // cell_off (all of it) visible to the whole workgroup
             write_cell_order(w, cells, [&](int c) { return (uint32_t)(s_tot[c] >> 32); });
+            SCATTER_PHASE(5);                                    // publisher: everything
             return;
         }
         __syncthreads();
         chunk_off = s_bcast[0];
+        SCATTER_PHASE(2);                                        // block scans
         if ((uint64_t)D > capacity) return;                      // overflow latched in the header by the publisher
         for (int c = tid; c < cells; c += SC_BLOCK) s_cnt2[c] = 0u;
     } else {
+        load_rows();
         D = w.header->num_rendered;
         if (a.host_hdr && blockIdx.x == 0 && threadIdx.x == 0)
             report_header(a.host_hdr, D, (uint64_t)D > capacity ? 1u : 0u, w.header->num_visible, a.hdr_tag);
@@ -416,24 +495,11 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     }
     __syncthreads();
 
-    constexpr int PER = CHUNK / SC_BLOCK;
-    uint4 r3[PER];
-    int ids[PER];
-    uint32_t depth_bits[PER];
-    uint32_t mine = 0;
 #pragma unroll
-    for (int it = 0; it < PER; ++it) {
-        ids[it] = blockIdx.x * CHUNK + it * SC_BLOCK + tid;
-        r3[it] = make_uint4(0, 0, 0, 0);
-        depth_bits[it] = 0;
-        if (ids[it] < P) {
-            r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
-            depth_bits[it] = reinterpret_cast<const uint4*>(splats + ids[it])[0].z;
-        }
-        mine += r3[it].z;
-    }
+    for (int it = 0; it < PER; ++it) mine += r3[it].z;
     uint32_t total;
     uint32_t off = chunk_off + block_excl_scan(mine, s_tmp, total);
+    SCATTER_PHASE(3);                                            // splat rows loaded, in-chunk prefix
 #pragma unroll
     for (int it = 0; it < PER; ++it) {
         if (r3[it].z) {
@@ -449,6 +515,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                 }
         }
     }
+    SCATTER_PHASE(4);                                            // entries scattered
 }
 
 // One 1024-thread workgroup per cell: second radix digit.  Counts the cell's entries per 8x8 sub-tile in
