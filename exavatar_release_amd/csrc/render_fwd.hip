@@ -392,14 +392,22 @@ __global__ __launch_bounds__(SBLOCK) void sort_short_kernel(Batch<RenderFwdArgs>
 
 // KEEP = true: merge source of a composite render (compose.hip): the sorted 64-bit keys replace the unsorted ones, in place.
 // Its own instantiation: as a run-time flag the extra stores cost the headline sort 1.4 us of 15.1 on C3.
+// Six waves per SIMD (<= 85 VGPRs; the eight-keys-per-thread paths of the long lists spill ~50 bytes): the launch is a
+// stream of ~3 700 three-microsecond workgroups for an avatar view, and at the 104 registers the compiler takes on its own
+// only four of them fit a CU -- the timeline of the launch (tools/gpu_sort_timeline.py) showed workgroups with a list still
+// STARTING 11.7 us in.  Six is also what the 25 KiB of LDS allow.  16.0 -> 13.6 us by events (five waves: 14.4), C3 +1.8 %.
 template <bool SPLIT, bool KEEP>
-__global__ __launch_bounds__(SBLOCK) void sort_subtiles_kernel(Batch<RenderFwdArgs> batch) {
+__global__ __launch_bounds__(SBLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void sort_subtiles_kernel(Batch<RenderFwdArgs> batch) {
     __shared__ __attribute__((aligned(16))) unsigned long long s_buf[SORT_TILE];
     __shared__ uint32_t s_cnt[SORT_TILE];                        // bucket counters / starts of the distribution sort
     __shared__ uint32_t s_misc[16];
     const RenderFwdArgs& a = batch.v[blockIdx.y];
     if ((int)blockIdx.x >= a.grid.subtiles + ORDER_WGS) return;   // a job with a smaller image than the largest of the batch
     const int tid = threadIdx.x;
+#ifdef EXA_PROBE_SORTLINE   // probe build only (tools/gpu_sort_timeline.py): start / end of every workgroup, 100 MHz clock
+    struct TL { const RenderFwdArgs& a; unsigned long long t0; int tid;
+        __device__ ~TL() { __syncthreads(); if (tid == 0) { a.tw.part_cnt[2 * blockIdx.x] = (uint32_t)t0; a.tw.part_cnt[2 * blockIdx.x + 1] = (uint32_t)wall_clock64(); } } } tl{a, wall_clock64(), tid};
+#endif
     if (blockIdx.x < ORDER_WGS) {
         order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid, [&](int st) { return a.tw.ranges[st]; });
         return;
