@@ -419,7 +419,10 @@ __global__ __launch_bounds__(SBLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     // Only the sub-tiles of the ACTIVE cells hold lists (cell_desc lists those cells first, heaviest first;
     // header.active_cells counts them): an avatar view has ~3 800 non-empty lists in 16 384 sub-tiles, and the
     // workgroups of the empty ones leave after ONE scalar load instead of two dependent vector loads.  (A
-    // grid-stride loop over the active sub-tiles with a smaller grid cost 2.5x the registers and ran slower.)
+    // grid-stride loop over the active sub-tiles with a smaller grid cost 2.5x the registers and ran slower; so did, in
+    // round 3, a grid over 3/8 of the cells whose workgroups continue with further lists only when more cells are
+    // active: the loop around the sorts spills on the hot path at six waves per SIMD -- 13.4 -> 48.9 us -- although the
+    // timeline shows the dispatch of the 12 600 idle workgroups lasting as long as the sorting itself.)
     const int wg = (int)blockIdx.x - ORDER_WGS;
     if (wg >= (int)a.tw.header->active_cells * SUBS_PER_CELL) return;
     if (SPLIT && a.tw.cell_long[wg >> 6] == 0u) return;         // the same word for the 64 workgroups of a cell
