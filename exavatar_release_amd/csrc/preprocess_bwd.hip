@@ -43,6 +43,13 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
     const int gf = PREFIX ? out.grad_first : 0;
     if (PREFIX && (int)((blockIdx.x + 1) * GPB) <= gf) return;  // workgroup-uniform
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef EXA_PROBE_PBWD      // probe build only (tools/gpu_pbwd_phases.py): phases of every wave on the 100 MHz clock
+    const unsigned long long pb_t0 = wall_clock64();
+    float pb_ph[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#define PBWD_PHASE(i) pb_ph[i] = (float)(wall_clock64() - pb_t0)
+#else
+#define PBWD_PHASE(i) do { } while (0)
+#endif
     const int idx = VW == 1 ? blockIdx.x * BLOCK + threadIdx.x : blockIdx.x * 64 + lane;
     // NO per-lane early exit: the wave-cooperative gather below needs all 64 lanes, also in the last, partly filled
     // wave (Gaussians appended by densification sit exactly there)
@@ -113,6 +120,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             }
         }
 
+        PBWD_PHASE(0);                                          // splat row 3 here (first trip), heavy splats gathered
         float vmean[3] = {0.f, 0.f, 0.f}, vm2[2] = {0.f, 0.f}, vscale[3] = {0.f, 0.f, 0.f};
         float vq[4] = {0.f, 0.f, 0.f, 0.f}, vcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float vop = 0.f, vcol[3] = {0.f, 0.f, 0.f};
@@ -120,6 +128,11 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             // ---- gather this Gaussian's blended instances (contiguous slots, each written at most once) ----------
             float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
             {
+                // (Round 3, phase probe tools/gpu_pbwd_phases.py: the wave leaves this loop with its SLOWEST lane -- 9.2 us of
+                //  the kernel's 14 on C3, chain rule 1.5, stores 0.5.  Requesting the next trip's `touched` bytes during the
+                //  current one and fetching the flagged records compacted changed nothing (20.2 vs 20.4 us); all eight
+                //  records of a trip at once: 22.8 us.  Like the column walk of cell_scatter, the loop does not respond to
+                //  fewer dependent trips: it is bound by the divergent 16-byte accesses themselves.)
                 const uint32_t n_own = r3.z < COOP_MIN ? r3.z : 0u;     // larger ones were fetched by the whole wave above
                 const uint32_t off = r3.w;
                 for (uint32_t i = 0; i < n_own; i += 8) {
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
                 }
             }
 
+            PBWD_PHASE(1);                                      // own partial records gathered
             mx += co[0]; my += co[1]; mxx += co[2]; mxy += co[3]; myy += co[4];
             vop += co[5]; vcol[0] += co[6]; vcol[1] += co[7]; vcol[2] += co[8]; dz_view += co[9];
 
@@ -361,6 +375,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             sh_init = true;
         }
         }
+        PBWD_PHASE(2);                                          // chain rule
         if (valid && a.dL_dmeans2D) {
             a.dL_dmeans2D[row * 3 + 0] = vm2[0]; a.dL_dmeans2D[row * 3 + 1] = vm2[1]; a.dL_dmeans2D[row * 3 + 2] = 0.f;
         }
@@ -434,6 +449,20 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
 #pragma unroll
         for (int i = 0; i < 6; ++i) out.dL_dcov3D[row * 6 + i] = dcov[i];
     }
+#ifdef EXA_PROBE_PBWD
+    PBWD_PHASE(3);
+    {   // the wave's phases (max over its lanes), as floats in the z slots of its own rows of dL_dmeans2D
+        float m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[i] = pb_ph[i];
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) m[i] = fmaxf(m[i], __shfl_xor(m[i], d, 64));
+        }
+        if (lane < 4 && out.dL_dmeans2D) out.dL_dmeans2D[(row - lane + lane) * 3 + 2] = lane == 0 ? m[0] : lane == 1 ? m[1] : lane == 2 ? m[2] : m[3];
+        if (lane == 4 && out.dL_dmeans2D) out.dL_dmeans2D[row * 3 + 2] = (float)(pb_t0 & 0xffffff);
+    }
+#endif
 }
 
 // Fused densification statistics (include/exa_raster.h: exa_raster_densify_stats; reference
