@@ -280,6 +280,13 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
     const PreprocessArgs& a = batch.v[blockIdx.y];              // this workgroup's job (kernarg segment: scalar loads)
     if ((int)blockIdx.x >= num_chunks(a.P)) return;             // a job with fewer Gaussians than the largest of the batch
     const int tid = threadIdx.x;
+#ifdef EXA_PROBE_PFWD      // probe build only (tools/gpu_pfwd_phases.py): phases of every workgroup, 100 MHz clock, into the radii
+                           // of the chunk's first Gaussians (which the probe run does not use)
+    const unsigned long long pf_t0 = wall_clock64();
+#define PFWD_PHASE(i) do { __syncthreads(); if (tid == 0) a.radii[blockIdx.x * CHUNK + (i)] = (int)(wall_clock64() - pf_t0); } while (0)
+#else
+#define PFWD_PHASE(i) do { } while (0)
+#endif
     for (int c = tid; c < a.grid.cells; c += PBLOCK) s_cell[c] = 0ull;
     __syncthreads();
     uint32_t inst_sum = 0;
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
             }
         }
     }
+    PFWD_PHASE(1);                                              // Gaussians projected, records written, LDS histogram
     // chunk totals
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -354,6 +362,10 @@ __global__ __launch_bounds__(PBLOCK) void preprocess_fwd_kernel(Batch<Preprocess
     // this chunk's row of the (chunk, cell) count matrix: plain coalesced stores, zeros included
     unsigned long long* row = a.tw.chunk_cell + (size_t)blockIdx.x * a.grid.cells;
     for (int c = tid; c < a.grid.cells; c += PBLOCK) row[c] = s_cell[c];
+    PFWD_PHASE(2);                                              // chunk totals + matrix row stored
+#ifdef EXA_PROBE_PFWD
+    if (tid == 0) a.radii[blockIdx.x * CHUNK + 3] = (int)(pf_t0 & 0xffffff);
+#endif
 }
 
 __global__ __launch_bounds__(BLOCK) void mark_visible_kernel(int P, const float* __restrict__ means3D,
