@@ -348,7 +348,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
     const int tid = threadIdx.x, cells = g.cells;
 #ifdef EXA_PROBE_SCATTER   // probe build only (tools/gpu_scatter_phases.py): phases of every workgroup on the 100 MHz clock
     const unsigned long long ps_t0 = wall_clock64();
-#define SCATTER_PHASE(i) do { __syncthreads(); if (tid == 0) w.part_cnt[40000 + 8 * blockIdx.x + (i)] = (uint32_t)(wall_clock64() - ps_t0) | ((i) == 0 ? 0u : 0u); } while (0)
+#define SCATTER_PHASE(i) do { __syncthreads(); if (tid == 0) w.part_cnt[40000 + 8 * blockIdx.x + (i)] = (uint32_t)(wall_clock64() - ps_t0); } while (0)
     if (tid == 0) { w.part_cnt[40000 + 8 * blockIdx.x + 6] = (uint32_t)ps_t0; }
 #else
 #define SCATTER_PHASE(i) do { } while (0)
