@@ -286,8 +286,8 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
     __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
     const int lane = tid & 63;
     // Histogram over the sub-tiles of the ACTIVE cells only (cell_desc lists them first; an avatar view: 70 of 256): the
-    // others are empty, the empty class comes last in the order and its count enters no offset.  These workgroups walked all ranges of the image in eight dependent trips and were the longest of the
-    // launch.
+    // others are empty, the empty class comes last in the order and its count enters no offset.  (These workgroups used
+    // to walk all ranges of the image in eight dependent trips and were the longest of the launch.)
     if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
     __syncthreads();
     const int counted = min(subtiles, (int)w.header->active_cells * SUBS_PER_CELL);
