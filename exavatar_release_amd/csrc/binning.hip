@@ -273,6 +273,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
         w.header->num_tile_instances = (uint32_t)tiles_tot;
     }
     if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+            if (tid < 4) w.bwd_meta[tid] = 0u;
     __syncthreads();                                             // cell_off (all of it) visible to the whole workgroup
     write_cell_order(w, cells, [&](int c) { return (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32); });
 }
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                 if (a.host_hdr) report_header(a.host_hdr, D, (uint64_t)D > capacity ? 1u : 0u, vis_total, a.hdr_tag);
             }
             if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+            if (tid < 4) w.bwd_meta[tid] = 0u;
             __syncthreads();                                     // cell_off (all of it) visible to the whole workgroup
             write_cell_order(w, cells, [&](int c) { return (uint32_t)(s_tot[c] >> 32); });
             SCATTER_PHASE(5);                                    // publisher: everything

@@ -99,6 +99,9 @@ constexpr int BIN_PARTS = EXA_BIN_PARTS;   // workgroups per cell in the sub-til
 struct TileWs {
     ExaRasterHeader* header;          // [1]          written by cell_scan_kernel
     uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class (zeroed by cell_scan)
+    uint32_t* bwd_meta;               // [4]   launch order of the backward blend (render_fwd.hip order_slots writes it, in the
+                                      //       sort launch: {batches in the main order, batches appended behind it, BWD_ORDER_MAGIC});
+                                      //       the order itself lives in the bucket array of the bin workspace, dead by then
     unsigned long long* chunk_cell;   // [chunks][cells]  per-(chunk, cell) counts inst << 32 | entries, plain stores by
                                       //              preprocess (NO atomics: same-address device atomics of ~150 chunks
                                       //              serialise at the memory side); cell_scan replaces the low word by the
@@ -137,6 +140,7 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     TileWs w;
     w.header = reinterpret_cast<ExaRasterHeader*>(p);
     w.cls_cur = reinterpret_cast<uint32_t*>(p + 256);
+    w.bwd_meta = reinterpret_cast<uint32_t*>(p + 128);
     p += HEADER_BYTES;
     w.chunk_cell = reinterpret_cast<unsigned long long*>(p); p += align256(uint64_t(chunks) * cells * 8);
     w.cell_cnt = reinterpret_cast<unsigned long long*>(p); p += align256(uint64_t(cells) * 8);
@@ -211,6 +215,8 @@ __host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t) {
 // size class instead of a random draw (measured on C3: the busiest SIMD had 2.06x the mean work with a
 // cell-major order, and that SIMD set the kernel time).
 constexpr int ORDER_CLASSES = 64;
+constexpr uint32_t BWD_ORDER_MAGIC = 0xB07DE7EDu;
+constexpr int BWD_ORDER_DEPTH = 16;       // batches of a list that take part in the batch-major order (class 63 = 16 batches or more)
 __device__ __forceinline__ int length_class(uint32_t n) { return n ? min(ORDER_CLASSES - 1, (int)((n + 15) / 16)) : 0; }
 
 // cell-major sub-tile index st = cell * 64 + local  ->  coordinates

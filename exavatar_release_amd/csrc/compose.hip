@@ -123,6 +123,7 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         h->num_instances = a.tw_a.header->num_instances + a.tw_b.header->num_instances;
         h->active_cells = 0u;
         h->num_tile_instances = a.tw_a.header->num_tile_instances + a.tw_b.header->num_tile_instances;
+        a.tw.bwd_meta[2] = 0u;                                   // no batch order for the backward of a composite (slot order)
         if (a.host_hdr) {
             typedef uint32_t v4u __attribute__((ext_vector_type(4)));
             const v4u v = {total * BATCH, overflow ? 1u : 0u, h->num_visible, a.hdr_tag};

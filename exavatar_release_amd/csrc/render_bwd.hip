@@ -135,6 +135,11 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     const RenderBwdArgs& a = batch.v[blockIdx.y];
     const uint32_t nslots = (uint32_t)(a.capacity / BATCH);
     const int lane = threadIdx.x;
+#ifdef EXA_PROBE_BWDLINE   // probe build only (tools/gpu_bwd_timeline.py): start / end of every wave on the chip-wide 100 MHz clock
+    struct TL { const RenderBwdArgs& a; unsigned long long t0; int lane;
+        __device__ ~TL() { if (lane == 0 && 2 * blockIdx.x + 1 < (uint32_t)(a.grid.cells * BIN_PARTS * SUBS_PER_CELL)) {
+            a.tw.part_cnt[2 * blockIdx.x] = (uint32_t)t0; a.tw.part_cnt[2 * blockIdx.x + 1] = (uint32_t)wall_clock64(); } } } tl{a, (unsigned long long)wall_clock64(), lane};
+#endif
     const float* __restrict__ bg = a.bg;
     float4* __restrict__ prec = a.partials.rec;
     uint8_t* __restrict__ touched = a.bw.touched;
@@ -213,17 +218,30 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     // 55.6 / 64.0 / 70.7 us, and persistent waves striding over the slots with a two-deep prefetch 81 us -- the batches'
     // costs differ by an order of magnitude (1..64 blended entries), so anything that takes work distribution away from
     // the hardware's wave dispatcher loses more to imbalance than it gains from hidden latency.
+    // Launch order (render_fwd.hip order_slots): wave w takes the w-th batch of the batch-major order the sort launch left
+    // in the (dead) bucket array -- heavy batches first, nothing dispatched for slots without work beyond the one load of
+    // the waves past the end.  Composites and the EXA_BWD_SPW variants keep the slot order.
+    uint32_t first_slot = blockIdx.x * SPW;
+    if (SPW == 1) {
+        const uint32_t m0 = a.tw.bwd_meta[0], m1 = a.tw.bwd_meta[1], magic = a.tw.bwd_meta[2];
+        // (requested together with the three words above: one trip; a composite's bin workspace has no bucket array)
+        const uint32_t mapped = a.bw.bucket ? reinterpret_cast<const uint32_t*>(a.bw.bucket)[min(blockIdx.x, nslots - 1u)] : 0u;
+        if (magic == BWD_ORDER_MAGIC && a.bw.bucket) {
+            if (blockIdx.x >= m0 + m1) return;
+            first_slot = mapped;
+        }
+    }
     BwdHdr hh[SPW];
     BwdPay pp[SPW];
 #pragma unroll
-    for (int i = 0; i < SPW; ++i) hh[i] = load_hdr(blockIdx.x * SPW + i);
+    for (int i = 0; i < SPW; ++i) hh[i] = load_hdr(first_slot + i);
 #pragma unroll
-    for (int i = 0; i < SPW; ++i) pp[i] = load_pay(hh[i], blockIdx.x * SPW + i);
+    for (int i = 0; i < SPW; ++i) pp[i] = load_pay(hh[i], first_slot + i);
 #pragma unroll
     for (int rep = 0; rep < SPW; ++rep) {
     const BwdHdr& h0 = hh[rep];
     const BwdPay& p0 = pp[rep];
-    const uint32_t slot = blockIdx.x * SPW + rep;
+    const uint32_t slot = first_slot + rep;
     if (is_active(h0)) {
     // ================================= one batch =================================================================
     const uint32_t bm_lo = __builtin_amdgcn_readfirstlane(h0.bm_lo), bm_hi = __builtin_amdgcn_readfirstlane(h0.bm_hi);

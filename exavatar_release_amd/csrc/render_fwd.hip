@@ -281,9 +281,18 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
 // writes the records.
 constexpr int ORDER_WGS = 16;
 constexpr int ORDER_U = 8;       // ranges in flight per thread while counting (16 cost the KEEP sort 32 VGPRs = a wave per SIMD)
+// The same workgroups write the launch order of the BACKWARD blend (one wave per 64-entry batch, render_bwd.hip):
+// batch-major -- the first batches of all lists, longest list first, then all second batches, ... -- which is heavy first
+// without knowing the blended counts: the front batches of a list are the ones whose entries get blended, the deep ones
+// the forward often does not even enter.  In slot order the launch ended with whatever the last cells held (a full batch
+// takes 18 us at five waves per SIMD, started as late as 35 us in) and spent a third of its dispatches on slots without
+// work (end slots, padding: 14 k of 24 k).  Position of batch b of the list at descending position p: B_b + p, with
+// B_b = sum over b' < b of the number of lists with more than b' batches -- all from the class histogram, no sort.
+// Batches from BWD_ORDER_DEPTH on (lists of > 1024 entries) are appended behind through a counter.
 template <typename RangeOf>       // RangeOf(st) -> [begin, end) of sub-tile st's list; the records hold what it returns
-__device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int part, int tid, RangeOf range_of) {
+__device__ __forceinline__ void order_slots(const TileWs& w, uint32_t* __restrict__ bwd_order, int subtiles, int part, int tid, RangeOf range_of) {
     __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
+    __shared__ uint32_t s_bbase[BWD_ORDER_DEPTH + 1];
     const int lane = tid & 63;
     // Histogram over the sub-tiles of the ACTIVE cells only (cell_desc lists them first; an avatar view: 70 of 256): the
     // others are empty, the empty class comes last in the order and its count enters no offset.  (These workgroups used
@@ -325,6 +334,13 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
         s_cnt[cls] = 0u;
     }
     __syncthreads();
+    if (tid == 0) {       // lists with more than b batches = lists of a class above 4 b = s_off[4 b]
+        uint32_t run = 0u;
+        for (int b = 0; b < BWD_ORDER_DEPTH; ++b) { s_bbase[b] = run; run += s_off[4 * b]; }
+        s_bbase[BWD_ORDER_DEPTH] = run;
+        if (part == 0) { w.bwd_meta[0] = run; w.bwd_meta[2] = bwd_order ? BWD_ORDER_MAGIC : 0u; }
+    }
+    __syncthreads();
     const int per = (subtiles + ORDER_WGS - 1) / ORDER_WGS;
     const int lo = part * per, hi = min(subtiles, lo + per);
     for (int base = lo; base < hi; base += SBLOCK * 4) {
@@ -361,7 +377,14 @@ __device__ __forceinline__ void order_slots(const TileWs& w, int subtiles, int p
             const int st = base + i * SBLOCK + tid;
             if (st < hi) {
                 const int cls = length_class(r[i].y - r[i].x);
-                w.slots[s_base[cls] + rank[i]] = make_uint4(r[i].x, r[i].y, (uint32_t)st, 0u);
+                const uint32_t pos = s_base[cls] + rank[i];
+                w.slots[pos] = make_uint4(r[i].x, r[i].y, (uint32_t)st, 0u);
+                const uint32_t nb = (r[i].y - r[i].x + BATCH - 1) / BATCH, slot0 = r[i].x / BATCH;
+                for (uint32_t b = 0; bwd_order && b < nb; ++b) {
+                    const uint32_t q = b < (uint32_t)BWD_ORDER_DEPTH ? s_bbase[b] + pos
+                                                                     : s_bbase[BWD_ORDER_DEPTH] + atomicAdd(&w.bwd_meta[1], 1u);
+                    bwd_order[q] = slot0 + b;
+                }
             }
         }
         __syncthreads();
@@ -406,10 +429,12 @@ __global__ __launch_bounds__(SBLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) 
     const int tid = threadIdx.x;
 #ifdef EXA_PROBE_SORTLINE   // probe build only (tools/gpu_sort_timeline.py): start / end of every workgroup, 100 MHz clock
     struct TL { const RenderFwdArgs& a; unsigned long long t0; int tid;
-        __device__ ~TL() { __syncthreads(); if (tid == 0) { a.tw.part_cnt[2 * blockIdx.x] = (uint32_t)t0; a.tw.part_cnt[2 * blockIdx.x + 1] = (uint32_t)wall_clock64(); } } } tl{a, wall_clock64(), tid};
+        __device__ ~TL() { __syncthreads(); if (tid == 0) { a.tw.part_cnt[2 * blockIdx.x] = (uint32_t)t0; a.tw.part_cnt[2 * blockIdx.x + 1] = (uint32_t)wall_clock64(); } } } tl{a, (unsigned long long)wall_clock64(), tid};
 #endif
     if (blockIdx.x < ORDER_WGS) {
-        order_slots(a.tw, a.grid.subtiles, (int)blockIdx.x, tid, [&](int st) { return a.tw.ranges[st]; });
+        // (the backward's order only for renders that keep their context: a no_grad frame has no backward)
+        order_slots(a.tw, a.store_ctx ? reinterpret_cast<uint32_t*>(a.bw.bucket) : nullptr, a.grid.subtiles, (int)blockIdx.x, tid,
+                    [&](int st) { return a.tw.ranges[st]; });
         return;
     }
 #ifdef EXA_PROBE_SORT
