@@ -41,10 +41,18 @@ background only and its backward writes zero gradients.  ``config.on_overflow``:
 * ``'raise'``: ``RuntimeError`` instead (from ``backward``, :func:`check_overflow` or a later call).
 
 ``config.overflow_check`` decides whether ``backward`` WAITS for a report that has not landed yet:
-``'always'`` does; ``'adaptive'`` (default) waits during the first ``config.verify_calls`` calls of a
-shape and whenever the last known D filled more than ``config.danger_fill`` of the buffer, and
-otherwise leaves the report to be drained later (an overflow found after its backward has returned
-can only be recorded -- the capacity memo grows -- and warned about).
+``'always'`` (default) does -- the report is written ~35 us into the forward, so by the time autograd
+reaches the render's backward it has normally landed and the wait costs nothing; backward therefore
+NEVER returns the gradients of an overflowed render.  ``'adaptive'`` (opt-in, for loops that cannot
+afford any host wait) waits during the first ``config.verify_calls`` calls of a shape and whenever
+the last known D filled more than ``config.danger_fill`` of the buffer, and otherwise leaves the
+report to be drained later: an overflow found after its backward has returned ZERO gradients can
+only be recorded -- the capacity memo grows -- and warned about (``'late'`` in ``overflow_events``).
+
+A render that nobody differentiates (``no_grad``, a skipped step) is repaired when its report is
+drained -- by a later call or :func:`check_overflow` -- from the input tensors as they are THEN: if
+they were modified in place in between (``optimizer.step()``), the corrected image shows the new
+values, and the ``RuntimeWarning`` says so.
 """
 import ctypes
 import time
@@ -80,7 +88,7 @@ class _Config:
     fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up)
     keep_debug = False        # developer probes: keep the workspaces of the most recent forward reachable
     on_overflow = 'retry'     # 'retry' | 'raise'
-    overflow_check = 'adaptive'   # 'adaptive' | 'always': does backward wait for a header report that has not landed?
+    overflow_check = 'always'     # 'always' | 'adaptive': does backward wait for a header report that has not landed?
     verify_calls = 4          # adaptive: the first calls of a shape wait for their report
     danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
     upstream_scale_grad = False   # True: dL/dscale as upstream returns it (w.r.t. scale_modifier * scale, i.e. divided
@@ -94,7 +102,8 @@ _seen_D = {}      # (device index, P, H, W) -> largest instance capacity a call 
 _verified = {}    # same key -> number of calls whose report was looked at before their backward returned
 _pending = []     # header reports nobody has consumed yet: _Pending records
 overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
-_capture_report = None   # (slot, tag): header-report slot baked into the call being CAPTURED (set by GraphedRenderer)
+_capture_report = None   # [(slot, tag) | None per job]: reserved header-report slots baked into the batched call being
+#                          CAPTURED (set by GraphedRenderer / GraphedIteration around their capture)
 _last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
 
 
@@ -195,25 +204,53 @@ def _make_settings(rs, device, keep):
 
 # ---- zero-copy header reports ------------------------------------------------------------------------------------
 class _HdrPool:
-    """Ring of 16-byte slots in pinned host memory the scatter kernel writes its header report into."""
+    """16-byte slots in pinned host memory the scatter kernel writes its header report into: a ring of N slots for eager
+    calls (one per render job, composite or focal-length flag; ``owner`` remembers the tag of the latest taker, so a
+    report whose slot was handed out again knows it was recycled) and RESERVED slots outside the ring for reports that
+    are baked into a captured hipGraph (``GraphedRenderer``, ``GraphedIteration``): a graph rewrites its slot on every
+    replay for as long as it lives, so it must never be dealt to anybody else."""
     N = 2048
+    RESERVED = 256
 
     def __init__(self):
-        self.buf = torch.zeros((self.N, 4), dtype=torch.int32, pin_memory=True)
+        total = self.N + self.RESERVED
+        self.buf = torch.zeros((total, 4), dtype=torch.int32, pin_memory=True)
         dp = ctypes.c_void_p()
         _lib.check(_lib.load().exa_raster_host_device_pointer(ctypes.c_void_p(self.buf.data_ptr()), ctypes.byref(dp)))
         self.dev_base = int(dp.value)
-        self.words = (ctypes.c_uint32 * (4 * self.N)).from_address(self.buf.data_ptr())
+        self.words = (ctypes.c_uint32 * (4 * total)).from_address(self.buf.data_ptr())
         self.next = 0
         self.tag = 1
+        self.owner = [0] * total
+        self.free_reserved = list(range(total - 1, self.N - 1, -1))
 
-    def take(self):
-        """(slot, tag, device address)."""
-        i = self.next
-        self.next = (i + 1) % self.N
+    def _next_tag(self):
         tag = self.tag
         self.tag = tag + 1 if tag < 0x7ffffff0 else 1
+        return tag
+
+    def take(self):
+        """(slot, tag, device address) of the next ring slot."""
+        i = self.next
+        self.next = (i + 1) % self.N
+        tag = self._next_tag()
+        self.owner[i] = tag
         return i, tag, self.dev_base + 16 * i
+
+    def reserve(self):
+        """(slot, tag, device address) of a slot outside the ring, held until :meth:`release`; None when all are taken."""
+        if not self.free_reserved:
+            return None
+        i = self.free_reserved.pop()
+        tag = self._next_tag()
+        self.owner[i] = tag
+        self.words[4 * i + 3] = 0
+        return i, tag, self.dev_base + 16 * i
+
+    def release(self, slot):
+        if slot >= self.N and slot not in self.free_reserved:
+            self.owner[slot] = 0
+            self.free_reserved.append(slot)
 
 
 _hdr_pool = None
@@ -239,7 +276,9 @@ class _Report:
     def ready(self):
         if self.event is not None:
             return self.event.query()
-        return _hdr_pool.words[4 * self.slot + 3] == self.tag
+        # a slot that was dealt again (> N renders later) will never show this report's tag: treat it as landed --
+        # values() then reads the header from the device
+        return _hdr_pool.words[4 * self.slot + 3] == self.tag or _hdr_pool.owner[self.slot] != self.tag
 
     def wait(self):
         if self.event is not None:
@@ -247,11 +286,12 @@ class _Report:
             return
         w = _hdr_pool.words
         i, tag = 4 * self.slot + 3, self.tag
-        t_end = time.perf_counter() + 2e-3
-        while w[i] != tag and time.perf_counter() < t_end:
-            pass
+        if _hdr_pool.owner[self.slot] == tag:
+            t_end = time.perf_counter() + 2e-3
+            while w[i] != tag and time.perf_counter() < t_end:
+                pass
         if w[i] != tag:
-            self.stream.synchronize()       # far behind: let the stream reach the scatter stage
+            self.stream.synchronize()       # far behind (or slot recycled): let the stream reach the scatter stage
 
     def values(self):
         """(needed capacity, overflow flag); call after ready() / wait()."""
@@ -337,11 +377,13 @@ def _consume(rec, block, from_backward=False):
                           % (need, j.capacity), RuntimeWarning)
             continue
         old = j.capacity
+        stale = tuple(t._version for t in (j.means3D, j.sh, j.colors, j.opac, j.scales, j.rot, j.cov) if t is not None) != j.versions
         _rerender(j, need, rec.store_ctx, rec.device)
         _record_overflow(j.key, need, old, 'retried')
         warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d: re-rendered with '
                       'enough room (outputs corrected in place; work that already read the incomplete image -- the loss '
-                      'value of this step -- is not).' % (need, old), RuntimeWarning)
+                      'value of this step -- is not).%s' % (need, old, ' Its input tensors were modified in place since the '
+                      'forward: the corrected image shows their CURRENT values.' if stale else ''), RuntimeWarning)
     if all_done:
         rec.done = True
     if msgs:
@@ -419,7 +461,7 @@ class _Job:
     """Host-side record of one render of a batch."""
     __slots__ = ('rs', 'P', 'nF', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
                  'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
-                 'gb', 'tb', 'keep_keys', 'rec', 'device')
+                 'gb', 'tb', 'keep_keys', 'rec', 'device', 'versions')
 
 
 _F32 = torch.float32
@@ -511,6 +553,7 @@ class _Rasterize(torch.autograd.Function):
             j.sh_M = int(j.sh.shape[1]) if j.sh is not None else 0
             j.key = (device.index, j.P, j.H, j.W)
             j.keep_keys, j.rec, j.device = keep_keys, None, device
+            j.versions = tuple(t._version for t in (j.means3D, j.sh, j.colors, j.opac, j.scales, j.rot, j.cov) if t is not None)
             jobs.append(j)
         if shared and K > 1:
             # "K views of the same Gaussians" is decided on what the kernels will see: the converted tensors
@@ -583,9 +626,9 @@ class _Rasterize(torch.autograd.Function):
                 j.geom_ptr = j.ws.data_ptr()
                 j.tile_ptr = j.geom_ptr + j.gb
                 _fill_forward_job(arr[k], j, reports[k] if reports is not None else None)
-                if capturing and _capture_report is not None and K == 1:
-                    arr[k].host_header = _hdr_pool.dev_base + 16 * _capture_report[0]
-                    arr[k].header_tag = _capture_report[1]
+                if capturing and _capture_report is not None and k < len(_capture_report) and _capture_report[k] is not None:
+                    arr[k].host_header = _hdr_pool.dev_base + 16 * _capture_report[k][0]
+                    arr[k].header_tag = _capture_report[k][1]
 
             if mode == 'exact':
                 _lib.check(lib.exa_raster_forward_bin_batch(arr, K, stream))
@@ -846,6 +889,18 @@ class _Compose(torch.autograd.Function):
             outs += [col, c.radii, d, al]
         if need_ctx:
             ctx.K, ctx.cjobs, ctx.device = K, cjobs, device
+            # B's converted inputs go through save_for_backward like _Rasterize's: an in-place update between the sources'
+            # forward and this backward (the splat records of the sources hold the OLD values) raises instead of mixing
+            saved, empty = [], None
+            for c in cjobs:
+                jb = c.b
+                for t in (jb.means3D, jb.sh, jb.colors, jb.opac, jb.scales, jb.rot, jb.cov):
+                    if t is None:
+                        if empty is None:
+                            empty = torch.empty(0, device=device)
+                        t = empty
+                    saved.append(t)
+            ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(*[outs[4 * k + 1] for k in range(K)])
         ctx.set_materialize_grads(False)
         return tuple(outs)
@@ -856,6 +911,7 @@ class _Compose(torch.autograd.Function):
             raise RuntimeError('exavatar_release_amd: backward called on a composite that stored no context')
         lib = _lib.load()
         K, cjobs, device = ctx.K, ctx.cjobs, ctx.device
+        saved = ctx.saved_tensors          # (checks the version counters of B's inputs)
         need = ctx.needs_input_grad[4:]
         arr = (_lib.ExaRasterBackwardJob * K)()
         keep, ret = [], [None, None, None, None]
@@ -905,9 +961,14 @@ class _Compose(torch.autograd.Function):
                 a = arr[k]
                 a.settings = ctypes.pointer(c.settings)
                 a.P, a.sh_M = P, sh_M
-                a.means3D, a.shs, a.colors_precomp = _addr(jb.means3D), _addr(jb.sh), _addr(jb.colors)
-                a.opacities, a.scales, a.rotations = _addr(jb.opac), _addr(jb.scales), _addr(jb.rot)
-                a.cov3D_precomp = _addr(jb.cov)
+                b_m3, b_sh, b_col, b_op, b_sc, b_rot, b_cov = saved[7 * k: 7 * k + 7]
+                a.means3D = b_m3.data_ptr()
+                a.shs = b_sh.data_ptr() if has_sh else None
+                a.colors_precomp = b_col.data_ptr() if has_col else None
+                a.opacities = b_op.data_ptr()
+                a.scales = b_sc.data_ptr() if has_sc else None
+                a.rotations = b_rot.data_ptr() if has_rot else None
+                a.cov3D_precomp = b_cov.data_ptr() if has_cov else None
                 a.radii = jb.radii.data_ptr()
                 a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = jb.geom_ptr, c.tile_ptr, c.bin_ptr, c.capacity
                 a.dL_dcolor, a.dL_ddepth, a.dL_dalpha = g_color.data_ptr(), _addr(g_depth), _addr(g_alpha)

@@ -361,6 +361,14 @@ class GraphedRenderer:
         self._intr, self._focal_src, self._focal_ver = None, None, None     # last verified intrinsics record / focal tensor
         self.captures = 0
 
+    def __del__(self):
+        try:
+            from . import rasterizer as rz
+            if self._slot is not None and rz._hdr_pool is not None:
+                rz._hdr_pool.release(self._slot[0])
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
     @property
     def inputs(self):
         """The static input tensors the graph reads (``mean_3d, scale, rotation, opacity, rgb | sh``): a producer may
@@ -403,11 +411,13 @@ class GraphedRenderer:
                 # include/exa_raster.h: host_header): every replay rewrites it, the host resets the tag before a replay and
                 # polls it afterwards -- no read-back, no synchronisation per frame
                 pool = rz._pool()
+                if self._slot is not None and pool is not None:
+                    pool.release(self._slot[0])               # the graph that wrote into it is gone
                 self._slot = None
-                if pool is not None:
-                    slot, tag, _ = pool.take()
-                    self._slot = (slot, tag)
-                    rz._capture_report = self._slot
+                got = pool.reserve() if pool is not None else None   # outside the ring eager renders draw from
+                if got is not None:
+                    self._slot = (got[0], got[1])
+                    rz._capture_report = [self._slot]
                 try:
                     self._graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self._graph):
