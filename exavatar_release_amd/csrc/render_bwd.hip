@@ -78,6 +78,11 @@ template <> struct XLayout<16> {
         x += __shfl_xor(x, 32, 64);
         return x;
     }
+    __device__ static __forceinline__ void reduce9(float& a, float& b, float& c, float& d, float& e, float& f, float& g,
+                                                   float& h, float& i) {
+        a = reduce(a); b = reduce(b); c = reduce(c); d = reduce(d); e = reduce(e); f = reduce(f); g = reduce(g);
+        h = reduce(h); i = reduce(i);
+    }
 };
 // GC = 8, entry-major lanes: lane = g * 8 + h sums pixel ROW h of entry g, so the eight partial sums of an entry sit in
 // eight CONSECUTIVE lanes and are combined with three DPP adds (quad_perm xor 1, xor 2, row_half_mirror) -- plain VALU
@@ -99,6 +104,27 @@ template <> struct XLayout<8> {
         x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));  // row_half_mirror
         return x;
     }
+    // The nine (ten) sums of a chunk, three stages of v_add_f32_dpp each.  Written out as ONE asm block because the
+    // compiler folds only some of the update_dpp + add pairs of reduce() (round 4 ISA: 21 v_mov_b32_dpp + 21 v_add_f32
+    // next to 6 fused v_add_f32_dpp, of 100 VALU instructions per chunk in phase B).  Stage by stage over all values: the
+    // DPP read of a register follows its VALU write by N - 1 >= 8 instructions; the s_nop covers the two wait states
+    // the first stage needs after the compiler's own writes (its hazard recognizer does not look into asm).
+#define EXA_DPP3(r) \
+    "v_add_f32_dpp " r ", " r ", " r " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define EXA_DPP4(r) \
+    "v_add_f32_dpp " r ", " r ", " r " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define EXA_DPP5(r) \
+    "v_add_f32_dpp " r ", " r ", " r " row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define EXA_STAGE9(M) M("%0") M("%1") M("%2") M("%3") M("%4") M("%5") M("%6") M("%7") M("%8")
+    __device__ static __forceinline__ void reduce9(float& a, float& b, float& c, float& d, float& e, float& f, float& g,
+                                                   float& h, float& i) {
+        asm("s_nop 1\n" EXA_STAGE9(EXA_DPP3) EXA_STAGE9(EXA_DPP4) EXA_STAGE9(EXA_DPP5)
+            : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h), "+v"(i));
+    }
+#undef EXA_STAGE9
+#undef EXA_DPP3
+#undef EXA_DPP4
+#undef EXA_DPP5
 };
 
 // Without the depth channel the fourth component of a staged float4 is dead, and the compiler narrows the LDS read to
@@ -362,9 +388,7 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             float mxy = fmaf(v0, mx, fmaf(-u0, Sy, Sxy));
             float myy = fmaf(v0, my - Sy, Sy);
             float dop = S0;
-            mx = XL::reduce(mx); my = XL::reduce(my); mxx = XL::reduce(mxx); mxy = XL::reduce(mxy); myy = XL::reduce(myy);
-            dop = XL::reduce(dop);
-            dr = XL::reduce(dr); dg = XL::reduce(dg); db = XL::reduce(db);
+            XL::reduce9(mx, my, mxx, mxy, myy, dop, dr, dg, db);
             if (HAS_DEPTH) dz = XL::reduce(dz);
             if (h == 0 && kk < cend) {
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
