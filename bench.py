@@ -517,10 +517,11 @@ def _timed_replays(ctxs, args, set_view, units_per_step):
 def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024, iters=30):
     """The five renders of one ExAvatar training sample -- scene, human, scene + human, refined human, scene + refined
     human (avatar/main/model.py:119-167; SURVEY.md 8d "ExAvatar-iteration equivalents") -- forward + backward through
-    the drop-in Python surface, EAGER (no hipGraph: the real model's P changes with densification), three ways:
-    five sequential GaussianRenderer calls on torch.cat((scene.detach(), human)) as the reference writes it, the same
-    five as one batched call (render_many), and render_iteration (Gaussian sets shared, detached scene as a constant
-    prefix of the composites).  100 k Dist-C scene + 50 k avatar-like human Gaussians at 1024 x 1024."""
+    the drop-in Python surface, four ways: five sequential GaussianRenderer calls on torch.cat((scene.detach(), human)) as
+    the reference writes it, the same five as one batched call (render_many), render_iteration (Gaussian sets shared, the
+    composites as merges of the plain renders' sorted lists) -- these three EAGER -- and the product class
+    GraphedIteration (render_iteration's kernels replayed from two captured hipGraphs, re-captured when P changes).
+    100 k Dist-C scene + 50 k avatar-like human Gaussians at 1024 x 1024."""
     import exavatar_release_amd as exa
     from exavatar_release_amd import scenes
     keys = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
@@ -536,8 +537,13 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
         rend = exa.GaussianRenderer()
         cat = lambda a, b: {k: torch.cat((a[k].detach(), b[k])) for k in keys}      # noqa: E731
 
+        graphed = exa.GraphedIteration((H, W), device)
+
         def iteration(how):
-            if how == 'sets':
+            if how == 'graphed':
+                res = graphed(scene, human, refined, cam, bg)
+                outs = [res[k] for k in exa.ITERATION_RENDERS]
+            elif how == 'sets':
                 res = exa.render_iteration(rend, scene, human, refined, (H, W), cam, bg)
                 outs = [res[k] for k in exa.ITERATION_RENDERS]
             else:
@@ -551,7 +557,7 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             loss.backward()
         out = {'workload': '%d k Dist-C scene + %d k avatar-like human Gaussians, %dx%d, 5 renders fwd+bwd, eager'
                            % (n_scene // 1000, n_human // 1000, W, H)}
-        for how in ('sequential', 'batched', 'sets'):
+        for how in ('sequential', 'batched', 'sets', 'graphed'):
             # two iterations with the two-stage protocol first: they record the instance count of every render of THIS
             # scene (the capacity memo is keyed on (P, H, W), and the timed C3 runs above used P = 150 k as well)
             exa.config.mode = 'exact'
@@ -574,6 +580,9 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             ms, host_ms = sorted(windows)[1]
             out[how] = {'ms_per_iteration': ms, 'renders_per_s': 5e3 / ms, 'host_ms_per_iteration': host_ms,
                         'windows_ms': [round(w[0], 4) for w in windows]}
+            if how == 'graphed':
+                out[how]['what'] = ('exa.GraphedIteration: one hipGraph for the five forwards, one for their backwards, same '
+                                    'loss in PyTorch between them; captures=%d' % graphed.captures)
         exa.check_overflow()
         return out
     finally:

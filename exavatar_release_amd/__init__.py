@@ -10,8 +10,9 @@ from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, chec
 from .densify import track_densify_stats
 from .losses import SSIM, PhotometricLoss, RGBLoss
 from .renderer import ITERATION_RENDERS, GaussianRenderer, GraphedRenderer, render_iteration, render_many, render_views
+from .graphed import GraphedIteration
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
            'rasterize_gaussians_batch', 'config', 'check_overflow', 'track_densify_stats', 'render_many', 'render_views',
-           'render_iteration', 'ITERATION_RENDERS', 'GraphedRenderer',
+           'render_iteration', 'ITERATION_RENDERS', 'GraphedRenderer', 'GraphedIteration',
            'SSIM', 'RGBLoss', 'PhotometricLoss']

@@ -40,3 +40,99 @@ def track_densify_stats(mean_2d_grad, radius, xyz_grad_accum=None, track_cnt=Non
     with torch.no_grad(), torch.cuda.device(device):
         _lib.check(lib.exa_raster_densify_stats(P, _ptr(g), _ptr(radius), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
                                                 _stream_ptr(device)))
+
+
+# ---- clone / split / prune of a Gaussian set, replicated-safe --------------------------------------------------------
+def synchronised_generator(seed, device):
+    """A ``torch.Generator`` on ``device`` seeded with ``seed``: created with the same seed on every rank of a
+    data-parallel run (and advanced in lockstep: the replicas densify from the same REDUCED statistics), it makes the
+    random samples of :func:`densify_and_prune` -- the reference draws them from the global CUDA RNG,
+    ``torch.normal`` at ``avatar/common/nets/module.py:198`` -- identical on all ranks, so the topology of the replicated
+    Gaussian set never diverges."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    return g
+
+
+def _quat_to_matrix(q):
+    q = q / q.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    w, x, y, z = q.unbind(1)
+    return torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)), 1).view(-1, 3, 3)
+
+
+def densify_and_prune(params, optimizer, grad_accum, track_cnt, *, grad_thr, extent, dense_percent=0.01, opacity_min=0.005,
+                      prune_big=False, split_factor=2, generator=None, rotation_to_matrix=None):
+    """Clone / split / prune one set of Gaussians and carry the optimizer state along -- what the reference's
+    ``SceneGaussian.densify_and_prune`` does with its Adam-state surgery (``avatar/common/nets/module.py:17-72,159-240``),
+    restated for a plain dict of parameters and any ``torch.optim`` optimizer with per-parameter state tensors.
+
+    ``params``: dict name -> ``nn.Parameter`` with first dimension P; needs ``'mean'`` [P, 3], ``'scale'`` [P, 3] (LOG
+    scales, activation ``exp``), ``'rotation'`` ([P, 4] quaternion w, x, y, z -- or give ``rotation_to_matrix``) and
+    ``'opacity'`` [P, 1] (logits, activation ``sigmoid``); every other entry (colours, SH) is carried along.  Each
+    parameter must be the single member of an optimizer group.  ``grad_accum`` / ``track_cnt``: the statistics of
+    :func:`track_densify_stats` (already reduced over the ranks: ``dist.reduce_densify_stats``).
+
+    Order of events as in the reference: mean screen-space gradient ``>= grad_thr`` selects; small ones (max scale
+    ``<= dense_percent * extent``) are CLONED, large ones SPLIT into ``split_factor`` samples of their own Gaussian (scale
+    divided by ``0.8 * split_factor``) and removed; then everything with opacity ``< opacity_min`` (and, with
+    ``prune_big``, max scale ``> 0.1 * extent``) is pruned.  Row order of the result: surviving originals, clones,
+    split samples.  New rows start with zero optimizer state.  ``generator``: see :func:`synchronised_generator`.
+
+    Returns ``(new_params, n_cloned, n_split, n_pruned)``; the caller allocates fresh statistics of the new length (the
+    reference zeroes them in ``densify``, module.py:223-225)."""
+    mean, scale, rot, opac = params['mean'], params['scale'], params['rotation'], params['opacity']
+    P0 = mean.shape[0]
+    with torch.no_grad():
+        g = torch.nan_to_num(grad_accum.reshape(-1) / track_cnt.reshape(-1))
+        big = torch.exp(scale).max(1).values > dense_percent * extent
+        hot = g >= grad_thr
+        clone_rows = torch.nonzero(hot & ~big).flatten()
+        split_rows = torch.nonzero(hot & big).flatten()
+        keep_rows = torch.nonzero(~(hot & big)).flatten()
+        rep = split_rows.repeat(split_factor)
+        std = torch.exp(scale[rep])
+        noise = torch.randn(std.shape, generator=generator, device=std.device, dtype=std.dtype) * std
+        R = (rotation_to_matrix or _quat_to_matrix)(rot[rep])
+        new = {}
+        for name, p in params.items():
+            parts = [p[keep_rows], p[clone_rows]]
+            if name == 'mean':
+                parts.append(torch.bmm(R, noise[:, :, None])[:, :, 0] + p[rep])
+            elif name == 'scale':
+                parts.append(torch.log(torch.exp(p[rep]) / (0.8 * split_factor)))
+            else:
+                parts.append(p[rep])
+            new[name] = torch.cat(parts)
+        # rows of the ORIGINAL set each new row descends from with its optimizer state (-1: a new row, zero state)
+        src = torch.cat((keep_rows, torch.full((clone_rows.numel() + rep.numel(),), -1, dtype=torch.long, device=keep_rows.device)))
+        drop = torch.sigmoid(new['opacity'])[:, 0] < opacity_min
+        if prune_big:
+            drop |= torch.exp(new['scale']).max(1).values > 0.1 * extent
+        valid = ~drop
+        src = src[valid]
+        out = {}
+        for group in optimizer.param_groups:
+            if len(group['params']) != 1:
+                continue
+            old = group['params'][0]
+            name = next((n for n, p in params.items() if p is old), None)
+            if name is None:
+                continue
+            fresh = torch.nn.Parameter(new[name][valid].contiguous().requires_grad_(True))
+            state = optimizer.state.pop(old, None)
+            if state is not None:
+                for k, v in list(state.items()):
+                    if isinstance(v, torch.Tensor) and v.dim() > 0 and v.shape[0] == P0:
+                        nv = torch.zeros((src.numel(),) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+                        old_rows = src >= 0
+                        nv[old_rows] = v[src[old_rows]]
+                        state[k] = nv
+                optimizer.state[fresh] = state
+            group['params'][0] = fresh
+            out[name] = fresh
+        missing = [n for n in params if n not in out]
+        if missing:
+            raise ValueError('densify_and_prune: parameters %s are not single members of an optimizer group' % missing)
+    return out, int(clone_rows.numel()), int(split_rows.numel()), int(drop.sum())

@@ -1,0 +1,427 @@
+"""hipGraph-captured training iteration: the five same-camera renders of one ExAvatar training sample
+(reference ``avatar/main/model.py:119-167``) forward AND backward, as a product class.
+
+The reference's training loop (``avatar/main/train.py:41-57``) issues five ``GaussianRenderer`` calls per sample and one
+``backward``; through the eager drop-in surface that is ~0.9 ms per iteration with the host as busy as the GPU
+(autograd nodes, ~60 launches, allocator calls).  The number of Gaussians only changes when the scene is densified or
+pruned (every 100 iterations, ``avatar/main/config.py:17-20``; the human's count never changes), the image size and the
+focal length practically never: between two such events every iteration launches the SAME kernels on the SAME buffers.
+:class:`GraphedIteration` captures them once -- one hipGraph for the five forwards, one for their backwards -- and
+replays them per iteration::
+
+    it = GraphedIteration((H, W), device)
+    for data in loader:
+        out = it(scene_asset, human_asset, human_asset_refined, cam_param, bg, scene_densify_stats)   # dict like render_iteration's
+        loss = my_losses(out, data)              # any PyTorch code: L1 / SSIM / LPIPS / PhotometricLoss ...
+        loss.backward()                          # gradients reach the asset tensors (and out[...]['mean_2d'].grad)
+        optimizer.step()
+
+What a call does: copy the asset tensors into the graph's static inputs (one fused multi-tensor copy), write the camera
+block with one kernel from the device-resident ``R`` / ``t`` (``exa_raster_camera_block``), replay the forward graph.
+``backward`` copies the incoming image gradients into static buffers, replays the backward graph and hands out one
+clone of the flat gradient buffer.  The asset tensors may be leaves or the outputs of networks (the reference's are:
+``SceneGaussian.forward`` / ``HumanGaussian.forward``); autograd continues into whatever produced them.
+
+Re-capture happens when P of a set changes (densify / prune), the colour input changes (rgb <-> sh), tan(fov) changes,
+a render needs more tile instances than its buffer holds (the plain renders report ``{needed, overflow}`` into reserved
+pinned-host slots ~35 us into the replay; they are polled right after the replay is queued -- the GPU is busy with the
+rest of the forward meanwhile -- and an overflowed iteration is re-captured with enough room and rendered again BEFORE
+the call returns: the images handed out are always complete, same contract as the eager path's
+``config.overflow_check = 'forward'``), or the densification-statistics tensors are replaced.  Results are bit-identical
+to eager :func:`renderer.render_iteration` (same kernels, same order; tests/test_gpu_graphed_iteration.py).
+
+The returned images alias the graph's static outputs: valid until the next call (clone what must survive).
+"""
+import time
+
+import torch
+
+from . import rasterizer as rz
+from .renderer import ITERATION_RENDERS, _sh_degree, camera_block_device, render_iteration
+
+_ASSET_KEYS = ('mean_3d', 'scale', 'rotation', 'opacity')
+_IMG_ONLY = (True, False, False) * 5
+_SETS = ('scene', 'human', 'human_refined')
+
+
+def _colour_key(asset):
+    return 'rgb' if _sh_degree(asset) is None else 'sh'
+
+
+class _Captured:
+    """Everything one capture owns (replaced as a whole on re-capture)."""
+    __slots__ = ('key', 'inputs', 'in_list', 'in_raw', 'probes', 'tan', 'fwd', 'pool', 'outs', 'out_list', 'radii', 'bwd',
+                 'slots', 'caps', 'dens_ptrs', 'sizes', 'diff_inputs')
+
+
+class _IterFn(torch.autograd.Function):
+    """Autograd boundary of a replayed iteration.  apply(owner, cap, *asset tensors [15], *probes [5]) -> 15 image planes
+    (img, depthmap, mask of the five renders) + 5 radii."""
+
+    @staticmethod
+    def forward(ctx, owner, cap, *tensors):
+        ctx.owner, ctx.cap = owner, cap
+        ctx.set_materialize_grads(False)
+        # Aliases of the static outputs: no copies (they are overwritten by the next replay).  Detached, because the static
+        # tensors carry the autograd graph of the CAPTURED call, which the backward graphs were recorded from and which
+        # must not be re-parented onto this node.
+        outs = tuple(o.detach() for o in cap.out_list) + tuple(r.detach() for r in cap.radii)
+        ctx.mark_non_differentiable(*outs[15:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        owner = ctx.owner
+        cap = owner._cap
+        if cap is not ctx.cap:
+            raise RuntimeError('exavatar_release_amd: GraphedIteration.backward after a later call replaced its capture '
+                               '(call backward before the next iteration)')
+        flat = owner._backward(grads[:15])
+        outs = []
+        off = 0
+        for need, n, shape in zip(ctx.needs_input_grad[2:], cap.sizes, cap.diff_inputs):
+            outs.append(flat[off:off + n].view(shape) if need else None)
+            off += n
+        return (None, None) + tuple(outs)
+
+
+class GraphedIteration:
+    """See the module docstring.  ``merge``: composites as list merges (default) or as constant-prefix renders, as in
+    :func:`renderer.render_iteration`.  ``capacity_growth``: head-room of the instance buffers over what the first
+    iteration of a capture needed.  ``check``: poll the overflow reports after every forward replay; switch off only when
+    the capacities are known to be sufficient.  ``capacities``: instance capacities
+    of the three plain renders (scene, human, refined human) for the FIRST capture instead of measuring them with an eager
+    iteration.  Counters: ``captures``, ``overflow_retries``."""
+
+    def __init__(self, img_shape, device, merge=True, capacity_growth=1.5, check=True, capacities=None):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise RuntimeError('exavatar_release_amd: GraphedIteration runs on a ROCm device only')
+        self.shape, self.device = (int(img_shape[0]), int(img_shape[1])), device
+        self.merge, self.growth, self.check = bool(merge), float(capacity_growth), bool(check)
+        self._cam = torch.zeros(38, dtype=torch.float32, device=device)   # viewmatrix 16 | projmatrix 16 | campos 3 | bg 3:
+        #                                                                   outlives the captures, which read views of it
+        self._cap = None
+        self._caps_hint = None if capacities is None else [int(c) for c in capacities]   # capacities of the next capture
+        self._intr, self._focal_src, self._focal_ver = None, None, None
+        self._bg_src, self._bg_ver = None, None
+        self._last_needs = None         # (P_scene, P_human, needs of the three plain renders) of the last checked iteration
+        self._reports_checked = True
+        self.captures = 0
+        self.overflow_retries = 0
+
+    # ---- capture ---------------------------------------------------------------------------------------------------
+    def _release(self):
+        cap, self._cap = self._cap, None
+        if cap is not None and cap.slots and rz._hdr_pool is not None:
+            for s in cap.slots:
+                if s is not None:
+                    rz._hdr_pool.release(s[0])
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _static_like(self, assets):
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = {}
+        for name, a in zip(_SETS, assets):
+            ck = _colour_key(a)
+            d = {k: torch.zeros(tuple(a[k].shape), **f32).requires_grad_(True) for k in _ASSET_KEYS + (ck,)}
+            if ck == 'sh' and a.get('sh_degree') is not None:
+                d['sh_degree'] = int(a['sh_degree'])
+            out[name] = d
+        return out
+
+    def _render(self, cap, dens):
+        c = self._cam
+        block = (cap.tan[0], cap.tan[1], c[0:16].view(4, 4), c[16:32].view(4, 4), c[32:35])
+        i = cap.inputs
+        return render_iteration(None, i['scene'], i['human'], i['human_refined'], self.shape, None, c[35:38], dens,
+                                merge=self.merge, cam_block=block, probes=cap.probes)
+
+    def _capture(self, assets, tan, dens, key):
+        dev = self.device
+        self._release()
+        cap = _Captured()
+        cap.key, cap.tan, cap.slots = key, tan, []
+        cap.inputs = self._static_like(assets)
+        cap.in_list = [cap.inputs[n][k] for n, a in zip(_SETS, assets) for k in _ASSET_KEYS + (_colour_key(a),)]
+        # The per-iteration values are written through `.data` aliases (same storage, their own version counters): the
+        # captured autograd graph saved the static leaves for its backward, and a copy_ that bumped THEIR counters would
+        # make a later recording of another backward pattern fail the saved-tensor check although nothing is stale (the
+        # kernels read the buffers at replay time).
+        cap.in_raw = [t.data for t in cap.in_list]
+        Ps, Ph = cap.inputs['scene']['mean_3d'].shape[0], cap.inputs['human']['mean_3d'].shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        cap.probes = [torch.zeros((n, 3), **f32).requires_grad_(True) for n in (Ps, Ph, Ph, Ph, Ph)]
+        cap.dens_ptrs = None if dens is None else tuple(None if t is None else t.data_ptr() for t in dens)
+        cap.diff_inputs = [tuple(t.shape) for t in cap.in_list + cap.probes]
+        cap.sizes = [t.numel() for t in cap.in_list + cap.probes]
+        self._fill_inputs(cap, assets)
+        saved = (rz.config.mode, rz.config.fixed_capacity)
+        try:
+            with torch.enable_grad():
+                # Capacities of the three plain renders (scene, human, refined human).  After an overflow: what the reports
+                # asked for.  After a change of P (densify / prune): the last measured needs scaled by the change -- a
+                # re-capture then costs two recordings, no eager pass, and an estimate that turns out too small is caught
+                # by the overflow reports like any other.  Otherwise one eager iteration with the two-stage protocol.
+                caps = self._caps_hint
+                if caps is None and self._last_needs is not None:
+                    ps0, ph0, n0 = self._last_needs
+                    rs, rh = Ps / max(ps0, 1), Ph / max(ph0, 1)
+                    caps = [int(n0[0] * max(rs, 1.0) * self.growth), int(n0[1] * max(rh, 1.0) * self.growth),
+                            int(n0[2] * max(rh, 1.0) * self.growth)]
+                if caps is None:
+                    rz.config.mode, rz.config.fixed_capacity = 'exact', None
+                    self._render(cap, None)
+                    torch.cuda.synchronize(dev)
+                    H, W = self.shape
+                    need = [rz._seen_D.get((dev.index, P, H, W), 0) for P in (Ps, Ph, Ph)]
+                    caps = [int(n * self.growth) for n in need]
+                caps = [max(c, 64) for c in caps]
+                if not self.merge:           # five jobs: scene, human, scene + human, refined, scene + refined
+                    caps = [caps[0], caps[1], caps[0] + caps[1], caps[2], caps[0] + caps[2]]
+                caps = [(c + 63) // 64 * 64 for c in caps]
+                cap.caps = caps
+                rz.config.mode, rz.config.fixed_capacity = 'capacity', list(caps)
+                if self.captures == 0:
+                    # once per object: a warm-up on a side stream (as torch.cuda.graph asks for), forward + backward
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        res = self._render(cap, None)
+                        torch.autograd.grad([res[k]['img'] for k in ITERATION_RENDERS], cap.in_list,
+                                            grad_outputs=[torch.ones_like(res[k]['img']) for k in ITERATION_RENDERS], allow_unused=True)
+                        del res
+                    torch.cuda.current_stream(dev).wait_stream(side)
+                    torch.cuda.synchronize(dev)
+                    rz.check_overflow_quiet()
+                # header reports of the plain renders go to reserved pinned-host slots (outside the ring eager calls use)
+                pool = rz._pool()
+                n_jobs = 3 if self.merge else 5
+                cap.slots = [None] * n_jobs
+                if pool is not None:
+                    for k in range(n_jobs):
+                        got = pool.reserve()
+                        cap.slots[k] = None if got is None else (got[0], got[1])
+                cap.pool = torch.cuda.graph_pool_handle()
+                cap.fwd = torch.cuda.CUDAGraph()
+                rz._capture_report = cap.slots
+                try:
+                    with torch.cuda.graph(cap.fwd, pool=cap.pool):
+                        res = self._render(cap, dens)
+                finally:
+                    rz._capture_report = None
+                cap.outs = res
+                cap.out_list = [res[k][n] for k in ITERATION_RENDERS for n in ('img', 'depthmap', 'mask')]
+                cap.radii = [res[k]['radius'] for k in ITERATION_RENDERS]
+                cap.bwd = {}
+                self.captures += 1
+        finally:
+            rz.config.mode, rz.config.fixed_capacity = saved
+        # the backward graph of the usual case -- gradients for the five colour images only -- is
+        # recorded right away; other patterns (depth / mask gradients, fewer images) on first use
+        self._capture_backward(cap, _IMG_ONLY)
+        self._cap = cap
+        return cap
+
+    def _capture_backward(self, cap, pattern):
+        """Backward graph for the set of outputs that receive a gradient (``pattern``: 15 booleans)."""
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_in = [torch.zeros_like(o) if on else None for o, on in zip(cap.out_list, pattern)]
+        outs = [o for o, on in zip(cap.out_list, pattern) if on]
+        gos = [g for g in g_in if g is not None]
+        inputs = cap.in_list + cap.probes
+        flat = torch.zeros(sum(cap.sizes), **f32)
+        saved = (rz.config.mode, rz.config.fixed_capacity)
+        try:
+            rz.config.mode, rz.config.fixed_capacity = 'capacity', list(cap.caps)
+            with torch.enable_grad():
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=cap.pool):
+                    grads = torch.autograd.grad(outs, inputs, grad_outputs=gos, allow_unused=True, retain_graph=True)
+                    off = 0
+                    for gr, n in zip(grads, cap.sizes):
+                        if gr is not None:            # (elementwise kernels only: memcpy / memset nodes are not replay-safe)
+                            torch.mul(gr.reshape(-1), 1.0, out=flat[off:off + n])
+                        off += n
+                unused = [gr is None for gr in grads]
+        finally:
+            rz.config.mode, rz.config.fixed_capacity = saved
+        cap.bwd[pattern] = (g, g_in, flat, unused)
+        return cap.bwd[pattern]
+
+    # ---- per call --------------------------------------------------------------------------------------------------
+    def _fill_inputs(self, cap, assets):
+        with torch.no_grad():
+            src = [a[k] for a in assets for k in _ASSET_KEYS + (_colour_key(a),)]
+            for d, s_ in zip(cap.in_list, src):
+                if tuple(d.shape) != tuple(s_.shape):
+                    raise ValueError('GraphedIteration: asset tensor of shape %s, captured for %s' % (tuple(s_.shape), tuple(d.shape)))
+            torch._foreach_copy_(cap.in_raw, [s_.detach() for s_ in src])
+
+    def _camera(self, cam_param):
+        """Write the camera block; returns (tan, check) with check = None or (pool, slot, tag) to poll after the replay."""
+        cap_cam = self._cam
+        f = cam_param['focal']
+        pool = rz._pool()
+        trusted = self._intr is not None and f is self._focal_src and getattr(f, '_version', None) == self._focal_ver
+        flag = chk = None
+        if self._intr is not None and not trusted and pool is not None:
+            fslot, ftag, faddr = pool.take()
+            flag, chk = (faddr, ftag), (pool, fslot, ftag)
+        intr, checking = camera_block_device(cam_param, self.shape, cap_cam, self._intr if flag else None, flag)
+        if not checking:
+            self._intr, self._focal_src, self._focal_ver = intr, f, getattr(f, '_version', None)
+            chk = None
+        return (intr[0], intr[1]), chk
+
+    def _focal_ok(self, chk, f):
+        pool, fslot, ftag = chk
+        w, b = pool.words, 4 * fslot
+        t_end = time.perf_counter() + 5e-3
+        while w[b + 3] != ftag and time.perf_counter() < t_end:
+            pass
+        if w[b + 3] != ftag:
+            torch.cuda.current_stream(self.device).synchronize()
+        if w[b + 3] != ftag or w[b] != 1:
+            self._intr = None
+            return False
+        self._focal_src, self._focal_ver = f, getattr(f, '_version', None)
+        return True
+
+    def _reset_reports(self, cap):
+        if rz._hdr_pool is not None:
+            w = rz._hdr_pool.words
+            for s in cap.slots:
+                if s is not None:
+                    w[4 * s[0] + 3] = 0
+
+    def _overflowed(self, cap):
+        """Wait for the header reports of the last forward replay; returns None or the capacities the renders need."""
+        if not self.check or self._reports_checked:
+            return None
+        self._reports_checked = True
+        w = rz._hdr_pool.words if rz._hdr_pool is not None else None
+        needs, over = [], False
+        for k, s in enumerate(cap.slots):
+            if s is None or w is None:
+                torch.cuda.current_stream(self.device).synchronize()
+                need, ovf = self._device_header(cap, k)
+            else:
+                b = 4 * s[0]
+                t_end = time.perf_counter() + 5e-3
+                while w[b + 3] != s[1] and time.perf_counter() < t_end:
+                    pass
+                if w[b + 3] != s[1]:
+                    torch.cuda.current_stream(self.device).synchronize()
+                if w[b + 3] == s[1]:
+                    need, ovf = int(w[b]), int(w[b + 1])
+                else:
+                    need, ovf = self._device_header(cap, k)
+            needs.append(need)
+            over = over or bool(ovf)
+        n3 = needs if self.merge else [needs[0], needs[1], needs[3]]
+        self._last_needs = (cap.sizes[0] // 3, cap.sizes[5] // 3, n3)
+        return needs if over else None
+
+    def _device_header(self, cap, k):
+        raise RuntimeError('exavatar_release_amd: GraphedIteration needs pinned host memory mapped for the device '
+                           '(header reports); use the eager render_iteration on this system')
+
+    def _replay_forward(self, assets, cam_param, bg, dens, refill):
+        """(Re-)capture if needed, fill the static inputs, replay the forward graph.  Returns the capture."""
+        dev = self.device
+        key = tuple((tuple(a['mean_3d'].shape), _colour_key(a), tuple(a[_colour_key(a)].shape)) for a in assets)
+        dens_ptrs = None if dens is None else tuple(None if t is None else t.data_ptr() for t in dens)
+        for _ in range(4):
+            cap = self._cap
+            # camera first: tan(fov) is part of the capture key
+            tan, chk = self._camera(cam_param)
+            if self._bg_src is not bg or self._bg_ver != getattr(bg, '_version', None):
+                with torch.no_grad():
+                    torch.mul(torch.as_tensor(bg, dtype=torch.float32, device=dev).reshape(-1), 1.0, out=self._cam[35:38])
+                self._bg_src, self._bg_ver = bg, getattr(bg, '_version', None)
+            if cap is None or cap.key != key or cap.tan != tan or cap.dens_ptrs != dens_ptrs:
+                try:
+                    cap = self._capture(assets, tan, dens, key)
+                finally:
+                    self._caps_hint = None
+            elif refill:
+                self._fill_inputs(cap, assets)
+            self._reset_reports(cap)
+            cap.fwd.replay()
+            self._reports_checked = False
+            if chk is not None and not self._focal_ok(chk, cam_param['focal']):
+                continue                      # the focal length changed: derive the intrinsics again, maybe re-capture
+            return cap
+        raise RuntimeError('exavatar_release_amd: GraphedIteration could not settle its camera intrinsics')
+
+    def __call__(self, scene_asset, human_asset, human_asset_refined, cam_param, bg=None, scene_densify_stats=None):
+        dev = self.device
+        assets = (scene_asset, human_asset, human_asset_refined)
+        modes = {_colour_key(a) for a in assets}
+        if len(modes) != 1:
+            raise ValueError('GraphedIteration: scene, human and refined human must carry the same colour input (rgb or sh)')
+        if bg is None:
+            bg = torch.ones(3, dtype=torch.float32, device=dev)
+        dens = scene_densify_stats
+        if dens is not None:
+            dens = rz._check_densify(dens, int(scene_asset['mean_3d'].shape[0]), dev)
+        with rz._on_device(dev):
+            self._args = (assets, cam_param, bg, dens)
+            cap = self._replay_forward(assets, cam_param, bg, dens, refill=True)
+            needs = self._overflowed(cap)
+            while needs is not None:          # repaired before anybody can read the outputs
+                cap = self._grow(needs)
+                needs = self._overflowed(cap)
+            grad = torch.is_grad_enabled() and any(a[k].requires_grad for a in assets for k in _ASSET_KEYS + (_colour_key(a),))
+            if not grad:
+                outs, radii = [o.detach() for o in cap.out_list], [r.detach() for r in cap.radii]
+                probes = [None] * 5
+            else:
+                # fresh leaves per iteration that alias the (never written, never read) static probes: their .grad is what
+                # the reference reads after backward (avatar/main/train.py:51)
+                probes = [p.detach().requires_grad_(True) for p in cap.probes]
+                src = [a[k] for a in assets for k in _ASSET_KEYS + (_colour_key(a),)]
+                res = _IterFn.apply(self, cap, *src, *probes)
+                outs, radii = res[:15], res[15:]
+        out = {}
+        for i, name in enumerate(ITERATION_RENDERS):
+            out[name] = {'img': outs[3 * i], 'depthmap': outs[3 * i + 1], 'mask': outs[3 * i + 2], 'mean_2d': probes[i],
+                         'is_vis': radii[i] > 0, 'radius': radii[i]}
+        return out
+
+    def _grow(self, needs):
+        """An instance buffer was too small: re-capture with room for ``needs`` and render the iteration again."""
+        old = self._cap
+        n3 = needs if self.merge else [needs[0], needs[1], needs[3]]
+        c3 = old.caps if self.merge else [old.caps[0], old.caps[1], old.caps[3]]
+        self._caps_hint = [max(int(n * self.growth), c) if n > c else c for n, c in zip(n3, c3)]
+        self.overflow_retries += 1
+        rz._record_overflow(('graphed_iteration',) + tuple(old.key), max(needs), max(old.caps), 'retried')
+        assets, cam_param, bg, dens = self._args
+        self._release()
+        return self._replay_forward(assets, cam_param, bg, dens, refill=False)
+
+    def _backward(self, grads):
+        """Replay the backward graph for the incoming image gradients; returns a private flat gradient buffer."""
+        dev = self.device
+        with rz._on_device(dev):
+            cap = self._cap
+            pattern = tuple(g is not None for g in grads)
+            if not any(pattern):
+                return torch.zeros(sum(cap.sizes), dtype=torch.float32, device=dev)
+            entry = cap.bwd.get(pattern) or self._capture_backward(cap, pattern)
+            g, g_in, flat, _unused = entry
+            with torch.no_grad():
+                dst = [d for d in g_in if d is not None]
+                src = [s_ if (s_.dtype == torch.float32 and s_.shape == d.shape) else s_.to(torch.float32).expand(d.shape)
+                       for s_, d in zip([s_ for s_ in grads if s_ is not None], dst)]
+                torch._foreach_copy_(dst, src)
+            g.replay()
+            return flat.clone()

@@ -40,14 +40,22 @@ background only and its backward writes zero gradients.  ``config.on_overflow``:
   are re-rendered when their report is drained (next call or :func:`check_overflow`).
 * ``'raise'``: ``RuntimeError`` instead (from ``backward``, :func:`check_overflow` or a later call).
 
-``config.overflow_check`` decides whether ``backward`` WAITS for a report that has not landed yet:
-``'always'`` (default) does -- the report is written ~35 us into the forward, so by the time autograd
-reaches the render's backward it has normally landed and the wait costs nothing; backward therefore
-NEVER returns the gradients of an overflowed render.  ``'adaptive'`` (opt-in, for loops that cannot
-afford any host wait) waits during the first ``config.verify_calls`` calls of a shape and whenever
-the last known D filled more than ``config.danger_fill`` of the buffer, and otherwise leaves the
-report to be drained later: an overflow found after its backward has returned ZERO gradients can
-only be recorded -- the capacity memo grows -- and warned about (``'late'`` in ``overflow_events``).
+``config.overflow_check`` decides WHEN the report is looked at:
+
+* ``'forward'`` (default): at the end of the render's own ``forward`` -- the report is written ~35 us
+  into the forward's kernels, about when the host has finished queueing them, so the poll costs a
+  few microseconds and no synchronisation; an overflowed render is repaired THERE, before anybody
+  can read its outputs: capacity mode then returns exactly what ``'exact'`` returns, images,
+  losses computed from them and gradients alike, always (tests/test_gpu_soak.py trains 300
+  iterations both ways to bit-identical parameters).
+* ``'always'``: in the render's ``backward`` (the forward never waits): backward never returns the
+  gradients of an overflowed render, but a loss that was computed from the incomplete image is stale
+  for that step (warned about).
+* ``'adaptive'`` (opt-in, for loops that cannot afford any host wait): like ``'always'`` during the
+  first ``config.verify_calls`` calls of a shape and whenever the last known D filled more than
+  ``config.danger_fill`` of the buffer; otherwise the report is left to be drained later: an overflow
+  found after its backward has returned ZERO gradients can only be recorded -- the capacity memo
+  grows -- and warned about (``'late'`` in ``overflow_events``).
 
 A render that nobody differentiates (``no_grad``, a skipped step) is repaired when its report is
 drained -- by a later call or :func:`check_overflow` -- from the input tensors as they are THEN: if
@@ -85,10 +93,11 @@ class _Config:
     mode = 'auto'             # 'auto' | 'exact' | 'capacity'
     capacity_growth = 1.5     # capacity mode: head-room over the largest D seen so far
     min_capacity = 1 << 16
-    fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up)
+    fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up); a list /
+    #                           tuple names one capacity per job of a batched call
     keep_debug = False        # developer probes: keep the workspaces of the most recent forward reachable
     on_overflow = 'retry'     # 'retry' | 'raise'
-    overflow_check = 'always'     # 'always' | 'adaptive': does backward wait for a header report that has not landed?
+    overflow_check = 'forward'    # 'forward' | 'always' | 'adaptive': where the header report is looked at (module docstring)
     verify_calls = 4          # adaptive: the first calls of a shape wait for their report
     danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
     upstream_scale_grad = False   # True: dL/dscale as upstream returns it (w.r.t. scale_modifier * scale, i.e. divided
@@ -346,9 +355,10 @@ def _rerender(j, need, store_ctx, device):
         _lib.check(lib.exa_raster_forward_batch(arr, 1, int(store_ctx), _stream_ptr(device)))
 
 
-def _consume(rec, block, from_backward=False):
+def _consume(rec, block, from_backward=False, in_forward=False):
     """Look at the reports of ``rec``; handle overflows.  Returns True when every report was consumed.
-    ``from_backward``: the caller is the render's own backward (it may still repair the context)."""
+    ``from_backward``: the caller is the render's own backward (it may still repair the context); ``in_forward``: its own
+    forward, before the outputs were handed out (nothing can have read the incomplete image)."""
     all_done = True
     msgs = []
     for k, (j, rep) in enumerate(zip(rec.jobs, rec.reports)):
@@ -380,10 +390,11 @@ def _consume(rec, block, from_backward=False):
         stale = tuple(t._version for t in (j.means3D, j.sh, j.colors, j.opac, j.scales, j.rot, j.cov) if t is not None) != j.versions
         _rerender(j, need, rec.store_ctx, rec.device)
         _record_overflow(j.key, need, old, 'retried')
-        warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d: re-rendered with '
-                      'enough room (outputs corrected in place; work that already read the incomplete image -- the loss '
-                      'value of this step -- is not).%s' % (need, old, ' Its input tensors were modified in place since the '
-                      'forward: the corrected image shows their CURRENT values.' if stale else ''), RuntimeWarning)
+        if not in_forward:       # (repaired inside its own forward: nobody saw the incomplete outputs, nothing to warn about)
+            warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d: re-rendered with '
+                          'enough room (outputs corrected in place; work that already read the incomplete image -- the loss '
+                          'value of this step -- is not).%s' % (need, old, ' Its input tensors were modified in place since '
+                          'the forward: the corrected image shows their CURRENT values.' if stale else ''), RuntimeWarning)
     if all_done:
         rec.done = True
     if msgs:
@@ -611,7 +622,8 @@ class _Rasterize(torch.autograd.Function):
                 j.bins = None
                 if mode == 'capacity':
                     if config.fixed_capacity is not None:
-                        cap = int(config.fixed_capacity)
+                        fc = config.fixed_capacity
+                        cap = int(fc[k] if isinstance(fc, (list, tuple)) else fc)
                     else:
                         cap = max(int(_seen_D[j.key] * config.capacity_growth), config.min_capacity)
                     j.capacity = (cap + 63) // 64 * 64
@@ -662,6 +674,17 @@ class _Rasterize(torch.autograd.Function):
                         for j in jobs:
                             j.rec = wr
 
+        if rec is not None and config.overflow_check == 'forward':
+            # the report landed about when the last launch above was queued: poll it now and repair an overflowed render
+            # before its outputs leave this function
+            with _on_device(device):
+                if _consume(rec, True, from_backward=True, in_forward=True):
+                    for j in rec.jobs:
+                        _verified[j.key] = _verified.get(j.key, 0) + 1
+                    try:
+                        _pending.remove(rec)
+                    except ValueError:
+                        pass
         if config.keep_debug:
             j = jobs[-1]
             _debug_last['tile'] = j.ws[j.gb:j.gb + j.tb]

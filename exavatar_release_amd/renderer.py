@@ -146,9 +146,12 @@ def _sh_degree(gaussian_assets):
     return deg
 
 
-def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, frozen_assets=None):
+def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, frozen_assets=None, cam_block=None,
+                mean_2d=None):
     """Settings tuple + rasterizer keyword arguments of one render, built exactly as module.py:594-640 does.
     ``frozen_assets``: constant Gaussians blended together with ``gaussian_assets`` (render_many / render_iteration).
+    ``cam_block``: a ready ``(tanfovx, tanfovy, viewmatrix, projmatrix, campos)`` instead of ``cam_param`` (device tensors
+    a captured hipGraph keeps reading: :class:`graphed.GraphedIteration`); ``mean_2d``: the screen-space probe to use.
     Beyond the reference: assets with ``sh`` [P, M, 3] (and no ``rgb``) are coloured IN the rasterizer -- the reference
     evaluates ``clamp_min(eval_sh(...) + 0.5, 0)`` in PyTorch first (module.py:258-266) and passes ``rgb``."""
     mean_3d = gaussian_assets['mean_3d']
@@ -157,7 +160,8 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
     if bg is None:
         bg = torch.ones((3), dtype=torch.float32, device=device)
 
-    tanfovx, tanfovy, view_matrix, full_proj_matrix, cam_pos = _camera_block(cam_param, img_shape, device)
+    tanfovx, tanfovy, view_matrix, full_proj_matrix, cam_pos = cam_block if cam_block is not None else \
+        _camera_block(cam_param, img_shape, device)
     raster_settings = GaussianRasterizationSettings(
         image_height=img_shape[0],
         image_width=img_shape[1],
@@ -175,7 +179,8 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
     # screen-space position probe for the densification gradient (module.py:626-629: zeros, requires_grad, retain_grad).
     # The rasterizer never reads its VALUES (only its .grad is produced), so every render gets a fresh leaf that aliases one
     # cached block of zeros instead of paying an allocation + a fill kernel per render (retain_grad is a no-op on a leaf).
-    mean_2d = _zero_probe(mean_3d.shape[0], device)
+    if mean_2d is None:
+        mean_2d = _zero_probe(mean_3d.shape[0], device)
     frozen = None
     if frozen_assets is not None:
         if (_sh_degree(frozen_assets) is None) != (sh_degree is None):
@@ -260,7 +265,7 @@ ITERATION_RENDERS = ('scene', 'human', 'scene_human', 'human_refined', 'scene_hu
 
 
 def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, img_shape, cam_param, bg,
-                     scene_densify_stats=None, merge=True):
+                     scene_densify_stats=None, merge=True, cam_block=None, probes=None):
     """The five same-camera renders of one ExAvatar training sample (``avatar/main/model.py:119-167``) as ONE batched
     call with the Gaussian SETS shared between them:
 
@@ -282,6 +287,12 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
     ``scene_densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` updated by the scene render's backward
     (``model.py:279-285``).  Returns a dict of the five output dicts keyed by :data:`ITERATION_RENDERS`.
 
+    Shapes (both formulations): a composite's ``radius`` / ``is_vis`` cover ``cat(scene, human)`` (P_scene + P_human rows, as
+    the reference's concatenated render returns them) while its ``mean_2d`` probe has the HUMAN's rows only (the scene is a
+    constant there and gets no screen-space gradient); the reference reads only ``img`` of the composites.
+    ``cam_block`` / ``probes``: see :func:`_raster_job` (``probes``: five ``mean_2d`` tensors in the order of
+    :data:`ITERATION_RENDERS`), used by :class:`graphed.GraphedIteration`.
+
     ``merge=True`` (default): the two composites are not binned at all.  ``scene``, ``human`` and ``human_refined`` are
     three jobs of one batched call whose sorts keep their keys; ``scene_human`` / ``scene_human_refined`` are COMPOSITE
     renders (``exa_raster_forward_compose_batch``, csrc/compose.hip) that reuse those renders' splat records and MERGE their
@@ -292,25 +303,32 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
     device = scene_asset['mean_3d'].device
     if device.type != 'cuda':
         raise RuntimeError('exavatar_release_amd: render_iteration runs on a ROCm device only')
-    if merge and (_sh_degree(scene_asset) is None) == (_sh_degree(human_asset) is None) and scene_asset['mean_3d'].shape[0] > 0 \
+    modes = {_sh_degree(a) is None for a in (scene_asset, human_asset, human_asset_refined)}
+    if len(modes) != 1:
+        raise ValueError('render_iteration: scene, human and refined human must all carry the same colour input (rgb or sh)')
+    pr = probes if probes is not None else (None,) * 5
+    kw = dict(cam_block=cam_block)
+    if merge and scene_asset['mean_3d'].shape[0] > 0 \
             and human_asset['mean_3d'].shape[0] > 0 and human_asset_refined['mean_3d'].shape[0] > 0:
         # three plain renders whose sorts keep their keys ...
-        plain = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats),
-                 _raster_job(human_asset, img_shape, cam_param, bg),
-                 _raster_job(human_asset_refined, img_shape, cam_param, bg)]
+        plain = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats, mean_2d=pr[0], **kw),
+                 _raster_job(human_asset, img_shape, cam_param, bg, mean_2d=pr[1], **kw),
+                 _raster_job(human_asset_refined, img_shape, cam_param, bg, mean_2d=pr[3], **kw)]
         outs, handles = rasterize_gaussians_batch(plain, keep_keys=True)
         # ... and the two composites as MERGES of their sorted lists (white background, as the reference renders them)
-        comp = [_raster_job(human_asset, img_shape, cam_param, None), _raster_job(human_asset_refined, img_shape, cam_param, None)]
+        comp = [_raster_job(human_asset, img_shape, cam_param, None, mean_2d=pr[2], **kw),
+                _raster_job(human_asset_refined, img_shape, cam_param, None, mean_2d=pr[4], **kw)]
         couts = rasterize_composites([(handles[0], handles[1]), (handles[0], handles[2])], comp)
         res = [_output_dict(plain[0], outs[0]), _output_dict(plain[1], outs[1]), _output_dict(comp[0], couts[0]),
                _output_dict(plain[2], outs[2]), _output_dict(comp[1], couts[1])]
         return dict(zip(ITERATION_RENDERS, res))
-    jobs = [(scene_asset, img_shape, cam_param, None, scene_densify_stats),
-            (human_asset, img_shape, cam_param, bg),
-            (human_asset, img_shape, cam_param, None, None, scene_asset),
-            (human_asset_refined, img_shape, cam_param, bg),
-            (human_asset_refined, img_shape, cam_param, None, None, scene_asset)]
-    return dict(zip(ITERATION_RENDERS, render_many(renderer, jobs)))
+    rj = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats, mean_2d=pr[0], **kw),
+          _raster_job(human_asset, img_shape, cam_param, bg, mean_2d=pr[1], **kw),
+          _raster_job(human_asset, img_shape, cam_param, None, None, scene_asset, mean_2d=pr[2], **kw),
+          _raster_job(human_asset_refined, img_shape, cam_param, bg, mean_2d=pr[3], **kw),
+          _raster_job(human_asset_refined, img_shape, cam_param, None, None, scene_asset, mean_2d=pr[4], **kw)]
+    outs = rasterize_gaussians_batch(rj)
+    return dict(zip(ITERATION_RENDERS, [_output_dict(j, o) for j, o in zip(rj, outs)]))
 
 
 class GraphedRenderer:

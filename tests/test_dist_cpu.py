@@ -101,3 +101,66 @@ def test_flat_grad_allreduce_world2_gloo():
         assert torch.all(acc == 3.0) and torch.all(cnt == 3.0)
         assert torch.equal(rmax, torch.arange(1000, dtype=torch.float32))
     assert torch.equal(res[0][0][0], res[1][0][0])
+
+
+def _worker8(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        P = 257
+        shapes = [(P, 3), (P, 3), (P, 4), (P, 1), (P, 3)]
+        like = [torch.zeros(s) for s in shapes]
+        red = FlatGradAllReducer(like, average=False, n_buffers=2)
+        sums = []
+        # five double-buffered steps; in step s, rank r leaves tensor (r + s) % 5 untouched (None) and ranks with
+        # r % 3 == s % 3 contribute nothing at all (a rank whose view saw no Gaussian): uneven None patterns must neither
+        # hang the collective nor leave stale values of an earlier step in the buffer
+        for step in range(5):
+            grads = [torch.full(s, float((rank + 1) * (i + 1) + 10 * step)) for i, s in enumerate(shapes)]
+            grads[(rank + step) % 5] = None
+            if rank % 3 == step % 3:
+                grads = [None] * 5
+            red.start(grads)
+            if step >= 1:
+                b = (step - 1) % 2
+                red.wait(b)
+                sums.append([v.clone() for v in red.buffer_views(b)])
+        red.finish()
+        sums.append([v.clone() for v in red.buffer_views(4 % 2)])
+        q.put((rank, [[float(t.flatten()[0]) for t in st] + [float((t - t.flatten()[0]).abs().max()) for t in st] for st in sums]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world8_uneven_none_grads():
+    """Eight ranks (gloo, CPU): the world size of the driver's scaling run.  Every step has a different pattern of missing
+    gradients per rank; all ranks must see the same sums, equal to the closed form, for every one of the five
+    double-buffered steps."""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, vals = q.get(timeout=300)
+        res[rank] = vals
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for step in range(5):
+        exp = []
+        for i in range(5):
+            tot = 0.0
+            for r in range(world):
+                if r % 3 == step % 3 or (r + step) % 5 == i:
+                    continue
+                tot += (r + 1) * (i + 1) + 10 * step
+            exp.append(tot)
+        for r in range(world):
+            got = res[r][step]
+            assert got[:5] == exp, (step, r, got[:5], exp)
+            assert max(got[5:]) == 0.0          # constant tensors: no stale element anywhere

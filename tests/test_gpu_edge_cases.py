@@ -255,7 +255,7 @@ def _reset_config():
     exa.config.mode = 'exact'
     exa.config.fixed_capacity = None
     exa.config.on_overflow = 'retry'
-    exa.config.overflow_check = 'adaptive'
+    exa.config.overflow_check = 'forward'       # the module default
 
 
 def test_overflowed_render_is_retried_in_backward_with_correct_gradients(dev):
@@ -270,6 +270,7 @@ def test_overflowed_render_is_retried_in_backward_with_correct_gradients(dev):
     (ref['img'] * G).sum().backward()
     try:
         exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
+        exa.config.overflow_check = 'always'        # look at the report in backward (the forward never waits)
         n0 = len(rz.overflow_events)
         a = _to(assets, dev)
         out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
@@ -295,6 +296,47 @@ def test_overflowed_render_is_retried_in_backward_with_correct_gradients(dev):
         _reset_config()
 
 
+def test_overflow_is_repaired_inside_forward_by_default(dev):
+    """``config.overflow_check = 'forward'`` (the default): the report is polled at the end of the render's own forward and an
+    overflowed render is repaired there -- the image the caller gets, a loss computed from it and the gradients are those of
+    the exact-mode render bit for bit, without any warning (nobody saw incomplete outputs); ``on_overflow = 'raise'`` raises
+    from the forward call."""
+    assets, shape, cam = scenes.make_config('c1')
+    camd = {k: v.to(dev) for k, v in cam.items()}
+    G = torch.randn(3, *shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    a_ref = _to(assets, dev)
+    ref = exa.GaussianRenderer()(a_ref, shape, camd, torch.ones(3, device=dev))
+    loss_ref = ((ref['img'] - G) ** 2).mean()          # a loss whose gradient depends on the image itself
+    loss_ref.backward()
+    try:
+        assert exa.config.overflow_check == 'forward'
+        exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
+        n0 = len(rz.overflow_events)
+        a = _to(assets, dev)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+            assert torch.equal(out['img'].detach(), ref['img'].detach())      # complete when the call returns
+            loss = ((out['img'] - G) ** 2).mean()
+            loss.backward()
+        assert not [x for x in w if issubclass(x.category, RuntimeWarning)]
+        assert len(rz.overflow_events) == n0 + 1 and rz.overflow_events[-1][3] == 'retried'
+        assert float(loss) == float(loss_ref)
+        for k in KEYS:
+            assert torch.equal(a[k].grad, a_ref[k].grad), k
+        assert torch.equal(out['mean_2d'].grad, ref['mean_2d'].grad)
+        assert not rz._pending
+        with torch.no_grad():                                                  # also without autograd
+            out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+        assert torch.equal(out['img'], ref['img'].detach())
+        exa.config.on_overflow = 'raise'
+        with pytest.raises(RuntimeError, match='overflow'):
+            exa.GaussianRenderer()(_to(assets, dev), shape, camd, torch.ones(3, device=dev))
+        torch.cuda.synchronize()
+    finally:
+        _reset_config()
+
+
 def test_overflowed_no_grad_render_is_rerendered_when_drained(dev):
     assets, shape, cam = scenes.make_config('c1')
     camd = {k: v.to(dev) for k, v in cam.items()}
@@ -303,6 +345,7 @@ def test_overflowed_no_grad_render_is_rerendered_when_drained(dev):
         ref = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
     try:
         exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
+        exa.config.overflow_check = 'always'        # (the default repairs it inside the forward call already)
         with torch.no_grad():
             out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
         with warnings.catch_warnings(record=True):

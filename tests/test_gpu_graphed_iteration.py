@@ -1,0 +1,220 @@
+"""GPU tests of ``GraphedIteration``: the five renders of one ExAvatar training sample (reference
+avatar/main/model.py:119-167) forward + backward through captured hipGraphs must be the eager ``render_iteration`` path bit
+for bit -- images, radii, every gradient incl. ``mean_2d.grad`` and the fused densification statistics -- across new
+cameras and values per iteration, a change of P (densify / prune, reference avatar/main/config.py:17-20), a forced
+instance-buffer overflow, a new focal length, depth / mask gradients and ``no_grad`` calls.  The eager path itself is held
+against the oracle in tests/test_gpu_parity.py.  /root/reference is never read here."""
+import pytest
+import torch
+
+import exavatar_release_amd as exa
+from exavatar_release_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
+H, W, F = 128, 160, 170.0
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a ROCm device'
+    from exavatar_release_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+@pytest.fixture(autouse=True)
+def _config():
+    saved = (exa.config.mode, exa.config.fixed_capacity)
+    exa.config.mode, exa.config.fixed_capacity = 'exact', None
+    yield
+    exa.config.mode, exa.config.fixed_capacity = saved
+
+
+def _sets(n_scene, n_human, seed, dev):
+    scene = scenes.dist_a_random(n_scene, H, W, seed=seed, focal=F)
+    human = scenes.dist_a_random(n_human, H, W, seed=seed + 1, focal=F, z_range=(2.0, 4.0))
+    g = torch.Generator().manual_seed(seed + 2)
+    refined = {k: (v + 0.01 * torch.randn(v.shape, generator=g) if k == 'mean_3d' else v.clone()) for k, v in human.items()}
+    return [{k: v.to(dev) for k, v in d.items()} for d in (scene, human, refined)]
+
+
+def _leaves(sets):
+    return [{k: v.detach().clone().requires_grad_(True) for k, v in d.items()} for d in sets]
+
+
+def _cam(i, dev, focal=F):
+    return {k: t.to(dev) for k, t in scenes.ring_camera(H, W, i, 40, radius=3.2, center=(0.0, 0.0, 3.0), focal=focal).items()}
+
+
+def _loss(out, G, with_planes):
+    terms = []
+    for i, name in enumerate(exa.ITERATION_RENDERS):
+        terms.append((out[name]['img'] * G[i]).sum() * (0.5 + 0.25 * i))
+        if with_planes and i in (1, 3):
+            terms.append((out[name]['mask'] * G[5][:1]).sum() + (out[name]['depthmap'] * G[5][1:2]).sum())
+    return sum(terms)
+
+
+def _stats(P, dev):
+    return tuple(torch.zeros(P, device=dev) for _ in range(3))
+
+
+def _run(fn, sets, cam, bg, G, dens=None, with_planes=False):
+    """One iteration through `fn` (graphed object or the eager function); returns (planes, radii, grads)."""
+    s, h, r = _leaves(sets)
+    out = fn(s, h, r, cam, bg, dens)
+    planes = [out[n][k].detach().clone() for n in exa.ITERATION_RENDERS for k in ('img', 'depthmap', 'mask')]
+    radii = [out[n]['radius'].clone() for n in exa.ITERATION_RENDERS]
+    vis = [out[n]['is_vis'].clone() for n in exa.ITERATION_RENDERS]
+    _loss(out, G, with_planes).backward()
+    torch.cuda.synchronize()
+    grads = [t[k].grad.clone() for t in (s, h, r) for k in KEYS]
+    grads += [out[n]['mean_2d'].grad.clone() for n in exa.ITERATION_RENDERS]
+    return planes, radii + vis, grads
+
+
+def _eager(merge=True):
+    rend = exa.GaussianRenderer()
+    return lambda s, h, r, cam, bg, dens=None: exa.render_iteration(rend, s, h, r, (H, W), cam, bg, dens, merge=merge)
+
+
+def _same(a, b, what):
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.shape == y.shape, (what, i, x.shape, y.shape)
+        assert torch.equal(x, y), '%s %d differs (max %.3e)' % (what, i, float((x.float() - y.float()).abs().max()))
+
+
+def _G(dev, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(3, H, W, generator=g).to(dev) for _ in range(6)]
+
+
+@pytest.mark.parametrize('merge', [True, False])
+def test_graphed_iteration_is_the_eager_iteration_bit_for_bit(dev, merge):
+    sets = _sets(3000, 1500, 51, dev)
+    G = _G(dev)
+    it = exa.GraphedIteration((H, W), dev, merge=merge)
+    eager = _eager(merge)
+    g = torch.Generator().manual_seed(9)
+    for i in range(4):
+        cam, bg = _cam(3 * i, dev), torch.rand(3, generator=g).to(dev)
+        if i:       # new values every iteration, as an optimizer step leaves them
+            sets = [{k: (v + 0.003 * torch.randn(v.shape, generator=g).to(dev) if k in ('mean_3d', 'rgb') else v) for k, v in d.items()}
+                    for d in sets]
+        da, db = _stats(3000, dev), _stats(3000, dev)
+        pa, ra, ga = _run(it, sets, cam, bg, G, da)
+        pb, rb, gb = _run(eager, sets, cam, bg, G, db)
+        _same(pa, pb, 'plane'); _same(ra, rb, 'radius / is_vis'); _same(ga, gb, 'grad')
+        _same(da, db, 'densify statistic')
+        assert float(da[1].sum()) > 0
+        # the statistics tensors changed -> their pointers are baked into the backward graph -> one capture per new set;
+        # keep them for the next iterations instead, as a training loop does
+    # same statistics tensors, same P, same focal: ONE more capture in total, whatever the camera / values / background
+    n0 = it.captures
+    dens = _stats(3000, dev)
+    dens_e = _stats(3000, dev)
+    for i in range(3):
+        cam = _cam(7 + i, dev)
+        cam['focal'] = cam['focal'].clone()        # a data loader hands out a fresh tensor per frame: checked on the device
+        bg = torch.rand(3, generator=g).to(dev)
+        pa, ra, ga = _run(it, sets, cam, bg, G, dens)
+        pb, rb, gb = _run(eager, sets, cam, bg, G, dens_e)
+        _same(pa, pb, 'plane'); _same(ga, gb, 'grad'); _same(dens, dens_e, 'accumulated statistic')
+    assert it.captures == n0 + 1
+    assert it.overflow_retries == 0
+
+
+def test_graphed_iteration_follows_p_changes_overflow_focal_and_gradient_patterns(dev):
+    G = _G(dev, 6)
+    eager = _eager()
+    it = exa.GraphedIteration((H, W), dev)
+    g = torch.Generator().manual_seed(10)
+    bg = torch.rand(3, generator=g).to(dev)
+    sets = _sets(2500, 1200, 61, dev)
+    pa, ra, ga = _run(it, sets, _cam(1, dev), bg, G)
+    pb, rb, gb = _run(eager, sets, _cam(1, dev), bg, G)
+    _same(pa, pb, 'plane'); _same(ra, rb, 'radius'); _same(ga, gb, 'grad')
+    assert it.captures == 1
+    # densify: P of the scene grows (clone + split appends rows), then prune: P shrinks -> one re-capture each, no eager pass
+    for n_scene in (3100, 2200):
+        sets2 = _sets(n_scene, 1200, 61, dev)
+        sets2[1], sets2[2] = sets[1], sets[2]
+        before = it.captures
+        pa, ra, ga = _run(it, sets2, _cam(2, dev), bg, G)
+        pb, rb, gb = _run(eager, sets2, _cam(2, dev), bg, G)
+        _same(pa, pb, 'plane after P change'); _same(ra, rb, 'radius'); _same(ga, gb, 'grad after P change')
+        assert it.captures == before + 1
+    # depth / mask gradients: another backward pattern, recorded on first use from inside autograd's backward
+    before = it.captures
+    pa, ra, ga = _run(it, sets2, _cam(4, dev), bg, G, with_planes=True)
+    pb, rb, gb = _run(eager, sets2, _cam(4, dev), bg, G, with_planes=True)
+    _same(pa, pb, 'plane'); _same(ga, gb, 'grad with depth / mask gradients')
+    pa, ra, ga = _run(it, sets2, _cam(5, dev), bg, G)              # ... and back to the usual pattern
+    pb, rb, gb = _run(eager, sets2, _cam(5, dev), bg, G)
+    _same(ga, gb, 'grad')
+    assert it.captures == before
+    # a new focal length: tan(fov) is a kernel argument -> re-capture; the frame is right
+    cam = _cam(5, dev, focal=F * 1.2)
+    pa, ra, ga = _run(it, sets2, cam, bg, G)
+    pb, rb, gb = _run(eager, sets2, cam, bg, G)
+    _same(pa, pb, 'plane at the new focal length'); _same(ga, gb, 'grad at the new focal length')
+    assert it.captures == before + 1
+    # no_grad evaluation render between training steps
+    with torch.no_grad():
+        out = it(*sets2, cam, bg)
+        ref = eager(*sets2, cam, bg)
+    for n in exa.ITERATION_RENDERS:
+        assert torch.equal(out[n]['img'], ref[n]['img']) and torch.equal(out[n]['radius'], ref[n]['radius'])
+        assert out[n]['mean_2d'] is None
+    # forced overflow: instance buffers far too small -> found right after the forward replay, re-captured with room and
+    # rendered again before the call returns: images AND gradients are those of the complete renders
+    small = exa.GraphedIteration((H, W), dev, capacities=(2048, 1024, 1024))
+    pa, ra, ga = _run(small, sets2, cam, bg, G)
+    _same(pa, pb, 'plane after the overflow retry'); _same(ga, gb, 'grad after the overflow retry')
+    assert small.overflow_retries >= 1 and small.captures >= 2
+    n_cap = small.captures
+    pa, ra, ga = _run(small, sets2, cam, bg, G)                     # the next iteration needs no further capture
+    _same(pa, pb, 'plane after the retry'); _same(ga, gb, 'grad')
+    assert small.captures == n_cap
+    with torch.no_grad():                                           # ... and so is a no_grad call on a too-small buffer
+        small2 = exa.GraphedIteration((H, W), dev, capacities=(2048, 1024, 1024))
+        out = small2(*sets2, cam, bg)
+        for n in exa.ITERATION_RENDERS:
+            assert torch.equal(out[n]['img'], ref[n]['img'])
+
+
+def test_graphed_iteration_drives_an_optimizer_like_the_eager_path(dev):
+    """Forty Adam steps on scene + human parameters through activations (the asset tensors are NON-leaf outputs of
+    sigmoid / exp, as the reference's SceneGaussian.forward hands them over, module.py:253-272): parameters after the
+    loop are bit-identical to the eager loop's."""
+    def loop(graphed):
+        torch.manual_seed(0)
+        sets = _sets(2000, 1000, 71, dev)
+        raw = []
+        for d in sets:
+            raw.append({'mean_3d': d['mean_3d'].clone().requires_grad_(True),
+                        'scale': d['scale'].log().requires_grad_(True),
+                        'rotation': d['rotation'].clone().requires_grad_(True),
+                        'opacity': torch.logit(d['opacity'].clamp(1e-4, 1 - 1e-4)).requires_grad_(True),
+                        'rgb': d['rgb'].clone().requires_grad_(True)})
+        opt = torch.optim.Adam([p for r in raw for p in r.values()], lr=2e-3, eps=1e-15)
+        act = lambda r: {'mean_3d': r['mean_3d'], 'scale': torch.exp(r['scale']), 'rotation': r['rotation'],     # noqa: E731
+                         'opacity': torch.sigmoid(r['opacity']), 'rgb': r['rgb']}
+        G = _G(dev, 8)
+        fn = exa.GraphedIteration((H, W), dev) if graphed else _eager()
+        dens = _stats(2000, dev)
+        losses = []
+        for i in range(40):
+            opt.zero_grad(set_to_none=True)
+            out = fn(act(raw[0]), act(raw[1]), act(raw[2]), _cam(i % 9, dev), torch.full((3,), 0.3, device=dev), dens)
+            loss = sum(((out[n]['img'] - G[k].sigmoid()) ** 2).mean() for k, n in enumerate(exa.ITERATION_RENDERS))
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        return [p.detach().clone() for r in raw for p in r.values()] + list(dens), losses
+    pa, la = loop(True)
+    pb, lb = loop(False)
+    _same(pa, pb, 'parameter / statistic after 40 Adam steps')
+    assert la == lb and la[-1] < la[0]

@@ -388,6 +388,7 @@ def test_capacity_overflow_is_reported(dev):
     exa.config.mode = 'capacity'
     exa.config.fixed_capacity = 1000            # far too small
     exa.config.on_overflow = 'raise'            # (the default, 'retry', is covered in tests/test_gpu_edge_cases.py)
+    exa.config.overflow_check = 'always'        # (the default, 'forward', raises from the render call itself)
     try:
         a = _to(assets, dev, grad=False)
         with torch.no_grad():
@@ -398,6 +399,7 @@ def test_capacity_overflow_is_reported(dev):
         exa.config.mode = 'exact'
         exa.config.fixed_capacity = None
         exa.config.on_overflow = 'retry'
+        exa.config.overflow_check = 'forward'
 
 
 def test_hipgraph_replay_equals_eager(dev):
@@ -826,6 +828,7 @@ def test_overflowed_render_raises_in_backward_and_writes_zero_gradients(dev):
     exa.config.mode = 'capacity'
     exa.config.fixed_capacity = 1024            # far too small
     exa.config.on_overflow = 'raise'
+    exa.config.overflow_check = 'always'
     try:
         a = _to(assets, dev)
         out = exa.GaussianRenderer()(a, shape, {k: v.to(dev) for k, v in cam.items()}, torch.ones(3, device=dev))
@@ -836,6 +839,7 @@ def test_overflowed_render_raises_in_backward_and_writes_zero_gradients(dev):
         exa.config.mode = 'exact'
         exa.config.fixed_capacity = None
         exa.config.on_overflow = 'retry'
+        exa.config.overflow_check = 'forward'
 
 
 def test_no_grad_render_matches_training_render(dev):
@@ -870,6 +874,30 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     res = json.loads(line)
     assert res['n_gpus'] == 2 and res['steps'] == 6 and res['value'] > 0 and res['scaling'] == 'weak'
     assert res['rccl']['world_size'] == 2 and res['rccl']['backend'] == 'gloo'
+
+
+def test_bench_eight_ranks_on_one_gpu_as_the_driver_types_it():
+    """`python bench.py --gpus 8 --steps K --warmup W` VERBATIM -- the command of the driver's 8-GPU scaling run -- with eight
+    ranks sharing this GPU over gloo (RCCL refuses duplicate devices; EXA_BENCH_BACKEND is the only difference to the real
+    run): the self-launch, the deal of 25 ring views per rank, two launch contexts with double-buffered flat gradients, the
+    asynchronous all-reduce around the hipGraph replays, `finish()`, both barriers and the max-over-ranks timing all run
+    to completion and rank 0 prints one line for a world of eight.  No scaling number is claimed from this."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EXA_BENCH_BACKEND='gloo', MASTER_PORT='29547', EXA_BENCH_SETTLE_STEPS='16')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '10', '--warmup', '3']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
+    res = json.loads(line)
+    assert res['n_gpus'] == 8 and res['steps'] == 10 and res['value'] > 0 and res['scaling'] == 'weak'
+    assert res['rccl']['world_size'] == 8 and res['rccl']['backend'] == 'gloo'
+    assert res['config']['views_per_rank'] == 25 and res['config']['launch'] == 'graph'
+    assert 'dp8' in res['config']['parallelism']
 
 
 SSIM_MAP_TOL = 1e-5          # |ssim| <= 1; separable fp32 filtering vs the reference's 2-D conv2d
