@@ -153,7 +153,8 @@ def main():
     # evenly.  In ring order the 20 steps of a `--steps 20 --warmup 5` run were views 5..24 -- a 36-degree arc of frontal
     # (heavy) views, 6-7 % slower than the mean over the ring that 200+ steps measure; frontal and side views of
     # an avatar differ by ~35 % in instances.  Training itself shuffles (reference DataLoader shuffle=True).
-    view_order = [(i * VIEW_STRIDE) % N_VIEWS for i in range(N_VIEWS)]
+    ring_order = os.environ.get('EXA_BENCH_VIEW_ORDER', 'stratified') == 'ring'      # rounds 1-2 protocol (value_no_settle)
+    view_order = list(range(N_VIEWS)) if ring_order else [(i * VIEW_STRIDE) % N_VIEWS for i in range(N_VIEWS)]
     my_views = exa_dist.shard_views(N_VIEWS, rank, world, order=view_order) if args.config != 'c1' else [0]
     vs = [view_settings(k, shape, args.config) for k in my_views]
     # one 48-float row per view: viewmatrix (16) | projmatrix (16) | campos (3) | pad -- a view switch is ONE copy
@@ -334,15 +335,22 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps * KV / elapsed
-        metric = 'train iters/sec (fwd+bwd raster) at 1024x1024 / ~150k Gaussians' if args.config != 'c5' or train else \
-            'forward renders/sec at 2048x2048 / 300k Gaussians, SH deg 3 (BASELINE configs[4])'
+        if not train:
+            metric = 'forward renders/sec at %dx%d / %dk Gaussians%s' % (W, H, P // 1000, ', SH deg 3 (BASELINE configs[4])' if use_sh else '')
+        elif args.config == 'c3':
+            metric = 'train iters/sec (fwd+bwd raster) at 1024x1024 / ~150k Gaussians'
+        else:
+            metric = 'train iters/sec (fwd+bwd raster) at %dx%d / ~%dk Gaussians (%s)' % (W, H, P // 1000, args.config)
         result = {
             'metric': metric,
             'value': value, 'unit': 'iters/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload + ', %d ring views dealt by dist.shard_views' % N_VIEWS,
-                       'view_order': 'step i -> ring view (i * %d) mod %d (stratified: every window of steps covers the ring)' % (VIEW_STRIDE, N_VIEWS),
+                       'view_order': 'ring order (step i -> view i)' if ring_order else
+                                     'step i -> ring view (i * %d) mod %d (stratified: every window of steps covers the ring)' % (VIEW_STRIDE, N_VIEWS),
+                       'parity_bar': 'image 1e-4 L-inf off the <= 0.04 % threshold-adjacent (ambiguous) pixels, which may be off by '
+                                     '2e-2; grads 1e-3 rel, 1e-1 * mean floor for Gaussians under an ambiguous pixel (tests/helpers.py)',
                        'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
                        'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle,
                        'views_in_flight_per_gpu': S, 'views_per_launch': KV,
@@ -413,6 +421,8 @@ def main():
             'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
             'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
+            'clock': 'HIP events around eager launches of the kernel, this run (2nd of two back-to-back steps, stratified views); '
+                     'the rocprofv3 --kernel-trace average of the graph-replayed step is in profiles/ (1-3 us lower)',
             'byte_model': 'SURVEY.md 8(d) with the run\'s own P, V and D = 16x16 tile instances (header.num_tile_instances)',
             'kernel_avg_us': avg_us,
             'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),
@@ -439,6 +449,9 @@ def main():
         torch.cuda.empty_cache()
         result['extra_c5_forward'] = other_config('c5', args)
         result['extra_c2'] = other_config('c2', args)
+        cold = cold_ring_order(args)
+        result['extra_cold_ring_order'] = cold
+        result['value_no_settle'] = cold.get('value')
 
     # ---- CPU baseline: the oracle on a bounded sample of the same workload (rank 0, N = 1) ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -485,7 +498,39 @@ def other_config(cfg, args):
         if r.returncode != 0 or not lines:
             return {'error': (r.stderr or r.stdout)[-300:]}
         d = json.loads(lines[-1])
-        return {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config')}
+        res = {k: d[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config')}
+        # step-level HBM roofline of that line from its own P, V, D (SURVEY.md 8(d) byte model; forward only for c5)
+        c = d['config']
+        P, V, D, WH = c['P'], c['mean_visible_V'], c['mean_instances_D'], c['W'] * c['H']
+        if 'forward' in c['mode']:
+            nbytes = 60 * P + 88 * V + 40 * D + 28 * WH + (192 * P if cfg == 'c5' else 0)
+        else:
+            nbytes = 128 * P + 252 * V + 44 * D + 56 * WH
+        gbs = nbytes / (d['ms_per_step'] * 1e-3) / 1e9
+        res['roofline'] = {'bound': 'hbm', 'level': 'whole step (graph replay)', 'algorithmic_bytes': nbytes, 'achieved': gbs,
+                           'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
+        return res
+    except Exception as e:  # noqa: BLE001
+        return {'error': str(e)[:200]}
+
+
+def cold_ring_order(args):
+    """The headline step measured the way rounds 1-2 measured it -- ring view order, NO settle phase: the timed steps start
+    right after the capacity calibration and cover a 36-degree arc of frontal (heavy) views -- in a child process, so that the
+    round-over-round trend stays readable next to the settled, stratified headline."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', 'c3', '--steps', str(args.steps), '--warmup', str(args.warmup),
+           '--no-cpu-baseline', '--no-concurrent', '--no-kernel-timing', '--no-other-configs']
+    env = dict(os.environ, EXA_BENCH_SETTLE_STEPS='0', EXA_BENCH_VIEW_ORDER='ring')
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not lines:
+            return {'error': (r.stderr or r.stdout)[-300:]}
+        d = json.loads(lines[-1])
+        return {'value': d['value'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'warmup': d['warmup'],
+                'protocol': 'ring view order, settle_steps = 0 (the rounds 1-2 protocol; headline: stratified order + %s settle steps)'
+                            % os.environ.get('EXA_BENCH_SETTLE_STEPS', '300')}
     except Exception as e:  # noqa: BLE001
         return {'error': str(e)[:200]}
 

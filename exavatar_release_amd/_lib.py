@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# EXA_RASTER_LIB: developer override to load an experimental build of the same ABI (tools/gpu_variants.py)
+# EXA_RASTER_LIB: developer override to load an experimental build of the same ABI (tools/build_variant.sh, tools/gpu_ab.sh)
 LIB_PATH = os.environ.get('EXA_RASTER_LIB') or os.path.join(_HERE, 'libexa_raster.so')
 
 c_float_p = ctypes.c_void_p      # device pointers travel as plain addresses

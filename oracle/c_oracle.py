@@ -159,36 +159,3 @@ def render(gaussian_assets, img_shape, cam_param, bg=None, dL_dimg=None, dL_ddep
     return out
 
 
-_model = None
-
-
-def quad_stream_forward(gaussian_assets, img_shape, cam_param, bg=None, mode=1):
-    """Design model of the quad-stream forward schedule (``oracle/c/quad_stream_model.c``):
-    renders with ``mode`` 0 = today's schedule (64 lanes walk every staged entry), 1 = four independent 16-lane quad
-    streams with conservative box masks, 2 = with exact masks, and counts the loop trips of all three.
-    Returns ``(img [3,H,W], depth [1,H,W], alpha [1,H,W], stats dict)``."""
-    global _model
-    from oracle import raster_oracle as ro
-    if _model is None:
-        path = os.path.join(_HERE, 'c', 'libquad_model.so')
-        if not os.path.exists(path):
-            subprocess.run(['make', '-s', '-C', os.path.join(_HERE, 'c'), 'libquad_model.so'], check=True)
-        _model = ctypes.CDLL(path)
-        _model.exa_model_quad_stream_forward.restype = ctypes.c_long
-        _model.exa_model_quad_stream_forward.argtypes = [ctypes.POINTER(OrcSettings), ctypes.c_int32] + [ctypes.c_void_p] * 5 + \
-            [ctypes.c_int32] + [ctypes.c_void_p] * 4
-    if bg is None:
-        bg = torch.ones(3)
-    st = _settings(ro.settings_from_camera(cam_param, img_shape, bg))
-    H, W = st.image_height, st.image_width
-    m3, col, op = _f32(gaussian_assets['mean_3d']), _f32(gaussian_assets['rgb']), _f32(gaussian_assets['opacity'])
-    sc, rot = _f32(gaussian_assets['scale']), _f32(gaussian_assets['rotation'])
-    color, depth, alpha = np.empty((3, H, W), np.float32), np.empty((1, H, W), np.float32), np.empty((1, H, W), np.float32)
-    stats = (ctypes.c_long * 8)()
-    rc = _model.exa_model_quad_stream_forward(ctypes.byref(st), int(m3.shape[0]), _ptr(m3), _ptr(col), _ptr(op), _ptr(sc),
-                                              _ptr(rot), int(mode), _ptr(color), _ptr(depth), _ptr(alpha), stats)
-    if rc < 0:
-        raise RuntimeError('exa_model_quad_stream_forward failed with status %d' % rc)
-    names = ('list_entries', 'entries_walked_today', 'trips_today', 'trips_quad_box', 'trips_quad_exact', 'unused',
-             'nonempty_subtiles', 'entries_box_mask_all_quads')
-    return torch.from_numpy(color), torch.from_numpy(depth), torch.from_numpy(alpha), dict(zip(names, list(stats)))

@@ -234,24 +234,6 @@ def test_thread_count_does_not_change_the_result():
         assert _rel(r2['grads'][k], r1['grads'][k]) <= 1e-6
 
 
-@pytest.mark.parametrize('mode', [0, 1, 2])
-def test_quad_stream_schedule_model_renders_the_oracles_image(mode):
-    """oracle/c/quad_stream_model.c (design model of a candidate forward-blend schedule): today's schedule,
-    quad streams with conservative box masks and with exact masks all reproduce the oracle's image -- no contributing
-    entry is dropped by a mask, padding and the stop rule are right -- and the trip counts are ordered as expected."""
-    H, W, f = 96, 128, 150.0
-    a = scenes.dist_a_random(2000, H, W, seed=3, focal=f)
-    cam = scenes.neutral_camera(H, W, focal=f)
-    bg = torch.tensor([0.2, 0.4, 0.6])
-    ref = co.render(a, (H, W), cam, bg)
-    amb = ref['pixel_margin'] < 1e-4
-    img, dep, alp, st = co.quad_stream_forward(a, (H, W), cam, bg, mode)
-    assert float((img - ref['img']).abs().amax(0)[~amb].max()) <= IMG_TOL
-    assert float((dep - ref['depthmap']).abs()[0][~amb].max()) <= 1e-5 and float((alp - ref['mask']).abs()[0][~amb].max()) <= IMG_TOL
-    assert st['trips_quad_exact'] <= st['trips_quad_box'] <= st['trips_today']
-    assert st['entries_walked_today'] <= st['list_entries']
-
-
 def test_bench_cpu_baseline_runs_on_the_c_restatement():
     """bench.py's cpu_baseline leg (kind "port"): the C restatement on the bench workload's own view, here C1."""
     import bench

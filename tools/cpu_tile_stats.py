@@ -6,7 +6,7 @@ C3 view 0:   16 px: 373 k entries, 318 k walked, 81.4 M pairs, lane efficiency 0
               8 px: 709 k entries, 502 k walked, 32.2 M pairs, lane efficiency 0.200   (this design)
               4 px: 1.68 M entries, 972 k walked, 15.5 M pairs, lane efficiency 0.413
               8 px wave, four independent 16-lane quad streams: 299 k trips (vs 502 k walked), lane efficiency 0.335
-              (per-ENTRY count; the exact model oracle/c/quad_stream_model.c -- groups of four, batches of 64, box masks --
+              (per-ENTRY count; the exact model quad_stream_model.c (removed in round 4; last in commit 44f775f under oracle/c/) -- groups of four, batches of 64, box masks --
                gives 95 k vs 127 k loop trips: x0.75)"""
 import sys, os, math, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
