@@ -583,8 +583,25 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
         cat = lambda a, b: {k: torch.cat((a[k].detach(), b[k])) for k in keys}      # noqa: E731
 
         graphed = exa.GraphedIteration((H, W), device)
+        # the reference's photometric objective per render (avatar/main/model.py:197-198, 214-215) through the fused
+        # producer of dL/dimg: human renders against the frame inside the person's bbox, the scene outside the mask
+        photo = exa.PhotometricLoss()
+        target = torch.rand(1, 3, H, W, device=device)
+        mask = (torch.rand(1, 1, H, W, device=device) > 0.7).float()
+        bbox = torch.tensor([[W // 4, H // 8, W // 2, 3 * H // 4]], dtype=torch.float32)
 
         def iteration(how):
+            if how.endswith('_photometric'):
+                res = graphed(scene, human, refined, cam, bg) if how.startswith('graphed') else \
+                    exa.render_iteration(rend, scene, human, refined, (H, W), cam, bg)
+                loss = photo(res['scene']['img'][None], target, l1_weight=1 - mask, ssim_mask=1 - mask)
+                for k in exa.ITERATION_RENDERS[1:]:
+                    loss = loss + photo(res[k]['img'][None], target, bbox=bbox)
+                for t in (scene, human, refined):
+                    for v in t.values():
+                        v.grad = None
+                loss.backward()
+                return
             if how == 'graphed':
                 res = graphed(scene, human, refined, cam, bg)
                 outs = [res[k] for k in exa.ITERATION_RENDERS]
@@ -602,7 +619,7 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             loss.backward()
         out = {'workload': '%d k Dist-C scene + %d k avatar-like human Gaussians, %dx%d, 5 renders fwd+bwd, eager'
                            % (n_scene // 1000, n_human // 1000, W, H)}
-        for how in ('sequential', 'batched', 'sets', 'graphed'):
+        for how in ('sequential', 'batched', 'sets', 'graphed', 'sets_photometric', 'graphed_photometric'):
             # two iterations with the two-stage protocol first: they record the instance count of every render of THIS
             # scene (the capacity memo is keyed on (P, H, W), and the timed C3 runs above used P = 150 k as well)
             exa.config.mode = 'exact'
@@ -625,6 +642,10 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             ms, host_ms = sorted(windows)[1]
             out[how] = {'ms_per_iteration': ms, 'renders_per_s': 5e3 / ms, 'host_ms_per_iteration': host_ms,
                         'windows_ms': [round(w[0], 4) for w in windows]}
+            if how.endswith('_photometric'):
+                out[how]['what'] = ('loss = the fused PhotometricLoss (L1 + SSIM, reference weights) of every render against a '
+                                    'target image -- scene outside the mask, the four human renders inside a bbox -- instead of '
+                                    'sum(img * G): what a train.py on this package runs per iteration around the rasterizer')
             if how == 'graphed':
                 out[how]['what'] = ('exa.GraphedIteration: one hipGraph for the five forwards, one for their backwards, same '
                                     'loss in PyTorch between them; captures=%d' % graphed.captures)

@@ -72,6 +72,7 @@ class ExaRasterComposeJob(ctypes.Structure):
         ('tile_ws', c_void_p), ('bin_ws', c_void_p), ('capacity', ctypes.c_uint64),
         ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
         ('host_header', c_void_p), ('header_tag', ctypes.c_uint32),
+        ('a_color', c_void_p), ('a_depth', c_void_p), ('a_alpha', c_void_p), ('a_bg', c_void_p),
     ]
 
 
@@ -91,6 +92,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
         ('densify_grad_accum', c_void_p), ('densify_track_cnt', c_void_p), ('densify_radius_max', c_void_p),
         ('grad_first', ctypes.c_int32),
         ('compose_geom_a', c_void_p), ('compose_P_a', ctypes.c_int32), ('compose_capacity_b', ctypes.c_uint64),
+        ('dL_dcolor_indirect', c_void_p),
     ]
 
 
@@ -125,6 +127,7 @@ SIGNATURES = {
     'exa_raster_camera_block': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_float), c_void_p, c_void_p,
                                                c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p,
                                                ctypes.c_uint32, c_void_p]),
+    'exa_raster_store_pointers': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p), _I32, c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'exa_ssim_forward': (ctypes.c_int, [_I32, _I32, _I32] + [c_void_p] * 7),
@@ -160,7 +163,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 131:
+    if lib.exa_raster_version() < 132:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

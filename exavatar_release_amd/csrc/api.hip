@@ -195,6 +195,7 @@ int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, 
         r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
         r.store_ctx = store_ctx;
         r.keep_sorted_keys = j.keep_sorted_keys; r.splats2 = nullptr;
+        r.src_color = r.src_depth = r.src_alpha = r.src_bg = nullptr;
     }
     int rc;
     // (cell_scatter_kernel also clears the zero-filled section of the bin workspace: batch owners, blended masks, touched bytes)
@@ -242,6 +243,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         r.tw = carve_tile_ws(const_cast<void*>(j.tile_ws), g.cells, num_chunks(j.P));
         r.bw = carve_bin_ws(const_cast<void*>(j.bin_ws), j.capacity);
         r.bg = s->bg; r.dL_dcolor = j.dL_dcolor; r.dL_ddepth = j.dL_ddepth; r.dL_dalpha = j.dL_dalpha;
+        r.dL_dcolor_ind = j.dL_dcolor_indirect;
         r.partials = carve_grad_ws(j.grad_ws, j.capacity);
         r.grad_first = j.grad_first;
         if (j.compose_geom_a) {                 // composite: ids of two record arrays, A constant, B (= this job's tensors) trainable
@@ -466,6 +468,9 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
         if (j.capacity % BATCH || j.capacity_a % BATCH || j.capacity_b % BATCH)
             return fail(EXA_RASTER_E_INVALID, "capacity must be a multiple of 64");
         if (!j.out_color || !j.out_depth || !j.out_alpha) return fail(EXA_RASTER_E_NULLPTR, "output image is NULL");
+        const int n_src = (j.a_color != nullptr) + (j.a_depth != nullptr) + (j.a_alpha != nullptr) + (j.a_bg != nullptr);
+        if (n_src != 0 && n_src != 4) return fail(EXA_RASTER_E_INVALID, "composite: pass all of a_color / a_depth / a_alpha / a_bg or none");
+        if (j.a_color == j.out_color && j.a_color) return fail(EXA_RASTER_E_ALIAS, "composite: a_color aliases out_color");
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
@@ -485,11 +490,13 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
             c.bw = carve_compose_ws(j.bin_ws, j.capacity, j.capacity_b);
             c.capacity = j.capacity; c.capacity_b = j.capacity_b;
             c.host_hdr = static_cast<uint32_t*>(j.host_header); c.hdr_tag = j.header_tag;
+            c.src_color = j.a_color; c.src_bg = j.a_bg; c.bg = j.settings->bg;
             RenderFwdArgs& r = ra[k];
             r.grid = g; r.splats = static_cast<const Splat*>(j.geom_a); r.splats2 = static_cast<const Splat*>(j.geom_b);
             r.tw = c.tw; r.bw = c.bw; r.capacity = j.capacity;
             r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
             r.store_ctx = store_ctx; r.keep_sorted_keys = 0;
+            r.src_color = j.a_color; r.src_depth = j.a_depth; r.src_alpha = j.a_alpha; r.src_bg = j.a_bg;
         }
         int rc;
         EXA_TIMED(K_CELL_SCATTER, launch_compose(ca, n, st), "compose");
@@ -528,6 +535,24 @@ int exa_raster_camera_block(const float* R, const float* t, const float* proj16_
     EXA_HIP(launch_camera_block(R, t, p, viewmatrix_out, projmatrix_out, campos_out, focal, fx_expected, fy_expected,
                                 static_cast<uint32_t*>(host_flag), flag_tag, static_cast<hipStream_t>(stream)),
             "camera_block");
+    return 0;
+}
+
+namespace {
+struct Ptr16 { const void* p[16]; };
+__global__ void store_pointers_kernel(const void** table, Ptr16 v, int n) {
+    if ((int)threadIdx.x < n) table[threadIdx.x] = v.p[threadIdx.x];
+}
+}  // namespace
+
+int exa_raster_store_pointers(void* table, const void* const* ptrs, int32_t n, void* stream) {
+    if (!table || !ptrs) return fail(EXA_RASTER_E_NULLPTR, "store_pointers: NULL pointer");
+    if (n < 0 || n > 16) return fail(EXA_RASTER_E_INVALID, "store_pointers: n must be 0..16");
+    if (n == 0) return 0;
+    Ptr16 v;
+    for (int i = 0; i < 16; ++i) v.p[i] = i < n ? ptrs[i] : nullptr;
+    store_pointers_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const void**>(table), v, n);
+    EXA_HIP(hipGetLastError(), "store_pointers");
     return 0;
 }
 

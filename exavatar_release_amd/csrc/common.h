@@ -292,7 +292,14 @@ struct RenderFwdArgs {
     const float* bg; float* out_color; float* out_depth; float* out_alpha; int store_ctx;
     int keep_sorted_keys;      // sort_subtiles: also write the sorted 64-bit keys back over bw.keys (merge source)
     const Splat* splats2;      // composite: records of source B (ids with SRC_B); `splats` = source A
+    // composite, optional: source A's finished images + its background.  Equal backgrounds => a sub-tile without B entries
+    // has an empty list (compose.hip) and its pixels are copied from A's images (reuse_a_pixels below)
+    const float* src_color; const float* src_depth; const float* src_alpha; const float* src_bg;
 };
+// Composite renders: may the pixels of source A stand in for sub-tiles without B entries?  (Wave-uniform: six scalar loads.)
+__device__ __forceinline__ bool reuse_a_pixels(const float* src_color, const float* src_bg, const float* bg) {
+    return src_color != nullptr && src_bg[0] == bg[0] && src_bg[1] == bg[1] && src_bg[2] == bg[2];
+}
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s);
 // Composite of two finished renders (compose.hip): ranges / header / launch order / zero-fill, then the merged id lists
 struct ComposeArgs {
@@ -300,6 +307,7 @@ struct ComposeArgs {
     TileWs tw_a, tw_b; BinWs bw_a, bw_b;       // sources (sorted keys in bw.keys: forward with keep_sorted_keys)
     TileWs tw; BinWs bw; uint64_t capacity, capacity_b;   // the composite's own: bw.touched holds capacity_b bytes
     uint32_t* host_hdr; uint32_t hdr_tag;
+    const float* src_color; const float* src_bg; const float* bg;    // see RenderFwdArgs.src_color
 };
 hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s);
 // bin workspace of a composite: merged ids [cap] | zero-filled: owner [cap / 64 + 1], blended mask [cap / 64 + 1], touched
@@ -327,6 +335,7 @@ struct RenderBwdArgs {
     Grid grid; uint64_t capacity; int P;
     const Splat* splats; TileWs tw; BinWs bw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
+    const float* const* dL_dcolor_ind;   // optional: the colour gradient's address is loaded from here at execution time
     PartialWs partials;
     int grad_first;        // Gaussians below this index are constants (ExaRasterBackwardJob.grad_first)
     const Splat* splats2;  // composite (PREFIX instantiation): records of source B = the trainable Gaussians (ids with SRC_B),

@@ -8,6 +8,10 @@
 // are the sources' records, and the depth-sorted list of a sub-tile is the merge of the sources' two sorted lists (order of
 // the concatenated render: ascending depth bits, ties by index -- every A (scene) index precedes every B (human) index, so A
 // wins ties).  Two small launches replace five:
+// Where the human is absent the composite IS the scene render: with source A's finished images at hand (and equal
+// backgrounds) a sub-tile without B entries gets an empty list and its pixels are copied from A's images -- in ExAvatar's
+// composites ~3/4 of the image skip merge, blend and every backward wave (round 4; per five-render iteration: composite
+// forward 136 -> see DESIGN.md, bit-identical).
 //   compose_kernel   block 0 (one workgroup, all range loads of a thread in flight at once): list lengths nA + nB -> 64-aligned
 //                    ranges of the composite's own instance space, header; the other blocks zero-fill the composite's owner /
 //                    blended-mask / touched arrays and copy the launch order of the blend from the heavier source
@@ -51,6 +55,9 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
     const uint2* __restrict__ ra = a.tw_a.ranges;
     const uint2* __restrict__ rb = a.tw_b.ranges;
     const bool src_overflow = a.tw_a.header->overflow != 0u || a.tw_b.header->overflow != 0u;
+    // A's own pixels stand in where B has no entry (include/exa_raster.h, ExaRasterComposeJob.a_color): such a sub-tile gets
+    // an EMPTY list here -- no merge, no batch slots, nothing for the backward to look at -- and render_fwd copies it
+    const bool reuse = reuse_a_pixels(a.src_color, a.src_bg, a.bg);
     // ---- 64-aligned ranges: exclusive prefix of the slot counts over the sub-tiles (cell-major order, like the sources) ------
     // A wave takes whole CELLS (lane = sub-tile of the cell: 512-byte coalesced loads and stores; a thread-major split of the
     // sub-tiles touched 64 cache lines per load instruction and cost 25 us on this one CU): per trip 16 waves x 16 cells, the
@@ -70,6 +77,7 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         for (int i = 0; i < C_PER; ++i) {
             const bool valid = cell0 + wave * C_PER + i < cells && !src_overflow;
             len[i] = valid ? (x[i].y - x[i].x) + (y[i].y - y[i].x) : 0u;
+            if (reuse && y[i].y == y[i].x) len[i] = 0u;
             const uint32_t ns = list_slots(len[i]);
             uint32_t incl = ns;
 #pragma unroll

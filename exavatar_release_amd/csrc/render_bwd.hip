@@ -176,6 +176,8 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
             a.tw.part_cnt[2 * blockIdx.x] = (uint32_t)t0; a.tw.part_cnt[2 * blockIdx.x + 1] = (uint32_t)wall_clock64(); } } } tl{a, (unsigned long long)wall_clock64(), lane};
 #endif
     const float* __restrict__ bg = a.bg;
+    // (graph replays with a new gradient tensor per iteration: include/exa_raster.h, dL_dcolor_indirect; a scalar load)
+    const float* __restrict__ dL_dcolor = a.dL_dcolor_ind ? *a.dL_dcolor_ind : a.dL_dcolor;
     float4* __restrict__ prec = a.partials.rec;
     uint8_t* __restrict__ touched = a.bw.touched;
 
@@ -239,9 +241,9 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
         if (pxi < a.grid.W && pyi < a.grid.H) {
             const size_t HW = (size_t)a.grid.W * a.grid.H;
             const size_t pix = (size_t)pyi * a.grid.W + pxi;
-            p.gr = a.dL_dcolor[pix];
-            p.gg = a.dL_dcolor[HW + pix];
-            p.gb = a.dL_dcolor[2 * HW + pix];
+            p.gr = dL_dcolor[pix];
+            p.gg = dL_dcolor[HW + pix];
+            p.gb = dL_dcolor[2 * HW + pix];
             if (HAS_DEPTH && a.dL_ddepth) p.gd = a.dL_ddepth[pix];
             if (a.dL_dalpha) p.ga = a.dL_dalpha[pix];
         }

@@ -515,6 +515,19 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
     const float fx = (float)pxi, fy = (float)pyi;
     const uint2 range = TWO ? a.tw.ranges[slot.z] : make_uint2(slot.x, slot.y);
     const int n = (int)(range.y - range.x);
+    if (TWO && n == 0 && reuse_a_pixels(a.src_color, a.src_bg, a.bg)) {
+        // no entry of B in this sub-tile (compose.hip emptied its list): the composite's pixels are source A's own, which
+        // blended exactly the list the merge would have produced, over an equal background
+        if (inside) {
+            const size_t HW = (size_t)a.grid.W * a.grid.H, pix = (size_t)pyi * a.grid.W + pxi;
+            const float c0 = a.src_color[pix], c1 = a.src_color[HW + pix], c2 = a.src_color[2 * HW + pix];
+            const float d = a.src_depth[pix], al = a.src_alpha[pix];
+            a.out_color[pix] = c0; a.out_color[HW + pix] = c1; a.out_color[2 * HW + pix] = c2;
+            a.out_depth[pix] = d; a.out_alpha[pix] = al;
+        }
+        if (STORE && lane == 0) a.tw.fwd_exit[st] = make_uint2(0u, 0u);
+        return;
+    }
 
     float T = 1.0f, live = inside ? 1.0f : 0.0f;
     v2f Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};                     // (r, g) and (b, depth) accumulators

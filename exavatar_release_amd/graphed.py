@@ -32,9 +32,12 @@ to eager :func:`renderer.render_iteration` (same kernels, same order; tests/test
 
 The returned images alias the graph's static outputs: valid until the next call (clone what must survive).
 """
+import ctypes
 import time
 
 import torch
+
+from . import _lib
 
 from . import rasterizer as rz
 from .renderer import ITERATION_RENDERS, _sh_degree, camera_block_device, render_iteration
@@ -101,6 +104,9 @@ class GraphedIteration:
         self.merge, self.growth, self.check = bool(merge), float(capacity_growth), bool(check)
         self._cam = torch.zeros(38, dtype=torch.float32, device=device)   # viewmatrix 16 | projmatrix 16 | campos 3 | bg 3:
         #                                                                   outlives the captures, which read views of it
+        # pointer table of the backward graphs (ExaRasterBackwardJob.dL_dcolor_indirect): entry i holds the address the
+        # backward of render i reads dL/dimg from -- autograd's own tensor of this iteration, no copy into a static buffer
+        self._ptr_table = torch.zeros(16, dtype=torch.int64, device=device)
         self._cap = None
         self._caps_hint = None if capacities is None else [int(c) for c in capacities]   # capacities of the next capture
         self._intr, self._focal_src, self._focal_ver = None, None, None
@@ -240,18 +246,25 @@ class GraphedIteration:
         saved = (rz.config.mode, rz.config.fixed_capacity)
         try:
             rz.config.mode, rz.config.fixed_capacity = 'capacity', list(cap.caps)
+            base = self._ptr_table.data_ptr()
+            rz._capture_grad_ind = {g_in[3 * i].data_ptr(): base + 8 * i for i in range(5) if g_in[3 * i] is not None}
             with torch.enable_grad():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=cap.pool):
                     grads = torch.autograd.grad(outs, inputs, grad_outputs=gos, allow_unused=True, retain_graph=True)
-                    off = 0
+                    # pack into the flat buffer with ONE multi-tensor kernel (twenty elementwise launches cost ~40 us of
+                    # in-graph dispatch gaps; memcpy / memset nodes are not replay-safe on this runtime, a kernel is)
+                    views, present, off = [], [], 0
                     for gr, n in zip(grads, cap.sizes):
-                        if gr is not None:            # (elementwise kernels only: memcpy / memset nodes are not replay-safe)
-                            torch.mul(gr.reshape(-1), 1.0, out=flat[off:off + n])
+                        if gr is not None:
+                            views.append(flat[off:off + n].view(gr.shape))
+                            present.append(gr)
                         off += n
+                    torch._foreach_copy_(views, present)
                 unused = [gr is None for gr in grads]
         finally:
             rz.config.mode, rz.config.fixed_capacity = saved
+            rz._capture_grad_ind = None
         cap.bwd[pattern] = (g, g_in, flat, unused)
         return cap.bwd[pattern]
 
@@ -419,9 +432,24 @@ class GraphedIteration:
             entry = cap.bwd.get(pattern) or self._capture_backward(cap, pattern)
             g, g_in, flat, _unused = entry
             with torch.no_grad():
-                dst = [d for d in g_in if d is not None]
-                src = [s_ if (s_.dtype == torch.float32 and s_.shape == d.shape) else s_.to(torch.float32).expand(d.shape)
-                       for s_, d in zip([s_ for s_ in grads if s_ is not None], dst)]
-                torch._foreach_copy_(dst, src)
+                # colour gradients: the graph reads them THROUGH the pointer table, so a float32 contiguous tensor from
+                # autograd is used where it lies (it outlives the replay in stream order: the caching allocator hands its
+                # block only to work queued later on this stream); anything else is copied into the static buffer first.
+                # Depth / mask gradients (rare) always take the copy.
+                dst, src = [], []
+                ptrs = (ctypes.c_void_p * 5)()
+                for i, (s_, d) in enumerate(zip(grads, g_in)):
+                    if d is None:
+                        continue
+                    direct = i % 3 == 0 and s_.dtype == torch.float32 and s_.shape == d.shape and s_.is_contiguous()
+                    if i % 3 == 0:
+                        ptrs[i // 3] = s_.data_ptr() if direct else d.data_ptr()
+                    if not direct:
+                        dst.append(d)
+                        src.append(s_ if (s_.dtype == torch.float32 and s_.shape == d.shape) else s_.to(torch.float32).expand(d.shape))
+                if dst:
+                    torch._foreach_copy_(dst, src)
+                _lib.check(_lib.load().exa_raster_store_pointers(
+                    ctypes.c_void_p(self._ptr_table.data_ptr()), ptrs, 5, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             g.replay()
             return flat.clone()

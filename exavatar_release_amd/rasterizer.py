@@ -100,6 +100,7 @@ class _Config:
     overflow_check = 'forward'    # 'forward' | 'always' | 'adaptive': where the header report is looked at (module docstring)
     verify_calls = 4          # adaptive: the first calls of a shape wait for their report
     danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
+    compose_reuse_source = True   # composite renders copy source A's pixels where source B has no entry (developer A/B knob)
     upstream_scale_grad = False   # True: dL/dscale as upstream returns it (w.r.t. scale_modifier * scale, i.e. divided
     #                               by scale_modifier); identical for the reference, which passes 1.0 (module.py:615)
 
@@ -113,6 +114,8 @@ _pending = []     # header reports nobody has consumed yet: _Pending records
 overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
 _capture_report = None   # [(slot, tag) | None per job]: reserved header-report slots baked into the batched call being
 #                          CAPTURED (set by GraphedRenderer / GraphedIteration around their capture)
+_capture_grad_ind = None  # {data_ptr of a static dL/dcolor buffer: device address of its pointer-table entry}: set by
+#                           GraphedIteration while it RECORDS a backward graph (ExaRasterBackwardJob.dL_dcolor_indirect)
 _last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
 
 
@@ -798,6 +801,8 @@ class _Rasterize(torch.autograd.Function):
                 a.geom_ws, a.tile_ws, a.bin_ws = j.geom_ptr, j.tile_ptr, j.bin_ptr
                 a.capacity = j.capacity
                 a.dL_dcolor, a.dL_ddepth, a.dL_dalpha = g_color.data_ptr(), _addr(g_depth), _addr(g_alpha)
+                if _capture_grad_ind is not None:
+                    a.dL_dcolor_indirect = _capture_grad_ind.get(g_color.data_ptr())
                 a.grad_ws = grad_ws.data_ptr()
                 a.dL_dmeans2D, a.dL_dmeans3D, a.dL_dcolors = _addr(d_means2D), _addr(d_means3D), _addr(d_colors)
                 a.dL_dopacity, a.dL_dscales, a.dL_drotations = _addr(d_opac), _addr(d_scales), _addr(d_rot)
@@ -852,6 +857,11 @@ def _compose_launch(cjobs, store_ctx, device, capturing):
         base = c.planes.data_ptr()
         H, W = int(c.rs.image_height), int(c.rs.image_width)
         a.out_color, a.out_depth, a.out_alpha = base, base + 12 * H * W, base + 16 * H * W
+        # source A's finished images: where B has no entry the composite's pixels are A's (equal backgrounds are checked on
+        # the device): those sub-tiles skip merge, blend and backward (include/exa_raster.h, ExaRasterComposeJob.a_color)
+        if config.compose_reuse_source and ja.settings.bg:
+            pa = ja.planes.data_ptr()
+            a.a_color, a.a_depth, a.a_alpha, a.a_bg = pa, pa + 12 * H * W, pa + 16 * H * W, ja.settings.bg
         c.report = None
         a.host_header, a.header_tag = None, 0
         if pool is not None:
@@ -995,6 +1005,8 @@ class _Compose(torch.autograd.Function):
                 a.radii = jb.radii.data_ptr()
                 a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = jb.geom_ptr, c.tile_ptr, c.bin_ptr, c.capacity
                 a.dL_dcolor, a.dL_ddepth, a.dL_dalpha = g_color.data_ptr(), _addr(g_depth), _addr(g_alpha)
+                if _capture_grad_ind is not None:
+                    a.dL_dcolor_indirect = _capture_grad_ind.get(g_color.data_ptr())
                 a.grad_ws = grad_ws.data_ptr()
                 a.dL_dmeans2D, a.dL_dmeans3D, a.dL_dcolors = _addr(d_means2D), _addr(d_means3D), _addr(d_colors)
                 a.dL_dopacity, a.dL_dscales, a.dL_drotations = _addr(d_opac), _addr(d_scales), _addr(d_rot)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 131          /* 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 132          /* 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -229,7 +229,16 @@ typedef struct ExaRasterBackwardJob {
      * splat workspace, tile_ws / bin_ws / capacity are the COMPOSITE's workspaces, grad_ws holds 48 B x compose_capacity_b,
      * compose_geom_a / compose_P_a name source A's records (constants: no gradient) and grad_first must be 0. */
     const void* compose_geom_a; int32_t compose_P_a; uint64_t compose_capacity_b;
+    /* Optional (NULL = off): DEVICE address of one pointer that the kernels load at EXECUTION time and read dL/dcolor from,
+     * instead of `dL_dcolor` (which must still be non-NULL: it says that a colour gradient exists).  For callers that
+     * replay this call from a captured hipGraph while the gradient arrives in a different tensor every time (autograd
+     * hands `backward` a fresh one per iteration): exa_raster_store_pointers, enqueued on the same stream ahead of the
+     * replay, points the call at it -- no 12-byte-per-pixel copy into a static buffer (GraphedIteration). */
+    const float* const* dL_dcolor_indirect;
 } ExaRasterBackwardJob;
+
+/* Stores `n` (<= 16) pointers into `table` (device memory) with one tiny kernel, in stream order. */
+int exa_raster_store_pointers(void* table, const void* const* ptrs, int32_t n, void* stream);
 
 /*
  * Composite renders: "A and B rendered together" from two renders of the SAME camera and image size that already exist,
@@ -250,6 +259,13 @@ typedef struct ExaRasterComposeJob {
     void* tile_ws; void* bin_ws; uint64_t capacity;      /* capacity_a + capacity_b always suffices                     */
     float* out_color; float* out_depth; float* out_alpha;
     void* host_header; uint32_t header_tag;             /* as in ExaRasterForwardJob                                    */
+    /* Optional (all four NULL = off): source A's OWN finished output images and the background pointer it was rendered with.
+     * Where B has no entry in a sub-tile, the composite's pixels ARE A's pixels -- same list, same arithmetic -- provided
+     * the two backgrounds hold equal values (compared on the device): such sub-tiles then get an EMPTY list in the
+     * composite (no merge, no batch slots, no backward waves) and their 64 pixels are copied from A's images instead of
+     * being blended again.  In ExAvatar's scene + human composites (avatar/main/model.py:129,146: both on the default white
+     * background) that is every sub-tile outside the person: ~3/4 of the image.  Bit-identical either way. */
+    const float* a_color; const float* a_depth; const float* a_alpha; const float* a_bg;
 } ExaRasterComposeJob;
 /* tile_bytes / bin_bytes of a composite's workspaces, grad_bytes of its backward scratch (geom_bytes = 0) */
 int exa_raster_compose_sizes(int32_t W, int32_t H, uint64_t capacity, uint64_t capacity_b, ExaRasterWorkspaceSizes* out);

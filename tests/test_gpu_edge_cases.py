@@ -552,6 +552,58 @@ def test_composite_renders_depth_ties_long_lists_and_ragged_images(dev):
     _assert_iteration_agrees(res)
 
 
+def test_composite_copies_the_scene_where_the_human_is_absent(dev):
+    """Where source B (the human) has no entry in a sub-tile, the composite's pixels are source A's own render (same list,
+    same arithmetic, equal backgrounds): compose.hip empties such lists and render_fwd copies A's pixels
+    (ExaRasterComposeJob.a_color).  A small avatar in front of a scene that fills the image: most sub-tiles take the copy.
+    Bit-identical to blending everything again (knob off), to the concatenated render, in every image plane and gradient;
+    with a DIFFERENT background on the scene render the device-side check must switch the copy off."""
+    from exavatar_release_amd.renderer import _raster_job, _output_dict
+    from exavatar_release_amd.rasterizer import rasterize_composites, rasterize_gaussians_batch
+    H, W, f = 192, 256, 260.0
+    scene = scenes.dist_a_random(6000, H, W, seed=91, focal=f, z_range=(3.0, 8.0))
+    human = scenes.dist_b_avatar(3000, seed=92)
+    human['mean_3d'] = human['mean_3d'] * 0.45 + torch.tensor([0.0, 0.0, 1.6])     # small, in the middle, in front of the scene
+    human['scale'] = human['scale'] * 0.45
+    cam = {k: t.to(dev) for k, t in scenes.neutral_camera(H, W, focal=f).items()}
+    g = torch.Generator().manual_seed(93)
+    G = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(2)]
+    Gd = torch.randn(1, H, W, generator=g).to(dev)
+
+    def run(scene_bg, reuse):
+        exa.config.compose_reuse_source = reuse
+        try:
+            s, h = _to(scene, dev), _to(human, dev)
+            plain = [_raster_job(s, (H, W), cam, scene_bg), _raster_job(h, (H, W), cam, None)]
+            outs, handles = rasterize_gaussians_batch(plain, keep_keys=True)
+            comp = [_raster_job(h, (H, W), cam, None)]
+            co = rasterize_composites([(handles[0], handles[1])], comp)[0]
+            o = _output_dict(comp[0], co)
+            ((o['img'] * G[0]).sum() + (o['depthmap'] * Gd).sum() + (outs[0][0] * G[1]).sum()).backward()
+            torch.cuda.synchronize()
+            return [o['img'].detach().clone(), o['depthmap'].detach().clone(), o['mask'].detach().clone(), o['radius'].clone()], \
+                [h[k].grad.clone() for k in KEYS] + [s[k].grad.clone() for k in KEYS] + [o['mean_2d'].grad.clone()]
+        finally:
+            exa.config.compose_reuse_source = True
+    white = None
+    red = torch.tensor([1.0, 0.0, 0.0], device=dev)
+    base_p, base_g = run(white, False)
+    # how much of the image the human leaves alone: the copy must matter in this test
+    mask = base_p[2][0]
+    for name, (p_, g_) in (('copy', run(white, True)), ('other background: no copy', run(red, True))):
+        for i, (x, y) in enumerate(zip(p_, base_p)):
+            assert torch.equal(x, y), (name, 'plane', i)
+        for i, (x, y) in enumerate(zip(g_[:5] + g_[10:], base_g[:5] + base_g[10:])):        # (the scene's own gradients depend on its bg)
+            assert torch.equal(x, y), (name, 'grad', i)
+    # ... and the reference's formulation: one render of the concatenation
+    s, h = _to(scene, dev), _to(human, dev)
+    cat = {k: torch.cat((s[k].detach(), h[k])) for k in KEYS}
+    ref = exa.GaussianRenderer()(cat, (H, W), cam, None)
+    assert torch.equal(ref['img'].detach(), base_p[0]) and torch.equal(ref['depthmap'].detach(), base_p[1])
+    # the header of a composite with the copy names far fewer batch slots than the merged lists of the whole image would
+    assert float((mask > 0).float().mean()) > 0.5       # (the scene covers most pixels; the human only a few sub-tiles)
+
+
 def test_composite_render_agrees_with_the_oracle(dev):
     """The composite against the CPU oracle on the concatenation (not only against the HIP path's own concatenated render)."""
     H, W, f = 96, 128, 150.0

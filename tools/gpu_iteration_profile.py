@@ -18,8 +18,14 @@ rend = exa.GaussianRenderer()
 cat = lambda a, b: {k: torch.cat((a[k].detach(), b[k])) for k in keys}      # noqa: E731
 
 
+graphed = exa.GraphedIteration((H, W), dev) if how == 'graphed' else None
+
+
 def iteration():
-    if how == 'sets':
+    if how == 'graphed':
+        res = graphed(scene, human, refined, cam, bg)
+        outs = [res[k] for k in exa.ITERATION_RENDERS]
+    elif how == 'sets':
         res = exa.render_iteration(rend, scene, human, refined, (H, W), cam, bg)
         outs = [res[k] for k in exa.ITERATION_RENDERS]
     else:
