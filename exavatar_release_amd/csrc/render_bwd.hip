@@ -157,19 +157,31 @@ struct BwdPay {
 
 constexpr uint32_t NO_SLOT = 0xffffffffu;         // s_pslot of a constant (frozen) entry: nothing to write
 
-template <bool HAS_DEPTH, int GC, int SPW, bool PREFIX>
-__global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
+// WPB: independent waves per workgroup (each with its own slot and its own LDS; no barrier anywhere): a developer knob
+// (EXA_BWD_WPB = 2 | 4), default 1.  Measured in round 4 on the suspicion that launches over mostly EMPTY instance buffers
+// (the composites' backward: 80 k slots, a tenth of them with work) are bound by the dispatch of their workgroups: they
+// are not -- four waves per workgroup cost the five-render iteration 0.909 -> 0.968 ms with the composites alone and
+// 1.045 ms with the plain backward too, and the C3 headline 6 415 -> 6 365 it/s (a workgroup holds its LDS and its
+// dispatch slot until its slowest wave is done).
+template <bool HAS_DEPTH, int GC, int SPW, bool PREFIX, int WPB>
+__global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBwdArgs> batch) {
     typedef XLayout<GC> XL;
-    __shared__ BatchLds s_b;
-    __shared__ float4 s_pg[4 * 17];             // incoming gradient of each pixel (r, g, b, depth), 16 per pixel group;
+    __shared__ BatchLds s_b_[WPB];
+    __shared__ float4 s_pg_[WPB][4 * 17];       // incoming gradient of each pixel (r, g, b, depth), 16 per pixel group;
                                                 // group stride 17: the two groups one ds_read_b128 quarter-wave sees
                                                 // sit on different banks
-    __shared__ uint32_t s_pslot[64];            // Partial slot of each staged splat
-    __shared__ __attribute__((aligned(16))) float s_x[XLayout<GC>::FLOATS];   // {aG, w}[pixel group][splat][pixel of the group]
+    __shared__ uint32_t s_pslot_[WPB][64];      // Partial slot of each staged splat
+    __shared__ __attribute__((aligned(16))) float s_x_[WPB][XLayout<GC>::FLOATS];   // {aG, w}[pixel group][splat][pixel of the group]
 
     const RenderBwdArgs& a = batch.v[blockIdx.y];
     const uint32_t nslots = (uint32_t)(a.capacity / BATCH);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const uint32_t wg = (uint32_t)blockIdx.x * WPB + (uint32_t)wv;        // this wave's position in the launch
+    BatchLds& s_b = s_b_[wv];
+    float4* const s_pg = s_pg_[wv];
+    uint32_t* const s_pslot = s_pslot_[wv];
+    float* const s_x = s_x_[wv];
 #ifdef EXA_PROBE_BWDLINE   // probe build only (tools/gpu_bwd_timeline.py): start / end of every wave on the chip-wide 100 MHz clock
     struct TL { const RenderBwdArgs& a; unsigned long long t0; int lane;
         __device__ ~TL() { if (lane == 0 && 2 * blockIdx.x + 1 < (uint32_t)(a.grid.cells * BIN_PARTS * SUBS_PER_CELL)) {
@@ -260,13 +272,13 @@ __global__ __launch_bounds__(RBLOCK) void render_bwd_kernel(Batch<RenderBwdArgs>
     // the waves past the end.  Composites, the EXA_BWD_SPW variants and batched launches (K > 1 jobs: the stream of waves of
     // several jobs balances itself, and the extra dependent load cost 2.5 % there: 8 490 -> 8 260 it/s at K = 8) keep the
     // slot order.
-    uint32_t first_slot = blockIdx.x * SPW;
+    uint32_t first_slot = wg * SPW;
     if (SPW == 1 && gridDim.y == 1) {
         const uint32_t m0 = a.tw.bwd_meta[0], m1 = a.tw.bwd_meta[1], magic = a.tw.bwd_meta[2];
         // (requested together with the three words above: one trip; a composite's bin workspace has no bucket array)
-        const uint32_t mapped = a.bw.bucket ? reinterpret_cast<const uint32_t*>(a.bw.bucket)[min(blockIdx.x, nslots - 1u)] : 0u;
+        const uint32_t mapped = a.bw.bucket ? reinterpret_cast<const uint32_t*>(a.bw.bucket)[min(wg, nslots - 1u)] : 0u;
         if (magic == BWD_ORDER_MAGIC && a.bw.bucket) {
-            if (blockIdx.x >= m0 + m1) return;
+            if (wg >= m0 + m1) return;
             first_slot = mapped;
         }
     }
@@ -427,22 +439,24 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
     const Batch<RenderBwdArgs> b = make_batch(a, K);
     // EXA_BWD_LDS_PAD (bytes, developer knob): unused dynamic LDS per workgroup = fewer resident waves per SIMD (occupancy probe)
     static const int pad = [] { const char* e = getenv("EXA_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();
-#define EXA_LAUNCH_BWD(D, G, S) render_bwd_kernel<D, G, S, false><<<dim3((unsigned)((slots + S - 1) / S), K), RBLOCK, (size_t)pad, s>>>(b)
+    // waves per workgroup (see the kernel): 1; EXA_BWD_WPB overrides (A/B)
+    static const int wpb_env = [] { const char* e = getenv("EXA_BWD_WPB"); return e ? atoi(e) : 0; }();
+#define EXA_LAUNCH_BWD(D, G, S, PFX, W) \
+    render_bwd_kernel<D, G, S, PFX, W><<<dim3((unsigned)((slots + (S) * (W) - 1) / ((S) * (W))), K), RBLOCK * (W), (size_t)pad, s>>>(b)
+#define EXA_LAUNCH_BWD_D(G, S, PFX, W) do { if (depth) EXA_LAUNCH_BWD(true, G, S, PFX, W); else EXA_LAUNCH_BWD(false, G, S, PFX, W); } while (0)
     if (prefix) {
-        if (gc == 8) {
-            if (depth) render_bwd_kernel<true, 8, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
-            else render_bwd_kernel<false, 8, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
-        } else {
-            if (depth) render_bwd_kernel<true, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
-            else render_bwd_kernel<false, 16, 1, true><<<dim3((unsigned)slots, K), RBLOCK, (size_t)pad, s>>>(b);
-        }
+        const int w = wpb_env ? wpb_env : 1;
+        if (gc == 8) { if (w >= 4) EXA_LAUNCH_BWD_D(8, 1, true, 4); else EXA_LAUNCH_BWD_D(8, 1, true, 1); }
+        else EXA_LAUNCH_BWD_D(16, 1, true, 1);
     } else if (gc == 8) {
-        if (depth) EXA_LAUNCH_BWD(true, 8, 1); else EXA_LAUNCH_BWD(false, 8, 1);
+        const int w = wpb_env ? wpb_env : 1;
+        if (w >= 4) EXA_LAUNCH_BWD_D(8, 1, false, 4); else if (w == 2) EXA_LAUNCH_BWD_D(8, 1, false, 2); else EXA_LAUNCH_BWD_D(8, 1, false, 1);
     } else if (spw == 2) {
-        if (depth) EXA_LAUNCH_BWD(true, 16, 2); else EXA_LAUNCH_BWD(false, 16, 2);
+        EXA_LAUNCH_BWD_D(16, 2, false, 1);
     } else {
-        if (depth) EXA_LAUNCH_BWD(true, 16, 1); else EXA_LAUNCH_BWD(false, 16, 1);
+        EXA_LAUNCH_BWD_D(16, 1, false, 1);
     }
+#undef EXA_LAUNCH_BWD_D
 #undef EXA_LAUNCH_BWD
     return hipGetLastError();
 }
