@@ -30,10 +30,82 @@ namespace exa {
 // accumulated into one set of statistics): the per-view norms / counts / radii are summed in registers, across the
 // waves through LDS, and written by ONE thread per Gaussian -- the per-view read-modify-write below would race between
 // the waves of a workgroup.  (Distinct arrays per view need no such care; partial aliasing is rejected by the C ABI.)
+// ---- wave-cooperative gather of the partial records ---------------------------------------------------------------
+// The 64 Gaussians of a wave own CONSECUTIVE ranges of the Gaussian-major instance numbering (a typical avatar splat ~6
+// instances, some lane of most waves 25-40).  Until round 4 every lane walked its own range -- `touched` bytes, then the
+// flagged 48-byte records, eight instances per trip -- and the wave left that loop with its slowest lane: five trips of two
+// dependent, fully divergent gathers = 9-12 us of the kernel's 17.6 on C3 (tools/gpu_pbwd_phases.py).  Now the wave
+// streams the concatenation of its lanes' ranges through LDS: stream position q -> (lane, instance) by a binary search
+// over the wave's prefix of instance counts, GCH positions per chunk with ALL their `touched` bytes requested at once and
+// then all their flagged records (neighbouring lanes read neighbouring slots: coalesced), staged in LDS; each lane then
+// sums ITS instances from LDS in slot order -- the very order and arithmetic of the old per-lane loop (an unflagged slot adds
+// +0), so the results are bit-identical to it.  Two dependent global round trips per GCH slots of the whole wave instead of
+// per eight instances of its slowest lane.  Splats with >= COOP_MIN instances keep their own whole-wave path.
+#ifndef EXA_PBWD_GCH
+#define EXA_PBWD_GCH 256
+#endif
+constexpr int GCH = EXA_PBWD_GCH;             // staged slots per chunk and wave (48 B each)
+struct GatherLds {
+    uint32_t pre[64], off[64];
+    float4 rec[GCH * 3];
+};
+__device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const uint8_t* __restrict__ touched,
+                                              const float4* __restrict__ prec, float (&sum)[10], GatherLds& L, int lane) {
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    const uint32_t pre = incl - n;
+    const uint32_t S = (uint32_t)__shfl((int)incl, 63, 64);            // wave-uniform
+    if (S == 0u) return;
+    L.pre[lane] = pre; L.off[lane] = off;
+    wave_lds_fence();
+    for (uint32_t c0 = 0; c0 < S; c0 += GCH) {
+        uint32_t slot[GCH / 64];
+        uint32_t fl = 0;
+#pragma unroll
+        for (int u = 0; u < GCH / 64; ++u) {
+            const uint32_t q = c0 + 64u * u + (uint32_t)lane;
+            const bool in = q < S;
+            // the LAST lane g with pre[g] <= q owns position q (lanes without instances share their successor's prefix)
+            uint32_t g = 0;
+#pragma unroll
+            for (int s2 = 32; s2 > 0; s2 >>= 1)
+                if (L.pre[g + s2] <= q) g += s2;
+            slot[u] = in ? L.off[g] + (q - L.pre[g]) : 0u;
+            const uint32_t t = in ? touched[slot[u]] : 0u;
+            fl |= (t ? 1u : 0u) << u;
+        }
+#pragma unroll
+        for (int u = 0; u < GCH / 64; ++u) {
+            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
+            if ((fl >> u) & 1u) {
+                const float4* src = prec + (size_t)slot[u] * 3;
+                q0 = src[0]; q1 = src[1]; q2 = src[2];
+            }
+            float4* dst = L.rec + (64 * u + lane) * 3;
+            dst[0] = q0; dst[1] = q1; dst[2] = q2;
+        }
+        wave_lds_fence();
+        const uint32_t lo = pre > c0 ? pre : c0, hi = (pre + n) < (c0 + GCH) ? (pre + n) : (c0 + GCH);
+        for (uint32_t j = lo; j < hi; ++j) {
+            const float4* src = L.rec + (j - c0) * 3;
+            const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+            sum[0] += q0.x; sum[1] += q0.y; sum[2] += q0.z; sum[3] += q0.w;
+            sum[4] += q1.x; sum[5] += q1.y; sum[6] += q1.z; sum[7] += q1.w;
+            sum[8] += q2.x; sum[9] += q2.y;
+        }
+        wave_lds_fence();                                           // the next chunk overwrites the staging area
+    }
+}
+
 template <bool SUM, int VW, bool SH, bool PREFIX>
 __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K, int dens_shared) {
     static_assert(VW == 1 || (SUM && VW == BLOCK / 64), "views are split over the waves of a workgroup in SUM mode only");
     __shared__ float s_red[VW > 1 ? 23 * BLOCK : 1];
+    __shared__ GatherLds s_gather[BLOCK / 64];
     const PreprocessBwdArgs& out = batch.v[SUM ? 0 : blockIdx.y];
     constexpr int GPB = BLOCK / VW;                             // Gaussians per workgroup
     if ((int)(blockIdx.x * GPB) >= out.P) return;               // workgroup-uniform
@@ -121,51 +193,15 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         }
 
         PBWD_PHASE(0);                                          // splat row 3 here (first trip), heavy splats gathered
+        // ---- this wave's blended instances (contiguous slots, each written at most once), gathered together ----------
+        float own[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        stream_gather(r3.w, (vis && r3.z < COOP_MIN) ? r3.z : 0u, touched, prec, own, s_gather[threadIdx.x >> 6], lane);
         float vmean[3] = {0.f, 0.f, 0.f}, vm2[2] = {0.f, 0.f}, vscale[3] = {0.f, 0.f, 0.f};
         float vq[4] = {0.f, 0.f, 0.f, 0.f}, vcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float vop = 0.f, vcol[3] = {0.f, 0.f, 0.f};
         if (vis) {
-            // ---- gather this Gaussian's blended instances (contiguous slots, each written at most once) ----------
-            float mx = 0.f, my = 0.f, mxx = 0.f, mxy = 0.f, myy = 0.f, dz_view = 0.f;
-            {
-                // (Round 3, phase probe tools/gpu_pbwd_phases.py: the wave leaves this loop with its SLOWEST lane -- 9.2 us of
-                //  the kernel's 14 on C3, chain rule 1.5, stores 0.5.  Requesting the next trip's `touched` bytes during the
-                //  current one and fetching the flagged records compacted changed nothing (20.2 vs 20.4 us); all eight
-                //  records of a trip at once: 22.8 us.  Like the column walk of cell_scatter, the loop does not respond to
-                //  fewer dependent trips: it is bound by the divergent 16-byte accesses themselves.)
-                const uint32_t n_own = r3.z < COOP_MIN ? r3.z : 0u;     // larger ones were fetched by the whole wave above
-                const uint32_t off = r3.w;
-                for (uint32_t i = 0; i < n_own; i += 8) {
-                    // the `touched` bytes of eight instances in one round trip (a typical avatar splat has ~6) ...
-                    uint32_t fl = 0;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const bool in = i + u < n_own;
-                        const uint32_t t = touched[off + (in ? i + u : i)];
-                        fl |= (in && t) ? (1u << u) : 0u;
-                    }
-                    // ... then only the flagged records, four at a time: 12 independent loads in flight (an unflagged
-                    // slot re-reads the trip's first record -- a cache hit -- and is masked out)
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        if (((fl >> (4 * half)) & 15u) == 0u) continue;
-                        float4 q0[4], q1[4], q2[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const bool ok = (fl >> (4 * half + u)) & 1u;
-                            const float4* src = prec + (size_t)(off + (ok ? i + 4 * half + u : i)) * 3;
-                            q0[u] = src[0]; q1[u] = src[1]; q2[u] = src[2];
-                            if (!ok) { q0[u] = make_float4(0.f, 0.f, 0.f, 0.f); q1[u] = q0[u]; q2[u] = q0[u]; }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            mx += q0[u].x; my += q0[u].y; mxx += q0[u].z; mxy += q0[u].w;
-                            myy += q1[u].x; vop += q1[u].y; vcol[0] += q1[u].z; vcol[1] += q1[u].w;
-                            vcol[2] += q2[u].x; dz_view += q2[u].y;
-                        }
-                    }
-                }
-            }
+            float mx = own[0], my = own[1], mxx = own[2], mxy = own[3], myy = own[4], dz_view = own[9];
+            vop = own[5]; vcol[0] = own[6]; vcol[1] = own[7]; vcol[2] = own[8];
 
             PBWD_PHASE(1);                                      // own partial records gathered
             mx += co[0]; my += co[1]; mxx += co[2]; mxy += co[3]; myy += co[4];

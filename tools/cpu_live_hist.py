@@ -63,3 +63,44 @@ with torch.no_grad():
           % (float((hist * w).sum()) / tot, 100 - 100 * float((hist * w).sum()) / tot / 64))
     long_ = sorted(lists, reverse=True)[:10]
     print('  ten longest lists (listed, walked):', long_)
+
+# ---- the same question for the BACKWARD: per entered batch its blended entries in chunks of eight (render_bwd.hip), live
+# pixels at the first entry of every chunk
+with torch.no_grad():
+    hist_b = torch.zeros(65, dtype=torch.long)
+    for t in range(gx * gy):
+        s0, e0 = ranges[t].tolist()
+        if e0 == s0:
+            continue
+        tx, ty = t % gx, t // gx
+        ids = sorted_idx[s0:e0]
+        for sy in range(2):
+            for sx in range(2):
+                ox = tx * 16 + sx * 8; oy = ty * 16 + sy * 8
+                sel = (bx0[ids] <= ox + 7) & (bx1[ids] >= ox) & (by0[ids] <= oy + 7) & (by1[ids] >= oy)
+                l = ids[sel]
+                n = l.numel()
+                if n == 0:
+                    continue
+                X = torch.arange(ox, ox + 8, dtype=dtype).repeat(8); Y = torch.arange(oy, oy + 8, dtype=dtype).repeat_interleave(8)
+                dx = px[l][:, None] - X[None, :]; dy = py[l][:, None] - Y[None, :]
+                cn = conic[l]
+                power = -0.5 * (cn[:, 0:1] * dx * dx + cn[:, 2:3] * dy * dy) - cn[:, 1:2] * dx * dy
+                a = (opac[l][:, None] * torch.exp(power)).clamp(max=0.99)
+                valid = (power <= 0) & (a >= 1 / 255.)
+                av = torch.where(valid, a, torch.zeros_like(a))
+                Tin = torch.cumprod(1 - av, 0)
+                Tex = torch.cat((torch.ones(1, 64), Tin[:-1]), 0)
+                alive = Tex >= 1e-4
+                blended = (valid & alive).any(1)
+                live = alive.sum(1)
+                for b0 in range(0, n, 64):
+                    if not bool(alive[b0].any()):
+                        break
+                    idx = torch.nonzero(blended[b0:b0 + 64]).flatten() + b0
+                    if idx.numel():
+                        hist_b += torch.bincount(live[idx[::8]], minlength=65)
+    tot = int(hist_b.sum()); cum = torch.cumsum(hist_b, 0)
+    print('backward: chunks of eight blended entries:', tot)
+    for k in (4, 8, 16, 32, 48, 63, 64):
+        print('  chunks starting with <= %2d live pixels: %5.1f %%' % (k, 100.0 * int(cum[k]) / tot))
