@@ -35,7 +35,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_VIEWS = 200
 VIEW_STRIDE = 123      # step i renders ring view (i * VIEW_STRIDE) mod N_VIEWS (coprime: a permutation)
-PROFILE_PREFIXES = ('r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
+PROFILE_PREFIXES = ('r04', 'r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
 
 
 def parse():
@@ -432,6 +432,10 @@ def main():
         tr, src = pmc_traffic(dom) if args.config == 'c3' and train else (None, None)
         result['roofline']['traffic'] = tr
         result['roofline']['traffic_source'] = src
+        rp = rocprof_time(dom) if args.config == 'c3' and train else None
+        if rp is not None:      # the committed rocprofv3 average of the same kernel (kernel begin -> end, no launch gap in the bracket)
+            result['roofline']['rocprof'] = {'avg_launch_us': rp[0], 'frac': alg[dom] / (rp[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                             'source': rp[1]}
         eb = result.get('extra_batched_views')
         if isinstance(eb, dict) and 'ms_per_launch' in eb:
             kb = eb['views_per_launch']
@@ -483,6 +487,21 @@ def pmc_traffic(kernel):
         except Exception:  # noqa: BLE001
             pass
     return None, None
+
+
+def rocprof_time(kernel):
+    """(average duration in us of `kernel` by rocprofv3 --kernel-trace --stats, source) from the committed profile of the
+    newest round that has one (builder-side, NOT measured in this run); None if unavailable."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for prefix in PROFILE_PREFIXES:
+        try:
+            name = prefix + '_kernel_stats.json'
+            with open(os.path.join(here, 'profiles', name)) as f:
+                d = json.load(f)
+            return float(d['kernels'][kernel]['avg_us']), 'profiles/%s (%s; not collected in this run)' % (name, d['what'])
+        except Exception:  # noqa: BLE001
+            pass
+    return None
 
 
 def other_config(cfg, args):
