@@ -15,8 +15,9 @@
 // differ from the forward's by an ulp, which can move a `T < 1e-4` stop only when T (1 - alpha) lies within ~1e-7
 // (relative) of the threshold, with an effect of <= 1e-4 on that pixel's weights -- far inside the 1e-3 bar.
 //
-// The kernel is bound by VALU issue (profiles/: ~80 % of the issue slots with ~3 waves per SIMD; HBM < 10 % of
-// peak), so the design minimises instructions per (pixel, splat) pair.  Two phases per chunk of GC = 16 splats:
+// The kernel is bound by VALU issue (profiles/r04_pmc.md: the VALU pipes are busy 81 % of the launch incl. its ramp and tail,
+// five waves per SIMD at 91 VGPRs / 8 128 B of LDS per wave; 14 % of the HBM roofline), so the design minimises instructions
+// per (pixel, splat) pair.  Two phases per chunk of GC = 8 splats (GC = 16: the round-2 layout, EXA_BWD_GC=16):
 //
 //  Phase A  (lane = pixel, splats in list order): REPLAY the forward recurrence from the checkpoint with the
 //           forward's own code (blend.h) -- no 1/(1-alpha) reconstruction of T, no `n_contrib` array -- and
@@ -24,13 +25,15 @@
 //               R_i = (C_fin - C_i) . g - tail,      tail = T_fin (g_alpha - bg . g)
 //               dL/d(alpha_i) = T_i (c_i . g) - R_{i+1} / (1 - alpha_i)
 //           ("." also runs over the depth channel).  Two numbers per pair go to LDS as one 8-byte store:
-//           aG = G dL/dalpha and the blend weight w = alpha T.
-//  Phase B  (lane = splat g, pixel group h of 16 pixels): the transposed read (ds_read_b128, row stride 36 floats:
-//           conflict-free) turns the per-splat sums over the 64 pixels into per-lane accumulation.  The screen-space
-//           moments are accumulated against COMPILE-TIME pixel coordinates (x - 4 in -4..3, row 0 / 1 of the group):
-//           sum aG, sum aG x, sum aG x^2, sum aG y, sum aG x y -- 3.7 VALU per pixel instead of 8 with per-lane
-//           dx, dy -- and shifted to the splat centre once per chunk; + 3 (4) FMAs for the colour (depth) sums.
-//           The four pixel groups are combined with two shuffle steps.
+//           aG = G dL/dalpha and the blend weight w = alpha T.  236 VALU instructions per chunk.
+//  Phase B  (lane = (splat g, pixel row h), XLayout<8>): the transposed read (ds_read_b128, entry stride 132 floats:
+//           conflict-free in gfx950's lane groups) turns the per-splat sums over the 64 pixels into per-lane accumulation.
+//           The screen-space moments are accumulated against COMPILE-TIME pixel coordinates (x - 4 in -4..3):
+//           sum aG, sum aG x, sum aG x^2 per pixel row, shifted to the splat centre once per chunk; + 3 (4) FMAs for the
+//           colour (depth) sums.  The eight pixel rows of a splat sit in eight consecutive lanes and are combined with
+//           three v_add_f32_dpp each (one asm block for the nine sums).  92 VALU instructions per chunk.
+//  All staged float4 reads stay 16 bytes wide (keep_b128): narrowed to ds_read_b96 they cost 3.6 M bank-conflict cycles
+//  per dispatch in round 3.
 //
 // Only blended instances get their 48-byte Gaussian-major partial record written (exactly once: no memset, NO atomic
 // in the whole backward pass -- device-scope fp32 atomics run at ~12 G/s on MI355X -- bit-deterministic) and their
