@@ -387,7 +387,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
             depth_bits[it] = 0;
             if (ids[it] < P) {
                 r3[it] = reinterpret_cast<const uint4*>(splats + ids[it])[3];
-                depth_bits[it] = reinterpret_cast<const uint4*>(splats + ids[it])[0].z;
+                depth_bits[it] = reinterpret_cast<const uint4*>(splats + ids[it])[2].w;
             }
         }
     };

@@ -35,11 +35,14 @@ struct BatchLds {
     float4 col[BATCH];                           // r, g, b, depth
 };
 
-// Stage the record held by this lane (rows 0..2 of its Splat) as entry `lane` of the batch.
-__device__ __forceinline__ void stage_splat(BatchLds& s, int lane, const float4& r0, const float4& r1, const float4& r2) {
+// Stage the record held by this lane (rows 0..2 of its Splat) as entry `lane` of the batch.  Row 2 = (r, g, b, depth) goes
+// to LDS as loaded (common.h, Splat).
+// (r0 = the first TWO words of row 0 only: with the whole row loaded, the compiler recycled the registers of its dead
+//  components as address temporaries right behind the prefetch and waited for the load to land before it could.)
+__device__ __forceinline__ void stage_splat(BatchLds& s, int lane, const float2& r0, const float4& r1, const float4& r2) {
     s.px[lane] = r0.x; s.py[lane] = r0.y;
     s.ca[lane] = r1.x; s.cb[lane] = r1.y; s.cc[lane] = r1.z; s.op[lane] = r1.w;
-    s.col[lane] = make_float4(r2.x, r2.y, r2.z, r0.z);
+    s.col[lane] = r2;
 }
 
 // alpha (0 when the splat is skipped at this pixel: power > 0 or alpha < 1/255) and falloff G of two splats

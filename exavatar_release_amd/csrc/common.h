@@ -47,10 +47,14 @@ constexpr float T_EPS = 1e-4f;
 constexpr float LOG2E = 1.4426950408889634f;
 
 // 64-byte per-Gaussian splat record: one cache line per gather in the per-pixel kernels.
+// Row 2 is what the blends stage as their colour operand AS IT IS (r, g, b, depth: one ds_write_b128 of the loaded row).
+// Until round 4 the depth sat in row 0 and the staged float4 was assembled from two rows: the compiler placed that
+// v_mov right behind the prefetch loads of the NEXT batch and a `s_waitcnt vmcnt(1)` with it -- the forward blend
+// stalled for a whole gather round trip at the start of every 64-entry batch.
 struct alignas(64) Splat {
-    float px, py, depth; int32_t radius;          // row 0
+    float px, py; uint32_t flags; int32_t radius;  // row 0: pixel centre, SH clamp bits (bit c: channel c clamped), radius
     float ca, cb, cc, opacity;                    // row 1: (-A/2, -B, -C/2) * log2(e) of the conic (A, B, C), opacity
-    float r, g, b; uint32_t flags;                // row 2: colour + SH clamp bits (bit c: channel c clamped)
+    float r, g, b, depth;                         // row 2: colour, view-space depth
     uint32_t sub_x, sub_y, n_inst, inst_off;      // row 3: sx0 | sx1 << 16, sy0 | sy1 << 16 (sub-tile rect,
                                                   //        exclusive upper), instances, Gaussian-major offset
 };

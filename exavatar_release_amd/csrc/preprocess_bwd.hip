@@ -346,7 +346,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
 
         // ---- SH colour ---------------------------------------------------------------------------
         if (SH && a.shs) {
-            const uint32_t flags = reinterpret_cast<const uint4*>(a.splats + idc)[2].w;
+            const uint32_t flags = reinterpret_cast<const uint4*>(a.splats + idc)[0].z;
             const float g[3] = {(flags & 1u) ? 0.f : vcol[0], (flags & 2u) ? 0.f : vcol[1], (flags & 4u) ? 0.f : vcol[2]};
             const float* cp = a.campos;
             const float ux = x - cp[0], uy = y - cp[1], uz = z - cp[2];

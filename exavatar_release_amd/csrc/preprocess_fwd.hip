@@ -214,11 +214,11 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
         if (sxy[1] > sxy[0] && sxy[3] > sxy[2]) n_inst = (uint32_t)(sxy[1] - sxy[0]) * (uint32_t)(sxy[3] - sxy[2]);
         else sxy[0] = sxy[1] = sxy[2] = sxy[3] = 0;
     }
-    rec[0] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pvz), (uint32_t)radius);
+    rec[0] = make_uint4(__float_as_uint(px), __float_as_uint(py), flags, (uint32_t)radius);
     // conic pre-scaled for the per-pixel kernels: log2 G = A' dx^2 + B' dx dy + C' dy^2 (blend.h)
     rec[1] = make_uint4(__float_as_uint((-0.5f * LOG2E) * ca), __float_as_uint(-LOG2E * cb), __float_as_uint((-0.5f * LOG2E) * cc),
                         __float_as_uint(op));
-    rec[2] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cbl), flags);
+    rec[2] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cbl), __float_as_uint(pvz));
     rec[3] = make_uint4((uint32_t)sxy[0] | ((uint32_t)sxy[1] << 16), (uint32_t)sxy[2] | ((uint32_t)sxy[3] << 16),
                         n_inst, 0u);
     return n_inst;

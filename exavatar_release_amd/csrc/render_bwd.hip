@@ -152,7 +152,7 @@ struct BwdHdr {
 // ... and the batch itself (round trip 2): this lane's splat record, partial slot, the per-pixel state at the start of the
 // batch and at the forward's exit, the incoming pixel gradient.
 struct BwdPay {
-    float4 r0, r1, r2;
+    float2 r0; float4 r1, r2;
     uint32_t pslot;
     float cs0, cs1, cs2, cs3, cs4, cf0, cf1, cf2, cf3, cf4;
     float gr, gg, gb, gd, ga;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
     auto load_pay = [&](const BwdHdr& h, uint32_t slot) -> BwdPay {
         BwdPay p;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        p.r0 = zero4; p.r1 = zero4; p.r2 = zero4; p.pslot = 0u;
+        p.r0 = make_float2(0.f, 0.f); p.r1 = zero4; p.r2 = zero4; p.pslot = 0u;
         p.cs0 = 1.0f; p.cs1 = p.cs2 = p.cs3 = p.cs4 = 0.f;
         p.cf0 = p.cf1 = p.cf2 = p.cf3 = p.cf4 = 0.f;
         p.gr = p.gg = p.gb = p.gd = p.ga = 0.f;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
                 if (h.id & SRC_B) { base = a.splats2; last = (uint32_t)(a.P2 - 1); }
             }
             const float4* rec = reinterpret_cast<const float4*>(base + min(idx, last));
-            p.r0 = rec[0]; p.r1 = rec[1]; p.r2 = rec[2];
+            p.r0 = *reinterpret_cast<const float2*>(rec); p.r1 = rec[1]; p.r2 = rec[2];
             const uint4 r3 = reinterpret_cast<const uint4*>(rec)[3];
             const int sx0 = r3.x & 0xffff, sx1 = r3.x >> 16, sy0 = r3.y & 0xffff;
             p.pslot = r3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));

@@ -540,13 +540,14 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
 
     // software pipeline: ids two batches ahead, records one batch ahead
     uint32_t id_next = 0;
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    float2 r0 = make_float2(0.f, 0.f);
+    float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1;
     if (n > 0) {
         const uint32_t id0 = lane < n ? sorted[lane] : 0u;
         if (64 + lane < n) id_next = sorted[64 + lane];
         if (lane < n) {
             const float4* rec = record(id0);
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            r0 = *reinterpret_cast<const float2*>(rec); r1 = rec[1]; r2 = rec[2];
         }
     }
     // training: per-pixel state at the START of every batch slot (and at the exit), so that the backward
@@ -565,10 +566,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         // stage an all-zero record (opacity 0 -> alpha 0), so the blend below always runs whole groups of four
         {
             const int jn = base + 64 + lane;
-            r0 = make_float4(0.f, 0.f, 0.f, 0.f); r1 = r0; r2 = r0;
+            r0 = make_float2(0.f, 0.f); r1 = make_float4(0.f, 0.f, 0.f, 0.f); r2 = r1;
             if (jn < n) {
                 const float4* rec = record(id_next);
-                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+                r0 = *reinterpret_cast<const float2*>(rec); r1 = rec[1]; r2 = rec[2];
             }
             if (jn + 64 < n) id_next = sorted[jn + 64];
         }
