@@ -355,6 +355,7 @@ struct PreprocessBwdArgs {
     const float* means3D; const float* shs; const float* opacities;
     const float* scales; const float* rotations; const float* cov3D_precomp;
     const int32_t* radii; const Splat* splats; PartialWs partials; const uint8_t* touched;
+    uint64_t partial_bytes;                                    // size of partials.rec (48 B x capacity): bound of the buffer loads
     const ExaRasterHeader* header;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;

@@ -49,8 +49,17 @@ struct GatherLds {
     uint32_t pre[64], off[64];
     float4 rec[GCH * 3];
 };
+// The flagged records are fetched with BUFFER loads whose offset is pushed out of range for an unflagged slot: the hardware
+// returns zeros for such a lane without a memory request -- predication without a branch, so that the twelve loads of a
+// chunk leave back to back (conditional loads cost one `s_waitcnt` per branch region).
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr uint32_t BUF_OOB = 0xffffff00u;          // + 32 does not wrap; >= any bound this path is used with
 __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const uint8_t* __restrict__ touched,
-                                              const float4* __restrict__ prec, float (&sum)[10], GatherLds& L, int lane) {
+                                              const float4* __restrict__ prec, uint64_t prec_bytes, float (&sum)[10],
+                                              GatherLds& L, int lane) {
+    const bool use_buf = prec_bytes < (uint64_t)BUF_OOB;               // (a 4 GiB record array takes the pointer path)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float4*>(prec), 0, use_buf ? (int)(uint32_t)prec_bytes : 0, 0x00020000);
     uint32_t incl = n;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -63,30 +72,53 @@ __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const ui
     L.pre[lane] = pre; L.off[lane] = off;
     wave_lds_fence();
     for (uint32_t c0 = 0; c0 < S; c0 += GCH) {
-        uint32_t slot[GCH / 64];
-        uint32_t fl = 0;
+        // (Every loop below is its own straight-line block ON PURPOSE: with a load and its first use -- or a conditional
+        //  load and the store of its result -- in one loop body the compiler emits one branch region per iteration and an
+        //  `s_waitcnt vmcnt(0)` at each join: eight serial round trips per chunk instead of two.)
+        uint32_t slot[GCH / 64], tch[GCH / 64];
+        bool in[GCH / 64];
 #pragma unroll
         for (int u = 0; u < GCH / 64; ++u) {
             const uint32_t q = c0 + 64u * u + (uint32_t)lane;
-            const bool in = q < S;
+            in[u] = q < S;
             // the LAST lane g with pre[g] <= q owns position q (lanes without instances share their successor's prefix)
             uint32_t g = 0;
 #pragma unroll
             for (int s2 = 32; s2 > 0; s2 >>= 1)
                 if (L.pre[g + s2] <= q) g += s2;
-            slot[u] = in ? L.off[g] + (q - L.pre[g]) : 0u;
-            const uint32_t t = in ? touched[slot[u]] : 0u;
-            fl |= (t ? 1u : 0u) << u;
+            slot[u] = in[u] ? L.off[g] + (q - L.pre[g]) : off;          // (past the end: any address that is valid to read)
+        }
+#pragma unroll
+        for (int u = 0; u < GCH / 64; ++u) tch[u] = touched[slot[u]];   // unconditional: all requests leave back to back
+        uint32_t fl = 0;
+#pragma unroll
+        for (int u = 0; u < GCH / 64; ++u) fl |= (in[u] && tch[u]) ? (1u << u) : 0u;
+        float4 q0[GCH / 64], q1[GCH / 64], q2[GCH / 64];
+#pragma unroll
+        for (int u = 0; u < GCH / 64; ++u) {
+            q0[u] = make_float4(0.f, 0.f, 0.f, 0.f); q1[u] = q0[u]; q2[u] = q0[u];
+        }
+        if (use_buf) {
+#pragma unroll
+            for (int u = 0; u < GCH / 64; ++u) {                        // only the flagged records are fetched
+                const uint32_t bo = ((fl >> u) & 1u) ? slot[u] * 48u : BUF_OOB;
+                q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo, 0, 0));
+                q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 16u, 0, 0));
+                q2[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 32u, 0, 0));
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < GCH / 64; ++u) {
+                if ((fl >> u) & 1u) {
+                    const float4* src = prec + (size_t)slot[u] * 3;
+                    q0[u] = src[0]; q1[u] = src[1]; q2[u] = src[2];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < GCH / 64; ++u) {
-            float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0, q2 = q0;
-            if ((fl >> u) & 1u) {
-                const float4* src = prec + (size_t)slot[u] * 3;
-                q0 = src[0]; q1 = src[1]; q2 = src[2];
-            }
             float4* dst = L.rec + (64 * u + lane) * 3;
-            dst[0] = q0; dst[1] = q1; dst[2] = q2;
+            dst[0] = q0[u]; dst[1] = q1[u]; dst[2] = q2[u];
         }
         wave_lds_fence();
         const uint32_t lo = pre > c0 ? pre : c0, hi = (pre + n) < (c0 + GCH) ? (pre + n) : (c0 + GCH);
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         PBWD_PHASE(0);                                          // splat row 3 here (first trip), heavy splats gathered
         // ---- this wave's blended instances (contiguous slots, each written at most once), gathered together ----------
         float own[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        stream_gather(r3.w, (vis && r3.z < COOP_MIN) ? r3.z : 0u, touched, prec, own, s_gather[threadIdx.x >> 6], lane);
+        stream_gather(r3.w, (vis && r3.z < COOP_MIN) ? r3.z : 0u, touched, prec, a.partial_bytes, own, s_gather[threadIdx.x >> 6], lane);
         float vmean[3] = {0.f, 0.f, 0.f}, vm2[2] = {0.f, 0.f}, vscale[3] = {0.f, 0.f, 0.f};
         float vq[4] = {0.f, 0.f, 0.f, 0.f}, vcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float vop = 0.f, vcol[3] = {0.f, 0.f, 0.f};
