@@ -74,6 +74,7 @@ int check_inputs(int32_t P, int32_t sh_M, const float* means3D, const float* shs
                  int sh_degree) {
     if (P < 0) return fail(EXA_RASTER_E_INVALID, "P < 0");
     if (P == 0) return 0;
+    if (P > (1 << 26) - 4) return fail(EXA_RASTER_E_INVALID, "more than 2^26 - 4 Gaussians (32-bit byte offsets of the 64-byte splat records)");
     if (!means3D || !opacities) return fail(EXA_RASTER_E_NULLPTR, "means3D / opacities is NULL");
     if ((shs == nullptr) == (colors_precomp == nullptr))
         return fail(EXA_RASTER_E_INVALID, "provide exactly one of shs / colors_precomp");

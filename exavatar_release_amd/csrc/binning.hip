@@ -625,7 +625,11 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_kernel(Batch<BinArg
     __syncthreads();
     const int csx0 = (cp.cell % g.cx) * CELL_SUBS, csy0 = (cp.cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
-        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        // ONE 16-byte load of the entry: left to itself the compiler fetched the rect words first and sank the id word
+        // into the block that uses it -- behind a wait: a fourth dependent round trip in a launch that consists of four
+        uint4 en = b.bucket[e];
+        asm("" : "+v"(en.x) : "v"(en.y), "v"(en.z), "v"(en.w));
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, en, csx0, csy0);
         for (unsigned long long m = mask; m; m &= m - 1)
             __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));
@@ -706,7 +710,11 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
     __syncthreads();
     const int csx0 = (cell % g.cx) * CELL_SUBS, csy0 = (cell / g.cx) * CELL_SUBS;   // cell origin in sub-tiles
     for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
-        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, b.bucket[e], csx0, csy0);
+        // ONE 16-byte load of the entry: left to itself the compiler fetched the rect words first and sank the id word
+        // into the block that uses it -- behind a wait: a fourth dependent round trip in a launch that consists of four
+        uint4 en = b.bucket[e];
+        asm("" : "+v"(en.x) : "v"(en.y), "v"(en.z), "v"(en.w));
+        const unsigned long long mask = entry_mask<FOOTPRINT>(a.splats, en, csx0, csy0);
         for (unsigned long long m = mask; m; m &= m - 1)
             __hip_atomic_fetch_add(&s_cnt[__builtin_ctzll(m)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         reinterpret_cast<uint2*>(b.bucket + e)[1] = make_uint2((uint32_t)mask, (uint32_t)(mask >> 32));   // read back by this thread
