@@ -194,14 +194,10 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
     // (graph replays with a new gradient tensor per iteration: include/exa_raster.h, dL_dcolor_indirect; a scalar load)
     // (the cast matters: a pointer LOADED from memory is generic to the compiler, and flat loads also count on lgkmcnt --
     //  every LDS / scalar wait behind them would wait for HBM)
-#ifdef EXA_BWD_FLATPTR
-    const float* __restrict__ dL_dcolor = a.dL_dcolor_ind ? *a.dL_dcolor_ind : a.dL_dcolor;
-#else
     typedef const float __attribute__((address_space(1)))* gfloat_ptr;
     typedef const unsigned long long __attribute__((address_space(4)))* table_ptr;       // constant: a scalar load
     const gfloat_ptr dL_dcolor = a.dL_dcolor_ind ? (gfloat_ptr)(*(table_ptr)(unsigned long long)a.dL_dcolor_ind)
                                                  : (gfloat_ptr)a.dL_dcolor;
-#endif
     float4* __restrict__ prec = a.partials.rec;
     uint8_t* __restrict__ touched = a.bw.touched;
 
@@ -228,81 +224,10 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
         }
         return __builtin_amdgcn_readfirstlane(h.st1) != 0u && (lo | hi) != 0u;
     };
-#ifndef EXA_BWD_ONE_TRIP
-#define EXA_BWD_ONE_TRIP 1
-#endif
-#if EXA_BWD_ONE_TRIP
-    // All loads of the payload leave back to back, in ONE round trip: checkpoints and pixel gradients first (they depend on
-    // the header only), then the splat rows by BUFFER loads whose offset is pushed out of range for a lane without a
-    // blended entry (zeros, no memory request, no branch); the partial slot is derived from row 3 after everything is in
-    // flight.  (Until round 4 the rows sat in a conditional block that used row 3 at once: the checkpoint and gradient
-    // loads were only issued after the rows had landed -- two dependent round trips.)
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    typedef int v2i __attribute__((ext_vector_type(2)));
-    constexpr uint32_t ROW_OOB = 0xffffff00u;
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<Splat*>(a.splats), 0, a.P * 64, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<Splat*>(two ? a.splats2 : a.splats), 0,
-                                                                          (two ? a.P2 : a.P) * 64, 0x00020000);
-    auto load_pay = [&](const BwdHdr& h, uint32_t slot) -> BwdPay {
-        BwdPay p;
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        p.r0 = make_float2(0.f, 0.f); p.r1 = zero4; p.r2 = zero4; p.pslot = 0u;
-        p.cs0 = 1.0f; p.cs1 = p.cs2 = p.cs3 = p.cs4 = 0.f;
-        p.cf0 = p.cf1 = p.cf2 = p.cf3 = p.cf4 = 0.f;
-        p.gr = p.gg = p.gb = p.gd = p.ga = 0.f;
-        if (!is_active(h)) return p;
-        const uint32_t bm_lo = __builtin_amdgcn_readfirstlane(h.bm_lo), bm_hi = __builtin_amdgcn_readfirstlane(h.bm_hi);
-        const int st = (int)__builtin_amdgcn_readfirstlane(h.st1) - 1;
-        const int n = (int)__builtin_amdgcn_readfirstlane(h.n);
-        const int b0 = (int)(__builtin_amdgcn_readfirstlane(h.begin) / BATCH);
-        const SubTile sub = decode_subtile(st, a.grid);
-        const bool flagged = (((lane < 32 ? bm_lo : bm_hi) >> (lane & 31)) & 1u) != 0u;
-        // state at the START of this batch and at the forward's exit (the sub-tile's end slot)
-        const float* cf = a.bw.ckpt + (size_t)(b0 + (n + BATCH - 1) / BATCH) * (5 * 64) + lane;
-        const float* cs = a.bw.ckpt + (size_t)slot * (5 * 64) + lane;
-        if ((int)slot > b0) { p.cs0 = cs[0]; p.cs1 = cs[64]; p.cs2 = cs[128]; p.cs3 = cs[192]; p.cs4 = HAS_DEPTH ? cs[256] : 0.f; }
-        p.cf0 = cf[0]; p.cf1 = cf[64]; p.cf2 = cf[128]; p.cf3 = cf[192]; p.cf4 = HAS_DEPTH ? cf[256] : 0.f;
-        // incoming gradient of this lane's pixel (a pixel outside the image reads its clamped neighbour and drops it)
-        const int pxi = sub.ox + (lane & 7), pyi = sub.oy + (lane >> 3);
-        const bool in_img = pxi < a.grid.W && pyi < a.grid.H;
-        const size_t HW = (size_t)a.grid.W * a.grid.H;
-        const size_t pix = (size_t)min(pyi, a.grid.H - 1) * a.grid.W + min(pxi, a.grid.W - 1);
-        float gr = dL_dcolor[pix], gg = dL_dcolor[HW + pix], gb = dL_dcolor[2 * HW + pix], gd = 0.f, ga = 0.f;
-        if (HAS_DEPTH && a.dL_ddepth) gd = a.dL_ddepth[pix];
-        if (a.dL_dalpha) ga = a.dL_dalpha[pix];
-        // rows 0..3 of this lane's splat
-        uint32_t idx = h.id, last = (uint32_t)(a.P - 1);
-        bool from_b = false;
-        if (two) {
-            idx = h.id & ~SRC_B;
-            from_b = (h.id & SRC_B) != 0u;
-            if (from_b) last = (uint32_t)(a.P2 - 1);
-        }
-        const uint32_t row = min(idx, last) * 64u;
-        const uint32_t off_a = (flagged && !from_b) ? row : ROW_OOB;
-        v2i q0 = __builtin_amdgcn_raw_buffer_load_b64(rs_a, off_a, 0, 0);
-        v4i q1 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, off_a + 16u, 0, 0);
-        v4i q2 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, off_a + 32u, 0, 0);
-        v4i q3 = __builtin_amdgcn_raw_buffer_load_b128(rs_a, off_a + 48u, 0, 0);
-        if (two) {                                              // wave-uniform: source B's rows for its lanes (zeros elsewhere)
-            const uint32_t off_b = (flagged && from_b) ? row : ROW_OOB;
-            q0 |= __builtin_amdgcn_raw_buffer_load_b64(rs_b, off_b, 0, 0);
-            q1 |= __builtin_amdgcn_raw_buffer_load_b128(rs_b, off_b + 16u, 0, 0);
-            q2 |= __builtin_amdgcn_raw_buffer_load_b128(rs_b, off_b + 32u, 0, 0);
-            q3 |= __builtin_amdgcn_raw_buffer_load_b128(rs_b, off_b + 48u, 0, 0);
-        }
-        p.gr = in_img ? gr : 0.f; p.gg = in_img ? gg : 0.f; p.gb = in_img ? gb : 0.f;
-        p.gd = in_img ? gd : 0.f; p.ga = in_img ? ga : 0.f;
-        p.r0 = __builtin_bit_cast(float2, q0); p.r1 = __builtin_bit_cast(float4, q1); p.r2 = __builtin_bit_cast(float4, q2);
-        if (flagged) {
-            const uint32_t rx = (uint32_t)q3.x, ry = (uint32_t)q3.y;
-            const int sx0 = rx & 0xffff, sx1 = rx >> 16, sy0 = ry & 0xffff;
-            p.pslot = (uint32_t)q3.w + (uint32_t)((sub.gsy - sy0) * (sx1 - sx0) + (sub.gsx - sx0));
-            if (PREFIX && !trainable(h.id)) p.pslot = NO_SLOT;
-        }
-        return p;
-    };
-#else   // round 3's order: splat rows (conditional), then checkpoints and gradients
+    // (Round 4 built the alternative -- checkpoints and gradients first, then the splat rows by buffer loads pushed out of
+    //  range for lanes without a blended entry, everything in ONE round trip instead of two; commit "render_bwd: one-round-trip
+    //  payload loads" -- and measured 6 538 against 6 559 it/s on C3, three interleaved runs each: at five waves per SIMD the
+    //  prologue's latency is hidden, and the kernel is VALU-bound.  Not kept.)
     auto load_pay = [&](const BwdHdr& h, uint32_t slot) -> BwdPay {
         BwdPay p;
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -348,7 +273,6 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
         }
         return p;
     };
-#endif
 
     // SPW consecutive batch slots per wave (default 1): the headers of all of them are fetched in one round trip, their
     // payloads in a second one, then the batches are computed one after the other.  Measured on C3: SPW 1 / 2 / 4 =

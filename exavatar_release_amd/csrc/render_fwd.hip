@@ -148,13 +148,18 @@ __device__ __forceinline__ bool lds_bucket_sort(const unsigned long long* gkeys,
     const int lane = tid & 63, wave = tid >> 6;
     unsigned long long key[E];
     uint32_t dmin = 0xffffffffu, dmax = 0u;
+    // all E loads first, unconditionally (clamped index), their first use in a loop of its own: with load and use in one
+    // body the compiler waits for every key before it requests the next -- up to eight serial round trips (round 4 ISA)
+#pragma unroll
+    for (int e = 0; e < E; ++e) key[e] = gkeys[min(e * SBLOCK + tid, n - 1)];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = e * SBLOCK + tid;
-        key[e] = i < n ? gkeys[i] : ~0ull;
         if (i < n) {
             const uint32_t d = (uint32_t)(key[e] >> 32);
             dmin = min(dmin, d); dmax = max(dmax, d);
+        } else {
+            key[e] = ~0ull;
         }
         cnt[i] = 0u;
     }
