@@ -655,6 +655,11 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         return;
     }
     const int cell = cp.cell, tid = threadIdx.x;
+    // this thread's first entry is requested NOW: it depends on the part record only, and behind the barrier below it
+    // was a round trip of its own (the launch consists of three)
+    const uint32_t e_first = cp.lo + (uint32_t)tid;
+    // (unconditional, clamped into the cell's entries: a conditional load would be waited for at the join right here)
+    const uint4 en_first = b.bucket[min(e_first, max(cp.hi, 1u) - 1u)];
     if (tid < 64) {
         uint32_t n = 0, before = 0;
         const size_t first = (size_t)blockIdx.x - (size_t)cp.part;      // the cell's parts are consecutive workgroups
@@ -678,15 +683,16 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
         }
     }
     __syncthreads();
-    for (uint32_t e = cp.lo + tid; e < cp.hi; e += BIN_THREADS) {
-        const uint4 en = b.bucket[e];
+    auto scatter = [&](const uint4& en) {
         const unsigned long long key = ((unsigned long long)en.y << 32) | en.x;
         for (unsigned long long m = ((unsigned long long)en.w << 32) | en.z; m; m &= m - 1) {
             const int s = __builtin_ctzll(m);
             const uint32_t r = __hip_atomic_fetch_add(&s_cnt2[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             b.keys[s_off[s] + r] = key;
         }
-    }
+    };
+    if (e_first < cp.hi) scatter(en_first);
+    for (uint32_t e = e_first + BIN_THREADS; e < cp.hi; e += BIN_THREADS) scatter(b.bucket[e]);
 }
 
 // One workgroup per cell, both halves in one launch: for images with >= SINGLE_PART_CELLS cells (2048 x 2048 px) there are
