@@ -595,9 +595,16 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             float aeff[4], Tb[4], w[4];
             blend_group4(T, live, e.alpha, aeff, Tb, w);
             if (STORE) {                                         // wave-uniform bits: v_cmp into an SGPR pair + scalar ops
-                uint32_t nib = (__ballot(aeff[0] > 0.0f) ? 1u : 0u) | (__ballot(aeff[1] > 0.0f) ? 2u : 0u) |
-                               (__ballot(aeff[2] > 0.0f) ? 4u : 0u) | (__ballot(aeff[3] > 0.0f) ? 8u : 0u);
-                nib = __builtin_amdgcn_readfirstlane(nib);       // keep the mask in SGPRs
+                // four votes -> one nibble, on the scalar unit: left to the compiler the nibble is assembled in a VGPR (a
+                // v_cndmask, three v_or and a v_readfirstlane per group of four)
+                auto vote_bit = [](bool p, uint32_t bit) -> uint32_t {
+                    const unsigned long long m = __ballot(p);
+                    uint32_t r;
+                    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(r) : "s"(m), "s"(bit) : "scc");
+                    return r;
+                };
+                const uint32_t nib = vote_bit(aeff[0] > 0.0f, 1u) | vote_bit(aeff[1] > 0.0f, 2u) |
+                                     vote_bit(aeff[2] > 0.0f, 4u) | vote_bit(aeff[3] > 0.0f, 8u);
                 blended |= (unsigned long long)nib << k;
             }
             Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
