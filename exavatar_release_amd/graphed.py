@@ -131,14 +131,20 @@ class GraphedIteration:
             pass
 
     def _static_like(self, assets):
+        """Static input leaves of a capture: slices of ONE flat buffer (filled by one concatenation kernel per call)."""
         f32 = dict(dtype=torch.float32, device=self.device)
-        out = {}
+        shapes = [(name, k, tuple(a[k].shape)) for name, a in zip(_SETS, assets) for k in _ASSET_KEYS + (_colour_key(a),)]
+        numel = [int(torch.Size(sh).numel()) for _, _, sh in shapes]
+        pad = [(n + 3) // 4 * 4 for n in numel]                     # 16-byte aligned slices (float4 loads in the kernels)
+        flat = torch.zeros(sum(pad), **f32)
+        out, off = {name: {} for name in _SETS}, 0
+        for (name, k, sh), n, pn in zip(shapes, numel, pad):
+            out[name][k] = flat[off:off + n].view(sh).requires_grad_(True)
+            off += pn
         for name, a in zip(_SETS, assets):
-            ck = _colour_key(a)
-            d = {k: torch.zeros(tuple(a[k].shape), **f32).requires_grad_(True) for k in _ASSET_KEYS + (ck,)}
-            if ck == 'sh' and a.get('sh_degree') is not None:
-                d['sh_degree'] = int(a['sh_degree'])
-            out[name] = d
+            if _colour_key(a) == 'sh' and a.get('sh_degree') is not None:
+                out[name]['sh_degree'] = int(a['sh_degree'])
+        self._flat_in, self._flat_in_tight = flat.data, numel == pad     # (.data: its own version counter, see in_raw)
         return out
 
     def _render(self, cap, dens):
@@ -260,7 +266,10 @@ class GraphedIteration:
                             views.append(flat[off:off + n].view(gr.shape))
                             present.append(gr)
                         off += n
-                    torch._foreach_copy_(views, present)
+                    if len(present) == len(grads):
+                        torch.cat([gr.reshape(-1) for gr in present], out=flat)
+                    else:
+                        torch._foreach_copy_(views, present)
                 unused = [gr is None for gr in grads]
         finally:
             rz.config.mode, rz.config.fixed_capacity = saved
@@ -275,7 +284,10 @@ class GraphedIteration:
             for d, s_ in zip(cap.in_list, src):
                 if tuple(d.shape) != tuple(s_.shape):
                     raise ValueError('GraphedIteration: asset tensor of shape %s, captured for %s' % (tuple(s_.shape), tuple(d.shape)))
-            torch._foreach_copy_(cap.in_raw, [s_.detach() for s_ in src])
+            if self._flat_in_tight and all(s_.dtype == torch.float32 for s_ in src):
+                torch.cat([s_.detach().reshape(-1) for s_ in src], out=self._flat_in)      # one kernel (14 MB: ~10 us)
+            else:
+                torch._foreach_copy_(cap.in_raw, [s_.detach() for s_ in src])
 
     def _camera(self, cam_param):
         """Write the camera block; returns (tan, check) with check = None or (pool, slot, tag) to poll after the replay."""
