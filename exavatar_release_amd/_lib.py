@@ -59,6 +59,7 @@ class ExaRasterForwardJob(ctypes.Structure):
         ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
         ('keep_sorted_keys', ctypes.c_int32),
         ('host_header', c_void_p), ('header_tag', ctypes.c_uint32),
+        ('is_vis', c_void_p),
     ]
 
 
@@ -93,6 +94,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
         ('grad_first', ctypes.c_int32),
         ('compose_geom_a', c_void_p), ('compose_P_a', ctypes.c_int32), ('compose_capacity_b', ctypes.c_uint64),
         ('dL_dcolor_indirect', c_void_p),
+        ('accumulate', ctypes.c_int32),
     ]
 
 
@@ -163,7 +165,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 132:
+    if lib.exa_raster_version() < 133:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

@@ -170,7 +170,7 @@ int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st, bo
         a.viewmatrix = s->viewmatrix; a.projmatrix = s->projmatrix; a.campos = s->campos;
         a.means3D = j.means3D; a.shs = j.shs; a.colors_precomp = j.colors_precomp; a.opacities = j.opacities;
         a.scales = j.scales; a.rotations = j.rotations; a.cov3D_precomp = j.cov3D_precomp;
-        a.radii = j.radii; a.splats = static_cast<Splat*>(j.geom_ws);
+        a.radii = j.radii; a.is_vis = j.is_vis; a.splats = static_cast<Splat*>(j.geom_ws);
         a.tw = carve_tile_ws(j.tile_ws, a.grid.cells, num_chunks(j.P));
         ba[k] = bin_args(j);
     }
@@ -269,6 +269,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         b.dL_dopacity = j.dL_dopacity; b.dL_dscales = j.dL_dscales; b.dL_drotations = j.dL_drotations;
         b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;
         b.dens_accum = j.densify_grad_accum; b.dens_cnt = j.densify_track_cnt; b.dens_rmax = j.densify_radius_max;
+        b.accumulate = j.accumulate;
         b.grad_first = j.grad_first;            // (composite: 0 -- every Gaussian of B is trainable; partials / touched / header are the composite's)
         ++n;
     }
@@ -339,6 +340,7 @@ int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32
         if (sum_shared) {
             const ExaRasterBackwardJob &a = jobs[0], &b = jobs[k];
             if (b.grad_first != 0) return fail(EXA_RASTER_E_INVALID, "sum_shared and grad_first cannot be combined");
+            if (b.accumulate) return fail(EXA_RASTER_E_INVALID, "sum_shared and accumulate cannot be combined");
             if (b.compose_geom_a) return fail(EXA_RASTER_E_INVALID, "sum_shared and composite jobs cannot be combined");
             if (a.P != b.P || a.sh_M != b.sh_M || a.means3D != b.means3D || a.shs != b.shs || a.opacities != b.opacities ||
                 a.colors_precomp != b.colors_precomp || a.scales != b.scales || a.rotations != b.rotations ||
@@ -389,7 +391,7 @@ static ExaRasterForwardJob one_job(const ExaRasterSettings* s, int32_t P, int32_
                                    const float* scales, const float* rotations, const float* cov3D_precomp,
                                    int32_t* radii, void* geom_ws, void* tile_ws, void* bin_ws, uint64_t capacity,
                                    float* out_color, float* out_depth, float* out_alpha) {
-    ExaRasterForwardJob j;
+    ExaRasterForwardJob j{};                 // optional fields (is_vis, host_header ...) off
     j.settings = s; j.P = P; j.sh_M = sh_M; j.means3D = means3D; j.shs = shs; j.colors_precomp = colors_precomp;
     j.opacities = opacities; j.scales = scales; j.rotations = rotations; j.cov3D_precomp = cov3D_precomp;
     j.radii = radii; j.geom_ws = geom_ws; j.tile_ws = tile_ws; j.bin_ws = bin_ws; j.capacity = capacity;
@@ -434,7 +436,7 @@ int exa_raster_backward(const ExaRasterSettings* s, int32_t P, int32_t sh_M, con
                         const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha,
                         void* grad_ws, float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dcolors, float* dL_dopacity,
                         float* dL_dscales, float* dL_drotations, float* dL_dsh, float* dL_dcov3D, void* stream) {
-    ExaRasterBackwardJob j;
+    ExaRasterBackwardJob j{};                // optional fields (dL_dcolor_indirect, accumulate ...) off
     j.settings = s; j.P = P; j.sh_M = sh_M; j.means3D = means3D; j.shs = shs; j.colors_precomp = colors_precomp;
     j.opacities = opacities; j.scales = scales; j.rotations = rotations; j.cov3D_precomp = cov3D_precomp;
     j.radii = radii; j.geom_ws = geom_ws; j.tile_ws = tile_ws; j.bin_ws = bin_ws; j.capacity = capacity;

@@ -263,7 +263,7 @@ struct PreprocessArgs {
     const float* viewmatrix; const float* projmatrix; const float* campos;
     const float* means3D; const float* shs; const float* colors_precomp; const float* opacities;
     const float* scales; const float* rotations; const float* cov3D_precomp;
-    int32_t* radii; Splat* splats; TileWs tw;
+    int32_t* radii; uint8_t* is_vis; Splat* splats; TileWs tw;
 };
 hipError_t launch_preprocess_fwd(const PreprocessArgs* a, int K, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
@@ -361,6 +361,7 @@ struct PreprocessBwdArgs {
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;
     float* dens_accum; float* dens_cnt; float* dens_rmax;       // optional fused densification statistics (per view)
     int grad_first;        // Gaussians below this index are constants: no work, no output rows (output row = idx - grad_first)
+    int accumulate;        // != 0: the per-Gaussian outputs (all but dL_dmeans2D) hold values this call adds to
 };
 // sum_shared != 0: the K jobs are K views of the SAME Gaussians (identical input pointers and P): one thread
 // per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
     float dmean[3] = {0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f};
     float dq[4] = {0.f, 0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
-    bool sh_init = false;                                       // dL_dsh of this Gaussian already holds an earlier view's values
+    bool sh_init = out.accumulate != 0;                         // dL_dsh of this Gaussian already holds an earlier view's values
+    //                                                             (or another render's: ExaRasterBackwardJob.accumulate)
     float dn_acc = 0.f, dn_cnt = 0.f, dn_rmax = 0.f;            // dens_shared: this thread's share of the K views' statistics
 
     const int n_views = SUM ? K : 1;
@@ -508,6 +509,20 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         for (int k = 0; k < out.sh_M * 3; ++k) dsh[k] = 0.f;
     }
 
+    if (out.accumulate) {                                       // ExaRasterBackwardJob.accumulate: out = held + this render's
+        if (out.dL_dmeans3D) { dmean[0] += out.dL_dmeans3D[row * 3 + 0]; dmean[1] += out.dL_dmeans3D[row * 3 + 1]; dmean[2] += out.dL_dmeans3D[row * 3 + 2]; }
+        if (out.dL_dopacity) dop += out.dL_dopacity[row];
+        if (out.dL_dcolors) { dcol[0] += out.dL_dcolors[row * 3 + 0]; dcol[1] += out.dL_dcolors[row * 3 + 1]; dcol[2] += out.dL_dcolors[row * 3 + 2]; }
+        if (out.dL_dscales) { dscale[0] += out.dL_dscales[row * 3 + 0]; dscale[1] += out.dL_dscales[row * 3 + 1]; dscale[2] += out.dL_dscales[row * 3 + 2]; }
+        if (out.dL_drotations) {
+            const float4 h = reinterpret_cast<const float4*>(out.dL_drotations)[row];
+            dq[0] += h.x; dq[1] += h.y; dq[2] += h.z; dq[3] += h.w;
+        }
+        if (out.dL_dcov3D) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dcov[i] += out.dL_dcov3D[row * 6 + i];
+        }
+    }
     if (out.dL_dmeans3D) { out.dL_dmeans3D[row * 3 + 0] = dmean[0]; out.dL_dmeans3D[row * 3 + 1] = dmean[1]; out.dL_dmeans3D[row * 3 + 2] = dmean[2]; }
     if (out.dL_dopacity) out.dL_dopacity[row] = dop;
     if (out.dL_dcolors) { out.dL_dcolors[row * 3 + 0] = dcol[0]; out.dL_dcolors[row * 3 + 1] = dcol[1]; out.dL_dcolors[row * 3 + 2] = dcol[2]; }

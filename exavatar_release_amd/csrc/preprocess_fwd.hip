@@ -178,11 +178,13 @@ __device__ __forceinline__ uint32_t preprocess_one(const PreprocessArgs& a, int 
     sxy[0] = sxy[1] = sxy[2] = sxy[3] = 0;
     if (!visible) {
         a.radii[idx] = 0;
+        if (a.is_vis) a.is_vis[idx] = 0;
         const uint4 zero = make_uint4(0, 0, 0, 0);
         rec[0] = zero; rec[1] = zero; rec[2] = zero; rec[3] = zero;
         return 0;
     }
     a.radii[idx] = radius;
+    if (a.is_vis) a.is_vis[idx] = radius > 0;
     tiles16 = (uint32_t)((x1 - x0) * (y1 - y0));               // upstream's tiles_touched
     // colour: precomputed, or SH evaluated here (reference module.py:258-266 semantics)
     float cr, cg, cbl;

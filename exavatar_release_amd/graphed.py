@@ -40,7 +40,7 @@ import torch
 from . import _lib
 
 from . import rasterizer as rz
-from .renderer import ITERATION_RENDERS, _sh_degree, camera_block_device, render_iteration
+from .renderer import ITERATION_RENDERS, _CompositeOutput, _sh_degree, camera_block_device, render_iteration
 
 _ASSET_KEYS = ('mean_3d', 'scale', 'rotation', 'opacity')
 _IMG_ONLY = (True, False, False) * 5
@@ -59,7 +59,7 @@ class _Captured:
 
 class _IterFn(torch.autograd.Function):
     """Autograd boundary of a replayed iteration.  apply(owner, cap, *asset tensors [15], *probes [5]) -> 15 image planes
-    (img, depthmap, mask of the five renders) + 5 radii."""
+    (img, depthmap, mask of the five renders)."""
 
     @staticmethod
     def forward(ctx, owner, cap, *tensors):
@@ -68,9 +68,7 @@ class _IterFn(torch.autograd.Function):
         # Aliases of the static outputs: no copies (they are overwritten by the next replay).  Detached, because the static
         # tensors carry the autograd graph of the CAPTURED call, which the backward graphs were recorded from and which
         # must not be re-parented onto this node.
-        outs = tuple(o.detach() for o in cap.out_list) + tuple(r.detach() for r in cap.radii)
-        ctx.mark_non_differentiable(*outs[15:])
-        return outs
+        return tuple(o.detach() for o in cap.out_list)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -229,7 +227,10 @@ class GraphedIteration:
                     rz._capture_report = None
                 cap.outs = res
                 cap.out_list = [res[k][n] for k in ITERATION_RENDERS for n in ('img', 'depthmap', 'mask')]
-                cap.radii = [res[k]['radius'] for k in ITERATION_RENDERS]
+                # radius / is_vis of the three plain renders: static tensors the forward kernel rewrites per replay; the
+                # composites' are concatenations of them, built when somebody reads them (renderer._CompositeOutput)
+                plain = ('scene', 'human', 'human_refined') if self.merge else ITERATION_RENDERS
+                cap.radii = {k: (res[k]['radius'], res[k]['is_vis']) for k in plain}
                 cap.bwd = {}
                 self.captures += 1
         finally:
@@ -406,19 +407,24 @@ class GraphedIteration:
                 needs = self._overflowed(cap)
             grad = torch.is_grad_enabled() and any(a[k].requires_grad for a in assets for k in _ASSET_KEYS + (_colour_key(a),))
             if not grad:
-                outs, radii = [o.detach() for o in cap.out_list], [r.detach() for r in cap.radii]
+                outs = [o.detach() for o in cap.out_list]
                 probes = [None] * 5
             else:
                 # fresh leaves per iteration that alias the (never written, never read) static probes: their .grad is what
                 # the reference reads after backward (avatar/main/train.py:51)
                 probes = [p.detach().requires_grad_(True) for p in cap.probes]
                 src = [a[k] for a in assets for k in _ASSET_KEYS + (_colour_key(a),)]
-                res = _IterFn.apply(self, cap, *src, *probes)
-                outs, radii = res[:15], res[15:]
+                outs = _IterFn.apply(self, cap, *src, *probes)
+        self._args = None
         out = {}
         for i, name in enumerate(ITERATION_RENDERS):
-            out[name] = {'img': outs[3 * i], 'depthmap': outs[3 * i + 1], 'mask': outs[3 * i + 2], 'mean_2d': probes[i],
-                         'is_vis': radii[i] > 0, 'radius': radii[i]}
+            base = {'img': outs[3 * i], 'depthmap': outs[3 * i + 1], 'mask': outs[3 * i + 2], 'mean_2d': probes[i]}
+            if name in cap.radii:
+                base['is_vis'], base['radius'] = cap.radii[name][1], cap.radii[name][0]
+                out[name] = base
+            else:
+                rs, rb = cap.radii['scene'], cap.radii['human' if name == 'scene_human' else 'human_refined']
+                out[name] = _CompositeOutput(base, ((rs[0], rb[0]), (rs[1], rb[1])))
         return out
 
     def _grow(self, needs):

@@ -63,6 +63,7 @@ they were modified in place in between (``optimizer.step()``), the corrected ima
 values, and the ``RuntimeWarning`` says so.
 """
 import ctypes
+import threading
 import time
 import warnings
 import weakref
@@ -100,6 +101,9 @@ class _Config:
     overflow_check = 'forward'    # 'forward' | 'always' | 'adaptive': where the header report is looked at (module docstring)
     verify_calls = 4          # adaptive: the first calls of a shape wait for their report
     danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
+    fold_composite_grads = True   # a composite's gradients for source B are handed to B's own render, whose backward adds them
+    #                               inside its per-Gaussian kernel (ExaRasterBackwardJob.accumulate) instead of autograd
+    #                               summing the two with one kernel per tensor (developer A/B knob; same values bit for bit)
     compose_reuse_source = True   # composite renders copy source A's pixels where source B has no entry (developer A/B knob)
     upstream_scale_grad = False   # True: dL/dscale as upstream returns it (w.r.t. scale_modifier * scale, i.e. divided
     #                               by scale_modifier); identical for the reference, which passes 1.0 (module.py:615)
@@ -117,6 +121,17 @@ _capture_report = None   # [(slot, tag) | None per job]: reserved header-report 
 _capture_grad_ind = None  # {data_ptr of a static dL/dcolor buffer: device address of its pointer-table entry}: set by
 #                           GraphedIteration while it RECORDS a backward graph (ExaRasterBackwardJob.dL_dcolor_indirect)
 _last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
+_tls = threading.local()  # .is_vis: the `radii > 0` tensors the per-Gaussian kernel of the most recent call of this thread wrote
+#                           (ExaRasterForwardJob.is_vis), picked up by the renderer's output dict via take_is_vis()
+
+
+def take_is_vis():
+    """The boolean ``radii > 0`` tensors (one per job) of the most recent rasterizer call of this thread, written by the
+    forward kernel itself -- what ``GaussianRenderer`` returns as ``is_vis`` (reference ``avatar/common/nets/layer.py``)
+    without a comparison kernel per render.  One-shot: returns None when there is none or it was taken already."""
+    v = getattr(_tls, 'is_vis', None)
+    _tls.is_vis = None
+    return v
 
 
 def _ptr(t):
@@ -475,7 +490,7 @@ class _Job:
     """Host-side record of one render of a batch."""
     __slots__ = ('rs', 'P', 'nF', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
                  'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
-                 'gb', 'tb', 'keep_keys', 'rec', 'device', 'versions')
+                 'gb', 'tb', 'keep_keys', 'rec', 'device', 'versions', 'is_vis', 'stash', 'token_ref')
 
 
 _F32 = torch.float32
@@ -488,6 +503,7 @@ def _fill_forward_job(a, j, report=None):
     a.opacities, a.scales, a.rotations = _addr(j.opac), _addr(j.scales), _addr(j.rot)
     a.cov3D_precomp = _addr(j.cov)
     a.radii = j.radii.data_ptr()
+    a.is_vis = j.is_vis.data_ptr()
     a.geom_ws, a.tile_ws, a.bin_ws, a.capacity = j.geom_ptr, j.tile_ptr, j.bin_ptr, j.capacity
     base = j.planes.data_ptr()
     a.out_color, a.out_depth, a.out_alpha = base, base + 12 * j.H * j.W, base + 16 * j.H * j.W
@@ -509,6 +525,11 @@ def _grad_in(g, shape, device):
 
 
 N_IN = 8      # tensor arguments per job: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3D
+
+
+def _grad_pattern(*wanted):
+    """Which of (means3D, sh, colors, opacity, scales, rotations, cov3D) get a gradient, as a tuple of bools."""
+    return tuple(bool(w) for w in wanted)
 
 
 class _Rasterize(torch.autograd.Function):
@@ -620,6 +641,8 @@ class _Rasterize(torch.autograd.Function):
                 j.settings = _make_settings(j.rs, device, j.keep)
                 j.planes = torch.empty((5, j.H, j.W), dtype=_F32, device=device)   # colour | depth | alpha
                 j.radii = torch.empty((j.P,), dtype=torch.int32, device=device)
+                j.is_vis = torch.empty((j.P,), dtype=torch.bool, device=device)      # (one byte each: 0 / 1 from the kernel)
+                j.stash = j.token_ref = None
                 sz = _sizes(j.P, j.W, j.H, 0)
                 j.gb, j.tb = int(sz.geom_bytes), int(sz.tile_bytes)
                 j.bins = None
@@ -696,11 +719,18 @@ class _Rasterize(torch.autograd.Function):
             _debug_last['capacity'] = j.capacity
         if keep_keys:
             _last_handles = jobs
+        _tls.is_vis = [j.is_vis for j in jobs]
         ctx.need_ctx = need_ctx
         outs = []
         for j in jobs:
             c, d, a = j.planes.split((3, 1, 1))
             outs += [c, j.radii, d, a]
+        if keep_keys:
+            # One more (empty) differentiable output: composites of these renders take it as an input, which orders their
+            # backward BEFORE this node's and guarantees that this node's backward runs whenever theirs did -- the
+            # composites can then leave their gradients for source B with B's job (``_Job.stash``) and this backward adds
+            # them in its per-Gaussian kernel (config.fold_composite_grads).
+            outs.append(torch.empty(0, dtype=_F32, device=device))
         if need_ctx:
             ctx.K = K
             ctx.densify = densify
@@ -734,8 +764,14 @@ class _Rasterize(torch.autograd.Function):
         saved = ctx.saved_tensors
         device = saved[0].device
         need = ctx.needs_input_grad[7:]
-        arr = (_lib.ExaRasterBackwardJob * K)()
-        keep, ret = [], [None, None, None, None, None, None, None]
+        # a render none of whose images received a gradient does no work and returns None, as its own node would if it had
+        # been rendered by a call of its own (its backward would not run at all); K views summed in the kernel: all or none
+        dead = [grads[4 * k] is None and grads[4 * k + 2] is None and grads[4 * k + 3] is None for k in range(K)]
+        if ctx.shared and not all(dead):
+            dead = [False] * K
+        n_live = K - sum(dead)
+        arr = (_lib.ExaRasterBackwardJob * max(n_live, 1))()
+        keep, ret, late, pos = [], [None, None, None, None, None, None, None], [], 0
         rec = ctx.rec
         with _on_device(device):
             if rec is not None and not rec.done:
@@ -764,6 +800,14 @@ class _Rasterize(torch.autograd.Function):
                 has_sh, has_col, has_sc, has_rot, has_cov = ctx.has[k]
                 means3D, sh, col, opac, scales, rot, cov, radii = saved[8 * k: 8 * k + 8]
                 g_color, g_depth, g_alpha = grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]
+                if dead[k]:
+                    st, j.stash = j.stash, None
+                    if st is None:
+                        ret += [None] * N_IN
+                    else:                              # only the composites of this render were differentiated
+                        h3, hsh, hcol, hop, hsc, hrot, hcov = st[2]
+                        ret += [h3, None, hsh, hcol, hop, hsc, hrot, hcov]
+                    continue
 
                 g_color = _grad_in(g_color, (3, H, W), device)
                 if g_color is None:
@@ -779,15 +823,28 @@ class _Rasterize(torch.autograd.Function):
                 # AccumulateGrad adopts a contiguous view as `.grad` like any other tensor.
                 want = ((own and nd[0], 3), (nd[1], 3), (own and has_col and nd[3], 3), (own and nd[4], 1),
                         (own and has_sc and nd[5], 3), (own and has_rot and nd[6], 4), (own and has_cov and nd[7], 6))
-                widths = [w for on, w in want if on]
-                pieces = iter(torch.empty(Pg * sum(widths), dtype=_F32, device=device).split([Pg * w for w in widths])) \
-                    if widths else iter(())
-                d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
-                    [next(pieces).view(Pg, w) if on else None for on, w in want]
-                d_sh = torch.empty((Pg, sh_M, 3), dtype=_F32, device=device) if own and has_sh and nd[2] else None
+                want_sh = own and has_sh and nd[2]
+                # gradients a composite render left for these Gaussians (_Compose.backward): this call adds its own to them
+                st, j.stash = j.stash, None
+                fold = st is not None and not ctx.shared and nF == 0 and \
+                    st[1] == _grad_pattern(want[0][0], want_sh, want[2][0], want[3][0], want[4][0], want[5][0], want[6][0])
+                if fold:
+                    d_means3D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov = st[2]
+                    d_means2D = torch.empty((Pg, 3), dtype=_F32, device=device) if nd[1] else None
+                else:
+                    widths = [w for on, w in want if on]
+                    pieces = iter(torch.empty(Pg * sum(widths), dtype=_F32, device=device).split([Pg * w for w in widths])) \
+                        if widths else iter(())
+                    d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
+                        [next(pieces).view(Pg, w) if on else None for on, w in want]
+                    d_sh = torch.empty((Pg, sh_M, 3), dtype=_F32, device=device) if want_sh else None
+                    if st is not None:          # (a pattern this kernel path does not add in place: summed below)
+                        late += [(d, h) for d, h in zip((d_means3D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov), st[2])
+                                 if d is not None and h is not None]
                 grad_ws = torch.empty(int(_sizes(P, W, H, j.capacity).grad_bytes), dtype=torch.uint8, device=device)
                 keep += [g_color, g_depth, g_alpha, grad_ws]
-                a = arr[k]
+                a = arr[pos]
+                pos += 1
                 a.settings = ctypes.pointer(j.settings)   # built in forward; its tensors are kept alive by j.keep
                 a.P, a.sh_M = P, sh_M
                 a.means3D = means3D.data_ptr()
@@ -815,13 +872,17 @@ class _Rasterize(torch.autograd.Function):
                         a.dL_dmeans2D = d_tmp.data_ptr()
                     a.densify_grad_accum, a.densify_track_cnt, a.densify_radius_max = [_addr(t) for t in dens]
                 a.grad_first = nF
+                a.accumulate = 1 if fold else 0
                 if config.upstream_scale_grad and d_scales is not None and float(j.rs.scale_modifier) != 1.0:
                     keep.append((d_scales, float(j.rs.scale_modifier)))
                 ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
-            _lib.check(lib.exa_raster_backward_batch(arr, K, int(ctx.shared), _stream_ptr(device)))
+            if n_live:
+                _lib.check(lib.exa_raster_backward_batch(arr, n_live, int(ctx.shared), _stream_ptr(device)))
             for item in keep:
                 if isinstance(item, tuple):        # upstream's dL/dscale quirk: gradient w.r.t. (modifier * scale)
                     item[0].div_(item[1])
+            for d, h in late:
+                d.add_(h)
         return tuple(ret)
 
 
@@ -877,14 +938,16 @@ def _compose_launch(cjobs, store_ctx, device, capturing):
 class _Compose(torch.autograd.Function):
     """K composite renders of pairs of finished renders (``exa_raster_forward_compose_batch``): render k shows source A
     (a constant: the detached scene) and source B (trainable: the human) together, from the sources' own splat records and
-    sorted lists -- no preprocess, binning or sort of its own.  apply(K, sources, settings, grad_enabled, *tensors[8 K]):
+    sorted lists -- no preprocess, binning or sort of its own.  apply(K, sources, settings, grad_enabled, want_radii, token, *tensors[8 K]):
     ``sources[k] = (handle_a, handle_b)`` from ``rasterize_gaussians_batch(..., keep_keys=True)``; the tensors are B's inputs
-    (the same objects its own render got), they receive this render's gradients."""
+    (the same objects its own render got), they receive this render's gradients.  ``token``: None, or the ``.token`` of the
+    handles when ALL sources B come from that one batched call -- the gradients for B's tensors then travel through B's own
+    backward (``config.fold_composite_grads``) instead of being returned here."""
 
     @staticmethod
-    def forward(ctx, K, sources, settings, grad_enabled, *tensors):
+    def forward(ctx, K, sources, settings, grad_enabled, want_radii, token, *tensors):
         device = tensors[0].device
-        need_ctx = bool(grad_enabled) and any(ctx.needs_input_grad)
+        need_ctx = bool(grad_enabled) and any(ctx.needs_input_grad[6:])      # (the token alone asks for nothing)
         capturing = torch.cuda.is_current_stream_capturing()
         cjobs = []
         with _on_device(device):
@@ -911,7 +974,7 @@ class _Compose(torch.autograd.Function):
                 if c.settings.viewmatrix != ja.settings.viewmatrix:
                     raise ValueError('composite render: its camera differs from the sources\'')
                 c.planes = torch.empty((5, ja.H, ja.W), dtype=_F32, device=device)
-                c.radii = torch.cat((ja.radii, jb.radii))
+                c.radii = torch.cat((ja.radii, jb.radii)) if want_radii else None
                 c.key = ('compose', device.index, ja.P, jb.P, ja.H, ja.W)
                 cjobs.append(c)
             _compose_launch(cjobs, need_ctx, device, capturing)
@@ -922,6 +985,8 @@ class _Compose(torch.autograd.Function):
             outs += [col, c.radii, d, al]
         if need_ctx:
             ctx.K, ctx.cjobs, ctx.device = K, cjobs, device
+            ctx.fold = token is not None and bool(ctx.needs_input_grad[5]) and config.fold_composite_grads and \
+                all(c.b.token_ref is not None and c.b.token_ref() is token for c in cjobs)
             # B's converted inputs go through save_for_backward like _Rasterize's: an in-place update between the sources'
             # forward and this backward (the splat records of the sources hold the OLD values) raises instead of mixing
             saved, empty = [], None
@@ -934,7 +999,7 @@ class _Compose(torch.autograd.Function):
                         t = empty
                     saved.append(t)
             ctx.save_for_backward(*saved)
-        ctx.mark_non_differentiable(*[outs[4 * k + 1] for k in range(K)])
+        ctx.mark_non_differentiable(*[outs[4 * k + 1] for k in range(K) if outs[4 * k + 1] is not None])
         ctx.set_materialize_grads(False)
         return tuple(outs)
 
@@ -945,9 +1010,9 @@ class _Compose(torch.autograd.Function):
         lib = _lib.load()
         K, cjobs, device = ctx.K, ctx.cjobs, ctx.device
         saved = ctx.saved_tensors          # (checks the version counters of B's inputs)
-        need = ctx.needs_input_grad[4:]
+        need = ctx.needs_input_grad[6:]
         arr = (_lib.ExaRasterBackwardJob * K)()
-        keep, ret = [], [None, None, None, None]
+        keep, ret = [], [None, None, None, None, None, None]
         with _on_device(device):
             # A composite cannot overflow by itself (its buffer holds both sources' capacities); it is incomplete exactly
             # when a source overflowed.  The sources' reports are older than this render's, so they are looked at first;
@@ -1013,12 +1078,23 @@ class _Compose(torch.autograd.Function):
                 a.dL_dsh, a.dL_dcov3D = _addr(d_sh), _addr(d_cov)
                 a.grad_first = 0
                 a.compose_geom_a, a.compose_P_a, a.compose_capacity_b = ja.geom_ptr, ja.P, jb.capacity
-                ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
+                me = (id(ctx), k)
+                if ctx.fold and (jb.stash is None or jb.stash[0] == me):
+                    # leave them with B's job: B's own backward runs after this one (the token orders it) and adds its
+                    # gradients to these buffers inside its per-Gaussian kernel, then returns them as the tensors' gradients
+                    jb.stash = (me, _grad_pattern(nd[0], d_sh is not None, has_col and nd[3], nd[4], has_sc and nd[5],
+                                                  has_rot and nd[6], has_cov and nd[7]),
+                                (d_means3D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov))
+                    ret += [None, d_means2D, None, None, None, None, None, None]
+                    if ret[5] is None:
+                        ret[5] = torch.empty(0, dtype=_F32, device=device)
+                else:
+                    ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
             _lib.check(lib.exa_raster_backward_batch(arr, K, 0, _stream_ptr(device)))
         return tuple(ret)
 
 
-def rasterize_composites(sources, jobs):
+def rasterize_composites(sources, jobs, token=None, radii=True):
     """K composite renders -- "source A and source B rendered together" -- from renders that already exist.
 
     ``sources``: K pairs ``(handle_a, handle_b)`` of handles returned by ``rasterize_gaussians_batch(..., keep_keys=True)``
@@ -1027,7 +1103,9 @@ def rasterize_composites(sources, jobs):
     render got; they receive this render's gradients), a fresh ``means2D`` probe of B's length and ``raster_settings`` (the
     composite's background).  The composite reuses the sources' splat records and MERGES their sorted per-sub-tile lists:
     no preprocess, binning or sort of its own, bit-identical to rendering ``cat(A, B)``.  Returns K ``(color, radii, depth,
-    alpha)`` tuples; ``radii`` = ``cat(radii_a, radii_b)``."""
+    alpha)`` tuples; ``radii`` = ``cat(radii_a, radii_b)``.  ``token``: the ``.token`` of the handles list when every source B
+    belongs to that one batched call (see :class:`_Compose`); None is always correct.  ``radii=False``: the radii slot of
+    the returned tuples is None (no concatenation kernel; the caller builds it from the sources' radii if anybody asks)."""
     jobs = list(jobs)
     K = len(jobs)
     if K == 0:
@@ -1038,7 +1116,7 @@ def rasterize_composites(sources, jobs):
     for j in jobs:
         flat += [j.get(n) for n in _IN_NAMES]
     outs = _Compose.apply(K, tuple(tuple(s) for s in sources), tuple(j['raster_settings'] for j in jobs),
-                          torch.is_grad_enabled(), *flat)
+                          torch.is_grad_enabled(), bool(radii), token, *flat)
     return [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
 
 
@@ -1134,9 +1212,18 @@ def rasterize_gaussians_batch(jobs, keep_keys=False):
                             {'keep_keys': True} if keep_keys else None, *flat)
     res = [tuple(outs[4 * k: 4 * k + 4]) for k in range(K)]
     if keep_keys:
-        handles, _last_handles = _last_handles, None
+        handles, _last_handles = _Handles(_last_handles), None
+        handles.token = outs[4 * K]
+        ref = weakref.ref(handles.token)       # (weak: job -> token -> grad_fn -> ctx -> job would keep the workspaces alive)
+        for j in handles:
+            j.token_ref = ref
         return res, handles
     return res
+
+
+class _Handles(list):
+    """Handles of a ``keep_keys`` batch; ``token``: see :class:`_Compose`."""
+    token = None
 
 
 def _check_combo(shs, colors_precomp, scales, rotations, cov3D_precomp):

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from .camera import make_raster_matrices
 from .rasterizer import (GaussianRasterizationSettings, rasterize_composites, rasterize_gaussians,
-                         rasterize_gaussians_batch)
+                         rasterize_gaussians_batch, take_is_vis)
 
 
 _CAM_KEYS = ('focal', 'princpt', 'R', 't')
@@ -196,14 +196,101 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
                 densify_stats=densify_stats, frozen=frozen)
 
 
-def _output_dict(job, outs):
+def _output_dict(job, outs, is_vis=None):
+    """The reference's output dict (module.py:641-647).  ``is_vis`` (= ``radius > 0``): as the forward kernel wrote it
+    (``rasterizer.take_is_vis``), so that a render costs no comparison kernel."""
     render_img, radius, render_depthmap, render_mask = outs
     return {'img': render_img,
             'depthmap': render_depthmap,
             'mask': render_mask,
             'mean_2d': job['means2D'],
-            'is_vis': radius > 0,
+            'is_vis': is_vis if is_vis is not None else radius > 0,
             'radius': radius}
+
+
+class _CompositeOutput(dict):
+    """Output dict of a composite render (:func:`render_iteration`): ``radius`` / ``is_vis`` cover ``cat(scene, human)`` as the
+    reference's concatenated render returns them, but nothing on the reference's path reads them (it uses the composites'
+    ``img`` only, avatar/main/model.py:119-167) -- so the two concatenations run on first access instead of per iteration.
+    Behaves like the plain dict it stands for: every way of reading an entry or copying the dict materialises them first."""
+    __slots__ = ('_lazy',)
+    _KEYS = ('is_vis', 'radius')
+
+    def __init__(self, base, parts):
+        dict.__init__(self, base)
+        for k in self._KEYS:
+            dict.__setitem__(self, k, None)           # the keys exist: len(), `in` and keys() need no work
+        self._lazy = parts                            # ((radius_a, radius_b), (is_vis_a, is_vis_b))
+
+    def _materialise(self):
+        parts, self._lazy = self._lazy, None
+        if parts is not None:
+            dict.__setitem__(self, 'radius', torch.cat(parts[0]))
+            dict.__setitem__(self, 'is_vis', torch.cat(parts[1]))
+
+    def __getitem__(self, k):
+        if self._lazy is not None and k in self._KEYS:
+            self._materialise()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def __setitem__(self, k, v):
+        self._materialise()
+        dict.__setitem__(self, k, v)
+
+    def __delitem__(self, k):
+        self._materialise()
+        dict.__delitem__(self, k)
+
+    def update(self, *a, **kw):
+        self._materialise()
+        dict.update(self, *a, **kw)
+
+    def __iter__(self):                               # (overridden so that dict(x) / {**x} go through __getitem__)
+        return dict.__iter__(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def copy(self):
+        self._materialise()
+        return dict(dict.items(self))
+
+    def pop(self, k, *default):
+        self._materialise()
+        return dict.pop(self, k, *default)
+
+    def popitem(self):
+        self._materialise()
+        return dict.popitem(self)
+
+    def setdefault(self, k, default=None):
+        self._materialise()
+        return dict.setdefault(self, k, default)
+
+    def __eq__(self, other):
+        self._materialise()
+        return dict.__eq__(self, other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._materialise()
+        return dict.__repr__(self)
+
+    def __reduce__(self):
+        self._materialise()
+        return (dict, (dict(dict.items(self)),))
 
 
 class GaussianRenderer(nn.Module):
@@ -220,7 +307,8 @@ class GaussianRenderer(nn.Module):
         # an nn.Module per render
         outs = rasterize_gaussians(job['means3D'], job['means2D'], job['shs'], job['colors_precomp'], job['opacities'],
                                    job['scales'], job['rotations'], None, job['raster_settings'], densify_stats)
-        return _output_dict(job, outs)
+        vis = take_is_vis()
+        return _output_dict(job, outs[:4], vis[0] if vis else None)
 
 
 def render_many(renderer, jobs):
@@ -250,7 +338,8 @@ def render_many(renderer, jobs):
     rj = [_raster_job(j[0], j[1], j[2], j[3] if len(j) > 3 else None, j[4] if len(j) > 4 else None,
                       j[5] if len(j) > 5 else None) for j in jobs]
     outs = rasterize_gaussians_batch(rj)
-    return [_output_dict(j, o) for j, o in zip(rj, outs)]
+    vis = take_is_vis() or [None] * len(rj)
+    return [_output_dict(j, o, v) for j, o, v in zip(rj, outs, vis)]
 
 
 def render_views(renderer, gaussian_assets, img_shape, cam_params, bg=None):
@@ -315,20 +404,28 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
                  _raster_job(human_asset, img_shape, cam_param, bg, mean_2d=pr[1], **kw),
                  _raster_job(human_asset_refined, img_shape, cam_param, bg, mean_2d=pr[3], **kw)]
         outs, handles = rasterize_gaussians_batch(plain, keep_keys=True)
+        vis = take_is_vis() or (None, None, None)
         # ... and the two composites as MERGES of their sorted lists (white background, as the reference renders them)
         comp = [_raster_job(human_asset, img_shape, cam_param, None, mean_2d=pr[2], **kw),
                 _raster_job(human_asset_refined, img_shape, cam_param, None, mean_2d=pr[4], **kw)]
-        couts = rasterize_composites([(handles[0], handles[1]), (handles[0], handles[2])], comp)
-        res = [_output_dict(plain[0], outs[0]), _output_dict(plain[1], outs[1]), _output_dict(comp[0], couts[0]),
-               _output_dict(plain[2], outs[2]), _output_dict(comp[1], couts[1])]
-        return dict(zip(ITERATION_RENDERS, res))
+        couts = rasterize_composites([(handles[0], handles[1]), (handles[0], handles[2])], comp, token=handles.token,
+                                     radii=False)
+        res = [_output_dict(plain[k], outs[k], vis[k]) for k in range(3)]
+
+        def composite(k, b):
+            img, _none, depth, mask = couts[k]
+            radii = (outs[0][1], outs[b][1])
+            return _CompositeOutput({'img': img, 'depthmap': depth, 'mask': mask, 'mean_2d': comp[k]['means2D']},
+                                    (radii, tuple(v if v is not None else r > 0 for v, r in zip((vis[0], vis[b]), radii))))
+        return dict(zip(ITERATION_RENDERS, [res[0], res[1], composite(0, 1), res[2], composite(1, 2)]))
     rj = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats, mean_2d=pr[0], **kw),
           _raster_job(human_asset, img_shape, cam_param, bg, mean_2d=pr[1], **kw),
           _raster_job(human_asset, img_shape, cam_param, None, None, scene_asset, mean_2d=pr[2], **kw),
           _raster_job(human_asset_refined, img_shape, cam_param, bg, mean_2d=pr[3], **kw),
           _raster_job(human_asset_refined, img_shape, cam_param, None, None, scene_asset, mean_2d=pr[4], **kw)]
     outs = rasterize_gaussians_batch(rj)
-    return dict(zip(ITERATION_RENDERS, [_output_dict(j, o) for j, o in zip(rj, outs)]))
+    vis = take_is_vis() or [None] * 5
+    return dict(zip(ITERATION_RENDERS, [_output_dict(j, o, v) for j, o, v in zip(rj, outs, vis)]))
 
 
 class GraphedRenderer:

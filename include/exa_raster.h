@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 132          /* 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 133          /* 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -198,6 +198,9 @@ typedef struct ExaRasterForwardJob {
      * runtime call, copy or synchronisation; it works inside a captured hipGraph too (a plain store).  Use a fresh tag
      * (or reset the slot) per call to tell a new report from an old one. */
     void* host_header; uint32_t header_tag;
+    /* Optional (NULL = off): [dev] out uint8[P], is_vis[i] = radii[i] > 0, written by the per-Gaussian kernel next to radii --
+     * the `is_vis` of the reference's renderer (avatar/common/nets/layer.py: `radius > 0`) without a kernel of its own. */
+    uint8_t* is_vis;
 } ExaRasterForwardJob;
 
 typedef struct ExaRasterBackwardJob {
@@ -235,6 +238,11 @@ typedef struct ExaRasterBackwardJob {
      * hands `backward` a fresh one per iteration): exa_raster_store_pointers, enqueued on the same stream ahead of the
      * replay, points the call at it -- no 12-byte-per-pixel copy into a static buffer (GraphedIteration). */
     const float* const* dL_dcolor_indirect;
+    /* != 0: dL_dmeans3D, dL_dcolors, dL_dsh, dL_dopacity, dL_dscales, dL_drotations and dL_dcov3D already HOLD gradients
+     * (of another render of the same Gaussians, e.g. the composite that shows them over the scene) and this call ADDS its
+     * own to them: out = held + this render's, one read more per value and no separate summation pass.  dL_dmeans2D is
+     * per render and always overwritten.  Not combinable with sum_shared. */
+    int32_t accumulate;
 } ExaRasterBackwardJob;
 
 /* Stores `n` (<= 16) pointers into `table` (device memory) with one tiny kernel, in stream order. */

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 132
+    assert lib.exa_raster_version() == 133
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
@@ -83,10 +83,10 @@ def test_argument_validation_returns_negative_status_without_touching_the_gpu():
 
 def test_batch_job_structs_match_c_layout():
     # LP64: pointer, 2 x int32, then 8-byte fields only
-    assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8     # + keep_sorted_keys, host_header, header_tag (padded)
+    assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 8     # + keep_sorted_keys, host_header, header_tag (padded), is_vis
     assert _lib.ExaRasterForwardJob.keep_sorted_keys.offset == 136 and _lib.ExaRasterForwardJob.host_header.offset == 144
     assert _lib.ExaRasterForwardJob.capacity.offset == 104 and _lib.ExaRasterForwardJob.out_color.offset == 112
-    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8 + 8 + 3 * 8 + 8     # + composite fields, dL_dcolor_indirect
+    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8     # + composite fields, dL_dcolor_indirect, accumulate (padded)
     assert _lib.ExaRasterBackwardJob.grad_first.offset == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8
     assert _lib.ExaRasterBackwardJob.grad_ws.offset == 136
     lib = _lib.load()
@@ -258,3 +258,37 @@ def test_renderer_plumbing_of_sh_assets(monkeypatch):
         rn._raster_job(b, (32, 32), cam, None, None, a)
     j = rn._raster_job(b, (32, 32), cam, None, None, b)
     assert j['frozen']['shs'] is sh and j['frozen']['colors_precomp'] is None
+
+
+def test_composite_output_dict_behaves_like_the_dict_it_stands_for():
+    """renderer._CompositeOutput: radius / is_vis of a composite render are concatenated on first access; every way of
+    reading or copying the dict must see real tensors, in the reference's key order (module.py:641-647)."""
+    import copy
+    import pickle
+    from exavatar_release_amd.renderer import _CompositeOutput
+    ra, rb = torch.tensor([3, 0, 2], dtype=torch.int32), torch.tensor([0, 5], dtype=torch.int32)
+
+    def make():
+        base = {'img': torch.zeros(3, 2, 2), 'depthmap': torch.zeros(1, 2, 2), 'mask': torch.zeros(1, 2, 2), 'mean_2d': torch.zeros(2, 3)}
+        return _CompositeOutput(base, ((ra, rb), (ra > 0, rb > 0)))
+    want_r, want_v = torch.cat((ra, rb)), torch.cat((ra, rb)) > 0
+    o = make()
+    assert list(o.keys()) == ['img', 'depthmap', 'mask', 'mean_2d', 'is_vis', 'radius'] and len(o) == 6 and 'radius' in o
+    assert o._lazy is not None and torch.equal(o['img'], torch.zeros(3, 2, 2)) and o._lazy is not None   # other keys: no work
+    assert torch.equal(o['radius'], want_r) and torch.equal(o['is_vis'], want_v) and o['is_vis'].dtype == torch.bool
+    assert o._lazy is None and o['radius'] is o['radius']
+    for how in (dict, lambda d: {**d}, lambda d: d.copy(), copy.copy, lambda d: dict(d.items()), lambda d: pickle.loads(pickle.dumps(d)),
+                lambda d: {k: d[k] for k in d}, lambda d: dict(zip(d.keys(), d.values())), lambda d: {k: d.get(k) for k in d}):
+        c = how(make())
+        assert torch.equal(c['radius'], want_r) and torch.equal(c['is_vis'], want_v), how
+    o = make()
+    o['radius'] = 'mine'
+    assert o['radius'] == 'mine' and torch.equal(o['is_vis'], want_v)
+    o = make()
+    o.update(radius='mine')
+    assert o['radius'] == 'mine'
+    o = make()
+    assert torch.equal(o.pop('radius'), want_r) and 'radius' not in o and len(o) == 5
+    assert 'radius' in repr(make()) and 'None' not in repr(make())
+    assert make().get('nothing', 7) == 7 and torch.equal(make().get('radius'), want_r)
+    assert torch.equal(make().setdefault('radius', 1), want_r)

@@ -39,6 +39,7 @@ def iteration():
     loss.backward()
 
 
+exa.config.fold_composite_grads = os.environ.get('EXA_FOLD', '1') != '0'      # A/B knob
 exa.config.mode = 'exact'
 for _ in range(2):
     iteration()
