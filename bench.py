@@ -357,6 +357,12 @@ def main():
                                      '2e-2; grads 1e-3 rel, 1e-1 * mean floor for Gaussians under an ambiguous pixel (tests/helpers.py)',
                        'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
                        'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle,
+                       'view_switch': 'per step, inside the timed region: the next view\'s camera block (48 floats) copied into '
+                                      'the graph\'s static tensor by ' +
+                                      ('the runtime\'s blit (EXA_BENCH_CAM_COPY=memcpy)'
+                                       if os.environ.get('EXA_BENCH_CAM_COPY', 'kernel') == 'memcpy'
+                                       else 'one elementwise kernel (rounds 1-3: the runtime\'s blit, 3.6 us of GPU time; '
+                                            'EXA_BENCH_CAM_COPY=memcpy brings it back: -0.4 %)'),
                        'views_in_flight_per_gpu': S, 'views_per_launch': KV,
                        'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads (dist.FlatGradAllReducer)'
                                       % (world, n_float * 4),
@@ -613,7 +619,28 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
         mask = (torch.rand(1, 1, H, W, device=device) > 0.7).float()
         bbox = torch.tensor([[W // 4, H // 8, W // 2, 3 * H // 4]], dtype=torch.float32)
 
+        def synthetic_loss(out, G_):
+            return sum((out[k]['img'] * G_).sum() for k in exa.ITERATION_RENDERS)
+
+        def photometric_loss(out, target_, mask_):
+            loss = photo(out['scene']['img'][None], target_, l1_weight=1 - mask_, ssim_mask=1 - mask_)
+            for k in exa.ITERATION_RENDERS[1:]:
+                loss = loss + photo(out[k]['img'][None], target_, bbox=bbox)
+            return loss
+        # the same two losses RECORDED into the graph (GraphedIteration(loss_fn=...)): forward + loss + backward = one replay
+        graphed_l = exa.GraphedIteration((H, W), device, loss_fn=synthetic_loss)
+        graphed_pl = exa.GraphedIteration((H, W), device, loss_fn=photometric_loss)
+
         def iteration(how):
+            if how.endswith('_in_graph'):
+                for t in (scene, human, refined):
+                    for v in t.values():
+                        v.grad = None
+                if how == 'graphed_loss_in_graph':
+                    graphed_l(scene, human, refined, cam, bg, loss_args=(G,))['loss'].backward()
+                else:
+                    graphed_pl(scene, human, refined, cam, bg, loss_args=(target, mask))['loss'].backward()
+                return
             if how.endswith('_photometric'):
                 res = graphed(scene, human, refined, cam, bg) if how.startswith('graphed') else \
                     exa.render_iteration(rend, scene, human, refined, (H, W), cam, bg)
@@ -624,6 +651,15 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
                     for v in t.values():
                         v.grad = None
                 loss.backward()
+                return
+            if how == 'graphed_raster_only':
+                # what the headline measures for ONE render, for the five of an iteration: dL/dimg handed straight to the
+                # backward (= the loss sum(img * G) without its eleven PyTorch kernels per render)
+                res = graphed(scene, human, refined, cam, bg)
+                for t in (scene, human, refined):
+                    for v in t.values():
+                        v.grad = None
+                torch.autograd.backward([res[k]['img'] for k in exa.ITERATION_RENDERS], [G] * 5)
                 return
             if how == 'graphed':
                 res = graphed(scene, human, refined, cam, bg)
@@ -642,7 +678,8 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             loss.backward()
         out = {'workload': '%d k Dist-C scene + %d k avatar-like human Gaussians, %dx%d, 5 renders fwd+bwd, eager'
                            % (n_scene // 1000, n_human // 1000, W, H)}
-        for how in ('sequential', 'batched', 'sets', 'graphed', 'sets_photometric', 'graphed_photometric'):
+        for how in ('sequential', 'batched', 'sets', 'graphed', 'graphed_raster_only', 'graphed_loss_in_graph', 'sets_photometric',
+                    'graphed_photometric', 'graphed_photometric_in_graph'):
             # two iterations with the two-stage protocol first: they record the instance count of every render of THIS
             # scene (the capacity memo is keyed on (P, H, W), and the timed C3 runs above used P = 150 k as well)
             exa.config.mode = 'exact'
@@ -665,10 +702,18 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             ms, host_ms = sorted(windows)[1]
             out[how] = {'ms_per_iteration': ms, 'renders_per_s': 5e3 / ms, 'host_ms_per_iteration': host_ms,
                         'windows_ms': [round(w[0], 4) for w in windows]}
-            if how.endswith('_photometric'):
+            if how.endswith('_in_graph'):
+                out[how]['what'] = ('exa.GraphedIteration(loss_fn=...): the five forwards, the loss (%s) and the backwards recorded '
+                                    'into ONE hipGraph per iteration; loss.backward() hands the gradients the replay computed to '
+                                    'the asset tensors' % ('fused PhotometricLoss, as graphed_photometric' if 'photometric' in how
+                                                           else 'sum(img * G), as graphed'))
+            elif how.endswith('_photometric'):
                 out[how]['what'] = ('loss = the fused PhotometricLoss (L1 + SSIM, reference weights) of every render against a '
                                     'target image -- scene outside the mask, the four human renders inside a bbox -- instead of '
                                     'sum(img * G): what a train.py on this package runs per iteration around the rasterizer')
+            if how == 'graphed_raster_only':
+                out[how]['what'] = ('GraphedIteration with dL/dimg = G handed straight to backward (torch.autograd.backward(imgs, '
+                                    '[G] * 5)): the rasterizer work of the iteration alone, as the headline metric counts one render')
             if how == 'graphed':
                 out[how]['what'] = ('exa.GraphedIteration: one hipGraph for the five forwards, one for their backwards, same '
                                     'loss in PyTorch between them; captures=%d' % graphed.captures)

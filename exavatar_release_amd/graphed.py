@@ -31,6 +31,25 @@ the call returns: the images handed out are always complete, same contract as th
 to eager :func:`renderer.render_iteration` (same kernels, same order; tests/test_gpu_graphed_iteration.py).
 
 The returned images alias the graph's static outputs: valid until the next call (clone what must survive).
+
+**The loss inside the graph** (``loss_fn``).  With the loss in PyTorch between the two graphs the host is on the critical
+path again: after the forward replay it launches the loss kernels, runs the autograd engine through them and only then queues
+the backward replay (~0.3 ms of Python per iteration, during part of which the GPU waits).  A loss that is a fixed sequence of
+tensor operations can be recorded as well::
+
+    def my_loss(out, target, mask):              # out: the dict of the five renders; tensors only, no .item() / host branches
+        return photo(out['scene']['img'][None], target, l1_weight=1 - mask) + ...
+    it = GraphedIteration((H, W), device, loss_fn=my_loss)
+    for data in loader:
+        out = it(scene_asset, human_asset, human_asset_refined, cam_param, bg, stats, loss_args=(data['img'], data['mask']))
+        out['loss'].backward()                   # the gradients were computed by the SAME replay; this hands them on
+        optimizer.step()
+
+Forward, loss and backward are then ONE hipGraph per iteration; ``out['loss'].backward()`` only scales the (already
+computed) flat gradient buffer by the incoming gradient and passes its slices to the asset tensors.  ``loss_args`` are copied
+into static tensors of the capture per call (one fused copy; a change of their shapes re-captures); the images in ``out`` carry
+no autograd history in this mode (the loss is the only differentiable output).  The densification statistics are updated by
+the replay itself; an iteration that overflowed restores them from the copy the graph makes first and runs again.
 """
 import ctypes
 import time
@@ -54,7 +73,8 @@ def _colour_key(asset):
 class _Captured:
     """Everything one capture owns (replaced as a whole on re-capture)."""
     __slots__ = ('key', 'inputs', 'in_list', 'in_raw', 'probes', 'tan', 'fwd', 'pool', 'outs', 'out_list', 'radii', 'bwd',
-                 'slots', 'caps', 'dens_ptrs', 'sizes', 'diff_inputs')
+                 'slots', 'caps', 'dens_ptrs', 'sizes', 'diff_inputs', 'offsets', 'strides', 'loss', 'loss_args', 'flat',
+                 'unused', 'dens', 'dens_backup')
 
 
 class _IterFn(torch.autograd.Function):
@@ -63,7 +83,7 @@ class _IterFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, owner, cap, *tensors):
-        ctx.owner, ctx.cap = owner, cap
+        ctx.owner, ctx.cap, ctx.serial = owner, cap, owner._serial
         ctx.set_materialize_grads(False)
         # Aliases of the static outputs: no copies (they are overwritten by the next replay).  Detached, because the static
         # tensors carry the autograd graph of the CAPTURED call, which the backward graphs were recorded from and which
@@ -77,13 +97,47 @@ class _IterFn(torch.autograd.Function):
         if cap is not ctx.cap:
             raise RuntimeError('exavatar_release_amd: GraphedIteration.backward after a later call replaced its capture '
                                '(call backward before the next iteration)')
+        if owner._serial != ctx.serial:
+            raise RuntimeError('exavatar_release_amd: GraphedIteration.backward after a later call overwrote the forward '
+                               'state its backward graph reads (call backward before the next iteration)')
         flat = owner._backward(grads[:15])
-        outs = []
-        off = 0
-        for need, n, shape in zip(ctx.needs_input_grad[2:], cap.sizes, cap.diff_inputs):
-            outs.append(flat[off:off + n].view(shape) if need else None)
-            off += n
-        return (None, None) + tuple(outs)
+        return (None, None) + _grad_views(flat, cap, ctx.needs_input_grad[2:], None)
+
+
+def _grad_views(flat, cap, needed, unused):
+    """The slices of a flat gradient buffer as tensors of the inputs' shapes (as_strided: a third of the host time of
+    slice + view, twenty times per iteration)."""
+    outs = []
+    for i, need in enumerate(needed):
+        if need and not (unused is not None and unused[i]):
+            outs.append(torch.as_strided(flat, cap.diff_inputs[i], cap.strides[i], cap.offsets[i]))
+        else:
+            outs.append(None)
+    return tuple(outs)
+
+
+class _LossFn(torch.autograd.Function):
+    """Autograd boundary of an iteration whose loss and backward were part of the replay (``loss_fn``): apply(owner, cap,
+    *asset tensors [15], *probes [5]) -> the loss; backward scales the gradients the replay left in ``cap.flat``."""
+
+    @staticmethod
+    def forward(ctx, owner, cap, *tensors):
+        ctx.owner, ctx.cap, ctx.serial = owner, cap, owner._serial
+        return cap.loss.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        owner = ctx.owner
+        cap = owner._cap
+        if cap is not ctx.cap:
+            raise RuntimeError('exavatar_release_amd: GraphedIteration: backward of a loss after a later call replaced its '
+                               'capture (call backward before the next iteration)')
+        if owner._serial != ctx.serial:
+            raise RuntimeError('exavatar_release_amd: GraphedIteration: backward of a loss after a later call overwrote its '
+                               'gradients (call backward before the next iteration)')
+        with rz._on_device(owner.device):
+            flat = cap.flat * g                 # a private copy, scaled by dL/dloss (ones for a plain loss.backward())
+        return (None, None) + _grad_views(flat, cap, ctx.needs_input_grad[2:], cap.unused)
 
 
 class GraphedIteration:
@@ -92,14 +146,18 @@ class GraphedIteration:
     iteration of a capture needed.  ``check``: poll the overflow reports after every forward replay; switch off only when
     the capacities are known to be sufficient.  ``capacities``: instance capacities
     of the three plain renders (scene, human, refined human) for the FIRST capture instead of measuring them with an eager
-    iteration.  Counters: ``captures``, ``overflow_retries``."""
+    iteration.  ``loss_fn``: ``loss_fn(out, *loss_args) -> scalar tensor`` recorded into the graph together with its backward
+    (module docstring); calls then take ``loss_args=(tensors...)`` and return the loss as ``out['loss']``.
+    Counters: ``captures``, ``overflow_retries``."""
 
-    def __init__(self, img_shape, device, merge=True, capacity_growth=1.5, check=True, capacities=None):
+    def __init__(self, img_shape, device, merge=True, capacity_growth=1.5, check=True, capacities=None, loss_fn=None):
         device = torch.device(device)
         if device.type != 'cuda':
             raise RuntimeError('exavatar_release_amd: GraphedIteration runs on a ROCm device only')
         self.shape, self.device = (int(img_shape[0]), int(img_shape[1])), device
         self.merge, self.growth, self.check = bool(merge), float(capacity_growth), bool(check)
+        self.loss_fn = loss_fn
+        self._serial = 0                # number of forward replays: a backward must belong to the latest one
         self._cam = torch.zeros(38, dtype=torch.float32, device=device)   # viewmatrix 16 | projmatrix 16 | campos 3 | bg 3:
         #                                                                   outlives the captures, which read views of it
         # pointer table of the backward graphs (ExaRasterBackwardJob.dL_dcolor_indirect): entry i holds the address the
@@ -152,7 +210,7 @@ class GraphedIteration:
         return render_iteration(None, i['scene'], i['human'], i['human_refined'], self.shape, None, c[35:38], dens,
                                 merge=self.merge, cam_block=block, probes=cap.probes)
 
-    def _capture(self, assets, tan, dens, key):
+    def _capture(self, assets, tan, dens, key, loss_args=()):
         dev = self.device
         self._release()
         cap = _Captured()
@@ -170,6 +228,11 @@ class GraphedIteration:
         cap.dens_ptrs = None if dens is None else tuple(None if t is None else t.data_ptr() for t in dens)
         cap.diff_inputs = [tuple(t.shape) for t in cap.in_list + cap.probes]
         cap.sizes = [t.numel() for t in cap.in_list + cap.probes]
+        cap.strides = [tuple(t.stride()) for t in cap.in_list + cap.probes]
+        cap.offsets = [sum(cap.sizes[:i]) for i in range(len(cap.sizes))]
+        cap.loss = cap.flat = cap.unused = cap.dens_backup = None
+        cap.dens = None if dens is None else [t for t in dens if t is not None]
+        cap.loss_args = [t.detach().clone() for t in loss_args]          # static: the recorded loss reads these
         self._fill_inputs(cap, assets)
         saved = (rz.config.mode, rz.config.fixed_capacity)
         try:
@@ -203,8 +266,12 @@ class GraphedIteration:
                     side.wait_stream(torch.cuda.current_stream(dev))
                     with torch.cuda.stream(side):
                         res = self._render(cap, None)
-                        torch.autograd.grad([res[k]['img'] for k in ITERATION_RENDERS], cap.in_list,
-                                            grad_outputs=[torch.ones_like(res[k]['img']) for k in ITERATION_RENDERS], allow_unused=True)
+                        if self.loss_fn is not None:
+                            torch.autograd.grad(self.loss_fn(res, *cap.loss_args), cap.in_list, allow_unused=True)
+                        else:
+                            torch.autograd.grad([res[k]['img'] for k in ITERATION_RENDERS], cap.in_list,
+                                                grad_outputs=[torch.ones_like(res[k]['img']) for k in ITERATION_RENDERS],
+                                                allow_unused=True)
                         del res
                     torch.cuda.current_stream(dev).wait_stream(side)
                     torch.cuda.synchronize(dev)
@@ -220,9 +287,24 @@ class GraphedIteration:
                 cap.pool = torch.cuda.graph_pool_handle()
                 cap.fwd = torch.cuda.CUDAGraph()
                 rz._capture_report = cap.slots
+                if self.loss_fn is not None:
+                    cap.flat = torch.zeros(sum(cap.sizes), **f32)
+                    if cap.dens:
+                        cap.dens_backup = [torch.empty_like(t) for t in cap.dens]
                 try:
                     with torch.cuda.graph(cap.fwd, pool=cap.pool):
+                        if cap.dens_backup:
+                            # the replay's backward updates the statistics; an overflowed replay is thrown away and must
+                            # leave them as they were (_grow restores them from here)
+                            torch._foreach_copy_(cap.dens_backup, cap.dens)
                         res = self._render(cap, dens)
+                        if self.loss_fn is not None:
+                            loss = self.loss_fn(res, *cap.loss_args)
+                            if not (torch.is_tensor(loss) and loss.numel() == 1 and loss.requires_grad):
+                                raise ValueError('GraphedIteration: loss_fn must return a scalar tensor that depends on the renders')
+                            grads = torch.autograd.grad(loss, cap.in_list + cap.probes, allow_unused=True)
+                            cap.unused = self._pack(grads, cap, cap.flat)
+                            cap.loss = loss.detach()
                 finally:
                     rz._capture_report = None
                 cap.outs = res
@@ -237,7 +319,8 @@ class GraphedIteration:
             rz.config.mode, rz.config.fixed_capacity = saved
         # the backward graph of the usual case -- gradients for the five colour images only -- is
         # recorded right away; other patterns (depth / mask gradients, fewer images) on first use
-        self._capture_backward(cap, _IMG_ONLY)
+        if self.loss_fn is None:
+            self._capture_backward(cap, _IMG_ONLY)
         self._cap = cap
         return cap
 
@@ -259,24 +342,29 @@ class GraphedIteration:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=cap.pool):
                     grads = torch.autograd.grad(outs, inputs, grad_outputs=gos, allow_unused=True, retain_graph=True)
-                    # pack into the flat buffer with ONE multi-tensor kernel (twenty elementwise launches cost ~40 us of
-                    # in-graph dispatch gaps; memcpy / memset nodes are not replay-safe on this runtime, a kernel is)
-                    views, present, off = [], [], 0
-                    for gr, n in zip(grads, cap.sizes):
-                        if gr is not None:
-                            views.append(flat[off:off + n].view(gr.shape))
-                            present.append(gr)
-                        off += n
-                    if len(present) == len(grads):
-                        torch.cat([gr.reshape(-1) for gr in present], out=flat)
-                    else:
-                        torch._foreach_copy_(views, present)
-                unused = [gr is None for gr in grads]
+                    unused = self._pack(grads, cap, flat)
         finally:
             rz.config.mode, rz.config.fixed_capacity = saved
             rz._capture_grad_ind = None
         cap.bwd[pattern] = (g, g_in, flat, unused)
         return cap.bwd[pattern]
+
+    @staticmethod
+    def _pack(grads, cap, flat):
+        """Record the packing of ``grads`` into ``flat`` with ONE multi-tensor kernel (twenty elementwise launches cost ~40 us
+        of in-graph dispatch gaps; memcpy / memset nodes are not replay-safe on this runtime, a kernel is).  Returns the list
+        of "this input got no gradient" flags."""
+        views, present, off = [], [], 0
+        for gr, n in zip(grads, cap.sizes):
+            if gr is not None:
+                views.append(flat[off:off + n].view(gr.shape))
+                present.append(gr)
+            off += n
+        if len(present) == len(grads):
+            torch.cat([gr.reshape(-1) for gr in present], out=flat)
+        elif present:
+            torch._foreach_copy_(views, present)
+        return [gr is None for gr in grads]
 
     # ---- per call --------------------------------------------------------------------------------------------------
     def _fill_inputs(self, cap, assets):
@@ -359,10 +447,11 @@ class GraphedIteration:
         raise RuntimeError('exavatar_release_amd: GraphedIteration needs pinned host memory mapped for the device '
                            '(header reports); use the eager render_iteration on this system')
 
-    def _replay_forward(self, assets, cam_param, bg, dens, refill):
+    def _replay_forward(self, assets, cam_param, bg, dens, refill, loss_args=()):
         """(Re-)capture if needed, fill the static inputs, replay the forward graph.  Returns the capture."""
         dev = self.device
-        key = tuple((tuple(a['mean_3d'].shape), _colour_key(a), tuple(a[_colour_key(a)].shape)) for a in assets)
+        key = tuple((tuple(a['mean_3d'].shape), _colour_key(a), tuple(a[_colour_key(a)].shape)) for a in assets) + \
+            tuple((tuple(t.shape), t.dtype) for t in loss_args)
         dens_ptrs = None if dens is None else tuple(None if t is None else t.data_ptr() for t in dens)
         for _ in range(4):
             cap = self._cap
@@ -374,21 +463,39 @@ class GraphedIteration:
                 self._bg_src, self._bg_ver = bg, getattr(bg, '_version', None)
             if cap is None or cap.key != key or cap.tan != tan or cap.dens_ptrs != dens_ptrs:
                 try:
-                    cap = self._capture(assets, tan, dens, key)
+                    cap = self._capture(assets, tan, dens, key, loss_args)
                 finally:
                     self._caps_hint = None
             elif refill:
                 self._fill_inputs(cap, assets)
+                if loss_args:
+                    pairs = [(d, s_) for d, s_ in zip(cap.loss_args, loss_args) if d is not s_]
+                    if pairs:
+                        with torch.no_grad():
+                            torch._foreach_copy_([d for d, _ in pairs], [s_.detach() for _, s_ in pairs])
             self._reset_reports(cap)
             cap.fwd.replay()
+            self._serial += 1
             self._reports_checked = False
             if chk is not None and not self._focal_ok(chk, cam_param['focal']):
                 continue                      # the focal length changed: derive the intrinsics again, maybe re-capture
             return cap
         raise RuntimeError('exavatar_release_amd: GraphedIteration could not settle its camera intrinsics')
 
-    def __call__(self, scene_asset, human_asset, human_asset_refined, cam_param, bg=None, scene_densify_stats=None):
+    @property
+    def loss_inputs(self):
+        """The static tensors the recorded loss reads (one per ``loss_args`` entry, None before the first call): a producer
+        may write into them in place and pass them back as ``loss_args`` -- no per-call copy then."""
+        return None if self._cap is None else list(self._cap.loss_args)
+
+    def __call__(self, scene_asset, human_asset, human_asset_refined, cam_param, bg=None, scene_densify_stats=None,
+                 loss_args=()):
         dev = self.device
+        loss_args = tuple(loss_args)
+        if loss_args and self.loss_fn is None:
+            raise ValueError('GraphedIteration: loss_args without a loss_fn')
+        if not all(torch.is_tensor(t) and t.device == dev for t in loss_args):
+            raise ValueError('GraphedIteration: loss_args must be tensors on %s (close over everything else in loss_fn)' % dev)
         assets = (scene_asset, human_asset, human_asset_refined)
         modes = {_colour_key(a) for a in assets}
         if len(modes) != 1:
@@ -399,14 +506,24 @@ class GraphedIteration:
         if dens is not None:
             dens = rz._check_densify(dens, int(scene_asset['mean_3d'].shape[0]), dev)
         with rz._on_device(dev):
-            self._args = (assets, cam_param, bg, dens)
-            cap = self._replay_forward(assets, cam_param, bg, dens, refill=True)
+            self._args = (assets, cam_param, bg, dens, loss_args)
+            cap = self._replay_forward(assets, cam_param, bg, dens, refill=True, loss_args=loss_args)
             needs = self._overflowed(cap)
             while needs is not None:          # repaired before anybody can read the outputs
                 cap = self._grow(needs)
                 needs = self._overflowed(cap)
             grad = torch.is_grad_enabled() and any(a[k].requires_grad for a in assets for k in _ASSET_KEYS + (_colour_key(a),))
-            if not grad:
+            loss = None
+            if self.loss_fn is not None:
+                # forward, loss and backward were one replay: the images are results only, the loss carries the gradients
+                outs = [o.detach() for o in cap.out_list]
+                if grad:
+                    probes = [p.detach().requires_grad_(True) for p in cap.probes]
+                    src = [a[k] for a in assets for k in _ASSET_KEYS + (_colour_key(a),)]
+                    loss = _LossFn.apply(self, cap, *src, *probes)
+                else:
+                    probes, loss = [None] * 5, cap.loss.detach()
+            elif not grad:
                 outs = [o.detach() for o in cap.out_list]
                 probes = [None] * 5
             else:
@@ -425,6 +542,8 @@ class GraphedIteration:
             else:
                 rs, rb = cap.radii['scene'], cap.radii['human' if name == 'scene_human' else 'human_refined']
                 out[name] = _CompositeOutput(base, ((rs[0], rb[0]), (rs[1], rb[1])))
+        if loss is not None:
+            out['loss'] = loss
         return out
 
     def _grow(self, needs):
@@ -435,9 +554,12 @@ class GraphedIteration:
         self._caps_hint = [max(int(n * self.growth), c) if n > c else c for n, c in zip(n3, c3)]
         self.overflow_retries += 1
         rz._record_overflow(('graphed_iteration',) + tuple(old.key), max(needs), max(old.caps), 'retried')
-        assets, cam_param, bg, dens = self._args
+        assets, cam_param, bg, dens, loss_args = self._args
+        if old.dens_backup:                   # (loss_fn: the overflowed replay's backward already updated the statistics)
+            with torch.no_grad():
+                torch._foreach_copy_(old.dens, old.dens_backup)
         self._release()
-        return self._replay_forward(assets, cam_param, bg, dens, refill=False)
+        return self._replay_forward(assets, cam_param, bg, dens, refill=False, loss_args=loss_args)
 
     def _backward(self, grads):
         """Replay the backward graph for the incoming image gradients; returns a private flat gradient buffer."""

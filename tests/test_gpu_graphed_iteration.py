@@ -218,3 +218,104 @@ def test_graphed_iteration_drives_an_optimizer_like_the_eager_path(dev):
     pb, lb = loop(False)
     _same(pa, pb, 'parameter / statistic after 40 Adam steps')
     assert la == lb and la[-1] < la[0]
+
+
+# ---- the loss inside the graph (loss_fn) -------------------------------------------------------------------------------
+
+def _photo_loss(photo):
+    """The reference's photometric objective per render (avatar/main/model.py:197-198, 214-215) through the fused producer."""
+    def loss_fn(out, target, mask, weight):
+        loss = photo(out['scene']['img'][None], target, l1_weight=1 - mask, ssim_mask=1 - mask)
+        for k, n in enumerate(exa.ITERATION_RENDERS[1:]):
+            loss = loss + weight[k] * photo(out[n]['img'][None], target)
+        return loss + 0.01 * out['human']['mask'].mean() + 0.01 * out['scene_human']['depthmap'].mean()
+    return loss_fn
+
+
+def _run_loss(fn, graphed, loss_fn, sets, cam, bg, dens, args, scale=1.0):
+    s, h, r = _leaves(sets)
+    if graphed:
+        out = fn(s, h, r, cam, bg, dens, loss_args=args)
+        loss = out['loss']
+    else:
+        out = fn(s, h, r, cam, bg, dens)
+        loss = loss_fn(out, *args)
+    planes = [out[n][k].detach().clone() for n in exa.ITERATION_RENDERS for k in ('img', 'depthmap', 'mask')]
+    (scale * loss).backward()
+    torch.cuda.synchronize()
+    grads = [t[k].grad.clone() for t in (s, h, r) for k in KEYS]
+    grads += [out[n]['mean_2d'].grad.clone() for n in exa.ITERATION_RENDERS]
+    return planes, loss.detach().clone(), grads
+
+
+def test_loss_recorded_into_the_graph_is_the_eager_loop_bit_for_bit(dev):
+    photo = exa.PhotometricLoss()
+    loss_fn = _photo_loss(photo)
+    it = exa.GraphedIteration((H, W), dev, loss_fn=loss_fn)
+    eager = _eager()
+    g = torch.Generator().manual_seed(12)
+    sets = _sets(2600, 1300, 81, dev)
+    da, db = _stats(2600, dev), _stats(2600, dev)
+    for i in range(4):
+        cam, bg = _cam(2 * i + 1, dev), torch.rand(3, generator=g).to(dev)
+        args = (torch.rand(1, 3, H, W, generator=g).to(dev), (torch.rand(1, 1, H, W, generator=g) > 0.6).float().to(dev),
+                torch.rand(4, generator=g).to(dev))
+        if i == 2:      # the producer writes into the capture's own tensors: no copy
+            for d, s_ in zip(it.loss_inputs, args):
+                d.copy_(s_)
+            args_g = tuple(it.loss_inputs)
+        else:
+            args_g = args
+        pa, la, ga = _run_loss(it, True, loss_fn, sets, cam, bg, da, args_g)
+        pb, lb, gb = _run_loss(eager, False, loss_fn, sets, cam, bg, db, args)
+        _same(pa, pb, 'plane'); _same([la], [lb], 'loss'); _same(ga, gb, 'grad'); _same(da, db, 'densify statistic')
+        sets = [{k: (v + 0.003 * torch.randn(v.shape, generator=g).to(dev) if k in ('mean_3d', 'rgb') else v) for k, v in d.items()}
+                for d in sets]
+    assert it.captures == 1 and float(da[1].sum()) > 0
+    # an incoming gradient other than one scales the gradients handed on (the statistics inside the replay are those of
+    # d loss itself, i.e. of the plain loss.backward() the reference calls, avatar/main/train.py:46)
+    pa, la, ga = _run_loss(it, True, loss_fn, sets, cam, bg, _stats(2600, dev), args, scale=2.0)
+    pb, lb, gb = _run_loss(eager, False, loss_fn, sets, cam, bg, _stats(2600, dev), args, scale=2.0)
+    _same(ga, gb, 'grad of 2 * loss')
+    assert it.captures == 2           # (new statistics tensors: their addresses are part of the recording)
+    # P changes (densify / prune): one re-capture, still the eager loop
+    sets2 = _sets(3000, 1300, 82, dev)
+    da, db = _stats(3000, dev), _stats(3000, dev)
+    pa, la, ga = _run_loss(it, True, loss_fn, sets2, cam, bg, da, args)
+    pb, lb, gb = _run_loss(eager, False, loss_fn, sets2, cam, bg, db, args)
+    _same(pa, pb, 'plane after P change'); _same([la], [lb], 'loss'); _same(ga, gb, 'grad after P change'); _same(da, db, 'statistic')
+    assert it.captures == 3
+    # evaluation under no_grad: the loss value, no history
+    with torch.no_grad():
+        out = it(*sets2, cam, bg, da, loss_args=args)
+    assert not out['loss'].requires_grad and torch.equal(out['loss'], lb)
+    # a backward that comes after the next forward is refused (its gradients were overwritten)
+    s, h, r = _leaves(sets2)
+    first = it(s, h, r, cam, bg, da, loss_args=args)
+    it(s, h, r, cam, bg, da, loss_args=args)
+    with pytest.raises(RuntimeError, match='later call'):
+        first['loss'].backward()
+    with pytest.raises(ValueError, match='loss_args without'):
+        exa.GraphedIteration((H, W), dev)(*sets2, cam, bg, None, loss_args=args)
+
+
+def test_loss_in_the_graph_survives_an_overflow_with_the_statistics_intact(dev):
+    """Too-small instance buffers: the overflowed replay already ran its backward (and updated the densification
+    statistics); it is thrown away, the statistics are restored and the iteration runs again with room."""
+    G = _G(dev, 13)
+
+    def loss_fn(out, w):
+        return sum((out[n]['img'] * G[k]).sum() * w[k] for k, n in enumerate(exa.ITERATION_RENDERS))
+    sets = _sets(2500, 1200, 91, dev)
+    cam, bg = _cam(3, dev), torch.full((3,), 0.4, device=dev)
+    w = torch.rand(5, device=dev)
+    small = exa.GraphedIteration((H, W), dev, capacities=(2048, 1024, 1024), loss_fn=loss_fn)
+    eager = _eager()
+    da, db = _stats(2500, dev), _stats(2500, dev)
+    for t in da + db:
+        t.fill_(0.25)
+    for i in range(2):
+        pa, la, ga = _run_loss(small, True, loss_fn, sets, cam, bg, da, (w,))
+        pb, lb, gb = _run_loss(eager, False, loss_fn, sets, cam, bg, db, (w,))
+        _same(pa, pb, 'plane'); _same([la], [lb], 'loss'); _same(ga, gb, 'grad'); _same(da, db, 'densify statistic')
+    assert small.overflow_retries >= 1

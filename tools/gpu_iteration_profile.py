@@ -19,9 +19,17 @@ cat = lambda a, b: {k: torch.cat((a[k].detach(), b[k])) for k in keys}      # no
 
 
 graphed = exa.GraphedIteration((H, W), dev) if how == 'graphed' else None
+if how == 'graphed_loss':       # the same loss recorded into the graph: forward + loss + backward = one replay
+    graphed = exa.GraphedIteration((H, W), dev, loss_fn=lambda out, G_: sum((out[k]['img'] * G_).sum() for k in exa.ITERATION_RENDERS))
 
 
 def iteration():
+    if how == 'graphed_loss':
+        for t in (scene, human, refined):
+            for v in t.values():
+                v.grad = None
+        graphed(scene, human, refined, cam, bg, loss_args=(G,))['loss'].backward()
+        return
     if how == 'graphed':
         res = graphed(scene, human, refined, cam, bg)
         outs = [res[k] for k in exa.ITERATION_RENDERS]
