@@ -50,6 +50,18 @@ with open(os.path.join(out, prefix + '_kernel_stats.md'), 'w') as f:
                 f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3,
                                                                   float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
 
+# machine-readable copy (bench.py quotes the dominant kernel's rocprof average next to its own HIP-event bracket)
+if stats:
+    kern = {}
+    with open(stats[0]) as g:
+        for r in csv.DictReader(g):
+            k = short(r['Name'])
+            if k and k not in kern:          # (first = the instantiation with the most GPU time)
+                kern[k] = {'avg_us': float(r['AverageNs']) / 1e3, 'calls': int(r['Calls'])}
+    with open(os.path.join(out, prefix + '_kernel_stats.json'), 'w') as f:
+        json.dump({'what': 'rocprofv3 --kernel-trace --stats of `python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-concurrent` '
+                           '(C3, graph replay, ring average)', 'kernels': kern}, f, indent=1)
+
 # ---- HBM traffic -----------------------------------------------------------------------------------------
 fe, wr = counters('pmc_fetch'), counters('pmc_write')
 alg = bench['roofline'].get('algorithmic_bytes_per_launch')

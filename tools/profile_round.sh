@@ -36,3 +36,5 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_stats 
 ( cd $R && timeout 300 python tools/gpu_graphed_iter_profile.py > $O/graphed_iter_profile.log 2>&1 )
 cat $O/graphed_iter_profile.log | grep -v amdgpu
 grep "eager render\|^host:" $O/host_profile.log; cat $O/graphed.log | cut -c1-160; tail -2 $O/iter_repeat.log | cut -c1-300
+# round 4 (late): the same iteration with the loss recorded into the graph (timing only)
+( cd $R && for how in graphed graphed_loss sets; do timeout 200 python tools/gpu_iteration_profile.py $how 300 2>&1 | tail -1; done ) | tee $O/iter_times.log
