@@ -47,10 +47,12 @@ def _act(r):
 
 
 def run(dev, iters=300, mode='auto', graphed=False, densify_every=50, n_scene=1500, n_human=1500, rank=0, world=1, seed=0,
-        forget_every=0):
+        forget_every=0, loss_in_graph=False):
     """Returns a dict: final parameters (list of tensors), losses, P history, counters.  ``forget_every``: every that many
     iterations the capacity memo is scaled down to 60 % -- the situation of a scene that suddenly needs more tile
-    instances than any call before it, i.e. an overflow of every render of the next iteration."""
+    instances than any call before it, i.e. an overflow of every render of the next iteration.  ``loss_in_graph`` (with
+    ``graphed``): the photometric loss is recorded into the graph (``GraphedIteration(loss_fn=...)``), the five target images
+    travel as ``loss_args``."""
     saved = (exa.config.mode, exa.config.fixed_capacity, exa.config.capacity_growth, exa.config.min_capacity)
     exa.config.mode, exa.config.fixed_capacity = mode, None
     exa.config.capacity_growth, exa.config.min_capacity = 1.05, 64      # tight buffers: overflows WILL happen in 'auto'
@@ -85,7 +87,9 @@ def run(dev, iters=300, mode='auto', graphed=False, densify_every=50, n_scene=15
         cam = {k: t.to(dev).clone() for k, t in cams[0].items()}        # ONE set of camera tensors, updated in place
         stats = [torch.zeros(n_scene, 1, device=dev) for _ in range(3)]
         gen = exa_densify.synchronised_generator(1234 + seed, dev)
-        it = exa.GraphedIteration((H, W), dev) if graphed else None
+        def objective(out, *tgts):
+            return sum(photo(out[n]['img'][None], t) for n, t in zip(exa.ITERATION_RENDERS, tgts))
+        it = exa.GraphedIteration((H, W), dev, loss_fn=objective if loss_in_graph else None) if graphed else None
         my_views = exa_dist.shard_views(N_VIEWS, rank, world, shuffle=False)
         reducer = None
         losses, p_hist, evals = [], [], []
@@ -99,11 +103,15 @@ def run(dev, iters=300, mode='auto', graphed=False, densify_every=50, n_scene=15
                 for key in list(rz._seen_D):
                     rz._seen_D[key] = int(rz._seen_D[key] * 0.6)
             a_s, a_h, a_r = _act(scene), _act(human), _act(refined)
-            if graphed:
-                out = it(a_s, a_h, a_r, cam, bg, tuple(stats))
+            if graphed and loss_in_graph:
+                out = it(a_s, a_h, a_r, cam, bg, tuple(stats), loss_args=tuple(targets[v][n] for n in exa.ITERATION_RENDERS))
+                loss = out['loss']
             else:
-                out = exa.render_iteration(rend, a_s, a_h, a_r, (H, W), cam, bg, tuple(stats))
-            loss = sum(photo(out[n]['img'][None], targets[v][n]) for n in exa.ITERATION_RENDERS)
+                if graphed:
+                    out = it(a_s, a_h, a_r, cam, bg, tuple(stats))
+                else:
+                    out = exa.render_iteration(rend, a_s, a_h, a_r, (H, W), cam, bg, tuple(stats))
+                loss = sum(photo(out[n]['img'][None], targets[v][n]) for n in exa.ITERATION_RENDERS)
             loss.backward()
             params = [p for r in (scene, human, refined) for p in r.values()]
             if world > 1:

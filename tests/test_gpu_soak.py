@@ -5,7 +5,8 @@ avatar/main/model.py:279-292, avatar/common/nets/module.py:155-251).
 * ``config.mode = 'auto'`` (capacity-mode renders sized from a memo, deliberately tight so that overflows DO happen) against
   ``'exact'`` (upstream's protocol: a host round trip per render, cannot overflow): final parameters bit-identical, every
   overflow repaired (``'retried'``), no pending reports left behind, the loss goes down, P went up and down;
-* the same loop through ``GraphedIteration``: bit-identical again, one capture per change of P;
+* the same loop through ``GraphedIteration``: bit-identical again, one capture per change of P -- also with the loss recorded
+  into the graph (``loss_fn``);
 * two ranks (gloo, sharing this GPU): view-sharded, gradients through ``FlatGradAllReducer``, statistics through
   ``reduce_densify_stats``, split samples from a seed-synchronised generator: the replicas stay bit-identical.
 /root/reference is never read here."""
@@ -68,6 +69,11 @@ def test_soak_auto_and_graphed_equal_exact_bit_for_bit(dev):
     assert graphed['losses'] == exact['losses']
     n_densify = 300 // 50 - 1              # every densification replaces P and the statistics tensors: one capture each
     assert graphed['captures'] <= 1 + n_densify + graphed['retries'], (graphed['captures'], n_densify, graphed['retries'])
+    # ... and with the loss recorded into the graph (forward + loss + backward = one replay)
+    rz._seen_D.clear(); rz._verified.clear()
+    fused = _soak.run(dev, iters=300, mode='auto', graphed=True, loss_in_graph=True)
+    _same(fused['final'], exact['final'], 'graphed with the loss in the graph vs exact')
+    assert fused['losses'] == exact['losses'] and fused['p_hist'] == exact['p_hist']
     record_stats('soak', {'iters': 300, 'p_first': ph[0], 'p_max': max(ph), 'p_last': ph[-1], 'loss_first': first,
                           'loss_last': last, 'overflows_auto': len(kinds), 'captures_graphed': graphed['captures'],
                           'retries_graphed': graphed['retries'], 'ring_slots_used': (pool.next - ring0) % pool.N if pool else None})
