@@ -34,8 +34,20 @@ for k in [int(v) for v in (sys.argv[1:] or [0, 50])]:
     tt = tile[lay['part_cnt'][0]: lay['part_cnt'][0] + lay['part_cnt'][1]].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
     m = min(nslots, len(tt) // 2)
     start, end = tt[0:2 * m:2] * 0.01, tt[1:2 * m:2] * 0.01
-    nb, owner = nb[:m], owner[:m]
-    work = (owner[:, 0] != 0) & (nb > 0)
+    # the probe records by WAVE (blockIdx); since round 3 wave w takes the w-th batch of the batch-major order the sort launch
+    # left in the (dead) bucket array, and the waves past the order's end leave after one trip
+    meta = tile[128:144].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    off_bucket = a256(cap * 8) + a256(cap * 4)
+    order = binws[off_bucket: off_bucket + nslots * 4].view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
+    if meta[2] == 0xB07DE7ED:
+        n_ord = int(meta[0] + meta[1])
+        slot_of = np.where(np.arange(m) < n_ord, np.minimum(order[:m], nslots - 1), -1)
+        print('   batch-major order: %d + %d batches in the order (magic %#x)' % (meta[0], meta[1], meta[2]))
+    else:
+        slot_of = np.arange(m)
+    nb = np.where(slot_of >= 0, nb[np.maximum(slot_of, 0)], 0)
+    owner0 = np.where(slot_of >= 0, owner[np.maximum(slot_of, 0), 0], 0)
+    work = (owner0 != 0) & (nb > 0)
     t0 = start[work].min(); start = start - t0; end = end - t0
     dur = end - start
     print('view %d: capacity %d = %d batch slots (%d probed), %d with blended entries (%d entries)' % (k, cap, nslots, m, work.sum(), nb[work].sum()))
