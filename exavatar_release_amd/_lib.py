@@ -95,6 +95,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
         ('compose_geom_a', c_void_p), ('compose_P_a', ctypes.c_int32), ('compose_capacity_b', ctypes.c_uint64),
         ('dL_dcolor_indirect', c_void_p),
         ('accumulate', ctypes.c_int32),
+        ('used_slots', ctypes.c_uint32),
     ]
 
 
@@ -165,7 +166,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 133:
+    if lib.exa_raster_version() < 134:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

@@ -245,6 +245,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         r.bw = carve_bin_ws(const_cast<void*>(j.bin_ws), j.capacity);
         r.bg = s->bg; r.dL_dcolor = j.dL_dcolor; r.dL_ddepth = j.dL_ddepth; r.dL_dalpha = j.dL_dalpha;
         r.dL_dcolor_ind = j.dL_dcolor_indirect;
+        r.used_slots = j.used_slots;
         r.partials = carve_grad_ws(j.grad_ws, j.capacity);
         r.grad_first = j.grad_first;
         if (j.compose_geom_a) {                 // composite: ids of two record arrays, A constant, B (= this job's tensors) trainable

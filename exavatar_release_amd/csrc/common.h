@@ -340,6 +340,7 @@ struct RenderBwdArgs {
     const Splat* splats; TileWs tw; BinWs bw; const float* bg;
     const float* dL_dcolor; const float* dL_ddepth; const float* dL_dalpha;
     const float* const* dL_dcolor_ind;   // optional: the colour gradient's address is loaded from here at execution time
+    uint32_t used_slots;                 // batch slots the forward used (0 = capacity / 64): bounds the launch, nothing else
     PartialWs partials;
     int grad_first;        // Gaussians below this index are constants (ExaRasterBackwardJob.grad_first)
     const Splat* splats2;  // composite (PREFIX instantiation): records of source B = the trainable Gaussians (ids with SRC_B),

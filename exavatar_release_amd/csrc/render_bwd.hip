@@ -282,8 +282,8 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
     // Launch order (render_fwd.hip order_slots): wave w takes the w-th batch of the batch-major order the sort launch left
     // in the (dead) bucket array -- heavy batches first, nothing dispatched for slots without work beyond the one load of
     // the waves past the end.  Composites, the EXA_BWD_SPW variants and batched launches (K > 1 jobs: the stream of waves of
-    // several jobs balances itself, and the extra dependent load cost 2.5 % there: 8 490 -> 8 260 it/s at K = 8) keep the
-    // slot order.
+    // several jobs balances itself, and the extra dependent load cost 2.5 % there: 8 490 -> 8 260 it/s at K = 8; the three plain
+    // renders of the five-render iteration, K = 3: 0.755 -> 0.767 ms per iteration with the order) keep the slot order.
     uint32_t first_slot = wg * SPW;
     if (SPW == 1 && gridDim.y == 1) {
         const uint32_t m0 = a.tw.bwd_meta[0], m1 = a.tw.bwd_meta[1], magic = a.tw.bwd_meta[2];
@@ -439,7 +439,9 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
     uint64_t slots = 0;
     bool depth = false, prefix = false;
     for (int k = 0; k < K; ++k) {
-        slots = a[k].capacity / BATCH > slots ? a[k].capacity / BATCH : slots;
+        uint64_t mine = a[k].capacity / BATCH;                   // one wave per batch slot; the caller may know how many are in use
+        if (a[k].used_slots && a[k].used_slots < mine) mine = a[k].used_slots;
+        slots = mine > slots ? mine : slots;
         depth = depth || a[k].dL_ddepth != nullptr;
         prefix = prefix || a[k].grad_first > 0;
     }

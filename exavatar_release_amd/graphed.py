@@ -74,7 +74,7 @@ class _Captured:
     """Everything one capture owns (replaced as a whole on re-capture)."""
     __slots__ = ('key', 'inputs', 'in_list', 'in_raw', 'probes', 'tan', 'fwd', 'pool', 'outs', 'out_list', 'radii', 'bwd',
                  'slots', 'caps', 'dens_ptrs', 'sizes', 'diff_inputs', 'offsets', 'strides', 'loss', 'loss_args', 'flat',
-                 'unused', 'dens', 'dens_backup')
+                 'unused', 'dens', 'dens_backup', 'slots_c')
 
 
 class _IterFn(torch.autograd.Function):
@@ -157,6 +157,7 @@ class GraphedIteration:
         self.shape, self.device = (int(img_shape[0]), int(img_shape[1])), device
         self.merge, self.growth, self.check = bool(merge), float(capacity_growth), bool(check)
         self.loss_fn = loss_fn
+        self.tight_backward = True      # developer A/B knob: bake the batch slots in use into the backward launches (_backward)
         self._serial = 0                # number of forward replays: a backward must belong to the latest one
         self._cam = torch.zeros(38, dtype=torch.float32, device=device)   # viewmatrix 16 | projmatrix 16 | campos 3 | bg 3:
         #                                                                   outlives the captures, which read views of it
@@ -170,13 +171,14 @@ class GraphedIteration:
         self._last_needs = None         # (P_scene, P_human, needs of the three plain renders) of the last checked iteration
         self._reports_checked = True
         self.captures = 0
+        self.backward_captures = 0
         self.overflow_retries = 0
 
     # ---- capture ---------------------------------------------------------------------------------------------------
     def _release(self):
         cap, self._cap = self._cap, None
-        if cap is not None and cap.slots and rz._hdr_pool is not None:
-            for s in cap.slots:
+        if cap is not None and rz._hdr_pool is not None:
+            for s in (cap.slots or []) + (getattr(cap, 'slots_c', None) or []):
                 if s is not None:
                     rz._hdr_pool.release(s[0])
 
@@ -214,7 +216,7 @@ class GraphedIteration:
         dev = self.device
         self._release()
         cap = _Captured()
-        cap.key, cap.tan, cap.slots = key, tan, []
+        cap.key, cap.tan, cap.slots, cap.slots_c = key, tan, [], []
         cap.inputs = self._static_like(assets)
         cap.in_list = [cap.inputs[n][k] for n, a in zip(_SETS, assets) for k in _ASSET_KEYS + (_colour_key(a),)]
         # The per-iteration values are written through `.data` aliases (same storage, their own version counters): the
@@ -284,9 +286,17 @@ class GraphedIteration:
                     for k in range(n_jobs):
                         got = pool.reserve()
                         cap.slots[k] = None if got is None else (got[0], got[1])
+                # the composites report too ({slots in use, overflow}: written by the first kernel of their forward): their
+                # backward visits only the batch slots in use (ExaRasterBackwardJob.used_slots, _backward below)
+                cap.slots_c = [None, None] if self.merge else []
+                if pool is not None:
+                    for k in range(len(cap.slots_c)):
+                        got = pool.reserve()
+                        cap.slots_c[k] = None if got is None else (got[0], got[1])
                 cap.pool = torch.cuda.graph_pool_handle()
                 cap.fwd = torch.cuda.CUDAGraph()
                 rz._capture_report = cap.slots
+                rz._capture_report_c = cap.slots_c
                 if self.loss_fn is not None:
                     cap.flat = torch.zeros(sum(cap.sizes), **f32)
                     if cap.dens:
@@ -306,7 +316,7 @@ class GraphedIteration:
                             cap.unused = self._pack(grads, cap, cap.flat)
                             cap.loss = loss.detach()
                 finally:
-                    rz._capture_report = None
+                    rz._capture_report = rz._capture_report_c = None
                 cap.outs = res
                 cap.out_list = [res[k][n] for k in ITERATION_RENDERS for n in ('img', 'depthmap', 'mask')]
                 # radius / is_vis of the three plain renders: static tensors the forward kernel rewrites per replay; the
@@ -324,8 +334,9 @@ class GraphedIteration:
         self._cap = cap
         return cap
 
-    def _capture_backward(self, cap, pattern):
-        """Backward graph for the set of outputs that receive a gradient (``pattern``: 15 booleans)."""
+    def _capture_backward(self, cap, pattern, used=None):
+        """Backward graph for the set of outputs that receive a gradient (``pattern``: 15 booleans).  ``used``: None, or the
+        batch slots in use per plain job and per composite job, baked into the launches (the TIGHT graph, see _backward)."""
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         g_in = [torch.zeros_like(o) if on else None for o, on in zip(cap.out_list, pattern)]
@@ -338,6 +349,7 @@ class GraphedIteration:
             rz.config.mode, rz.config.fixed_capacity = 'capacity', list(cap.caps)
             base = self._ptr_table.data_ptr()
             rz._capture_grad_ind = {g_in[3 * i].data_ptr(): base + 8 * i for i in range(5) if g_in[3 * i] is not None}
+            rz._capture_used = used
             with torch.enable_grad():
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=cap.pool):
@@ -345,9 +357,13 @@ class GraphedIteration:
                     unused = self._pack(grads, cap, flat)
         finally:
             rz.config.mode, rz.config.fixed_capacity = saved
-            rz._capture_grad_ind = None
-        cap.bwd[pattern] = (g, g_in, flat, unused)
-        return cap.bwd[pattern]
+            rz._capture_grad_ind = rz._capture_used = None
+        self.backward_captures += 1
+        if used is None:
+            cap.bwd[pattern] = (g, g_in, flat, unused)
+            return cap.bwd[pattern]
+        cap.bwd[(pattern, 'tight')] = (g, g_in, flat, unused, used)
+        return cap.bwd[(pattern, 'tight')]
 
     @staticmethod
     def _pack(grads, cap, flat):
@@ -411,7 +427,7 @@ class GraphedIteration:
     def _reset_reports(self, cap):
         if rz._hdr_pool is not None:
             w = rz._hdr_pool.words
-            for s in cap.slots:
+            for s in cap.slots + cap.slots_c:
                 if s is not None:
                     w[4 * s[0] + 3] = 0
 
@@ -442,6 +458,18 @@ class GraphedIteration:
         n3 = needs if self.merge else [needs[0], needs[1], needs[3]]
         self._last_needs = (cap.sizes[0] // 3, cap.sizes[5] // 3, n3)
         return needs if over else None
+
+    def _slot_needs(self, cap):
+        """``num_rendered`` of every plain and composite render of the last forward replay, from their reports; None when one has
+        not landed (the host is ahead of the GPU) or reports are unavailable.  Never waits."""
+        if rz._hdr_pool is None:
+            return None
+        w, out = rz._hdr_pool.words, []
+        for s in cap.slots + cap.slots_c:
+            if s is None or w[4 * s[0] + 3] != s[1] or w[4 * s[0] + 1] != 0:
+                return None
+            out.append(int(w[4 * s[0]]))
+        return out
 
     def _device_header(self, cap, k):
         raise RuntimeError('exavatar_release_amd: GraphedIteration needs pinned host memory mapped for the device '
@@ -569,7 +597,25 @@ class GraphedIteration:
             pattern = tuple(g is not None for g in grads)
             if not any(pattern):
                 return torch.zeros(sum(cap.sizes), dtype=torch.float32, device=dev)
-            entry = cap.bwd.get(pattern) or self._capture_backward(cap, pattern)
+            # The backward blends launch one wave per 64-instance batch slot of their buffers, and those are sized with
+            # head-room (plain renders) or for both sources (composites: a fifth in use): ~100 k waves per iteration that only
+            # find out they have nothing to do (24 us of dispatch for the two composites alone).  This iteration's reports say
+            # how many slots ARE in use; a TIGHT recording of the backward with those counts (+ 25 %) baked into its launches
+            # is replayed whenever the current counts fit it, the full-size recording otherwise (reports not landed yet, or a
+            # count grew past the tight one, which is then recorded again).
+            entry = None
+            needs = self._slot_needs(cap) if self.tight_backward else None
+            if needs is not None:
+                t = cap.bwd.get((pattern, 'tight'))
+                if t is not None and all(n <= 64 * u for n, u in zip(needs, t[4][0] + t[4][1])):
+                    entry = t[:4]
+                else:
+                    prev = (t[4][0] + t[4][1]) if t is not None else [0] * len(needs)
+                    used = [max(int(n * 1.25) // 64 + 2, u) for n, u in zip(needs, prev)]
+                    n_plain = len(cap.slots)
+                    entry = self._capture_backward(cap, pattern, (used[:n_plain], used[n_plain:]))[:4]
+            if entry is None:
+                entry = cap.bwd.get(pattern) or self._capture_backward(cap, pattern)
             g, g_in, flat, _unused = entry
             with torch.no_grad():
                 # colour gradients: the graph reads them THROUGH the pointer table, so a float32 contiguous tensor from

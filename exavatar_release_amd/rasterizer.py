@@ -118,6 +118,9 @@ _pending = []     # header reports nobody has consumed yet: _Pending records
 overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
 _capture_report = None   # [(slot, tag) | None per job]: reserved header-report slots baked into the batched call being
 #                          CAPTURED (set by GraphedRenderer / GraphedIteration around their capture)
+_capture_report_c = None  # the same for the composite jobs of the call being captured (GraphedIteration)
+_capture_used = None      # (used batch slots per plain job, per composite job) baked into the backward being RECORDED
+#                           (ExaRasterBackwardJob.used_slots; GraphedIteration checks them against every replay's reports)
 _capture_grad_ind = None  # {data_ptr of a static dL/dcolor buffer: device address of its pointer-table entry}: set by
 #                           GraphedIteration while it RECORDS a backward graph (ExaRasterBackwardJob.dL_dcolor_indirect)
 _last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
@@ -336,6 +339,16 @@ class _Report:
         return int(w[b]), int(w[b + 1])
 
 
+def _landed_need(rep):
+    """``num_rendered`` of a pool-slot report that has landed and did not overflow, else None; never waits or synchronises."""
+    if rep is None or rep.event is not None or _hdr_pool is None:
+        return None
+    w, b = _hdr_pool.words, 4 * rep.slot
+    if w[b + 3] != rep.tag or w[b + 1] != 0:
+        return None
+    return int(w[b])
+
+
 class _Pending:
     """One capacity-mode call whose reports have not all been consumed: enough to re-render an overflowed job."""
     __slots__ = ('jobs', 'reports', 'store_ctx', 'device', 'done', 'backward_done', '__weakref__')
@@ -390,6 +403,7 @@ def _consume(rec, block, from_backward=False, in_forward=False):
         need, overflow = rep.values()
         rec.reports[k] = None
         _note(j.key, need)
+        j.need = need                # (the backward launches one wave per batch slot IN USE: ExaRasterBackwardJob.used_slots)
         if not overflow:
             continue
         if config.on_overflow == 'raise':
@@ -490,7 +504,7 @@ class _Job:
     """Host-side record of one render of a batch."""
     __slots__ = ('rs', 'P', 'nF', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
                  'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
-                 'gb', 'tb', 'keep_keys', 'rec', 'device', 'versions', 'is_vis', 'stash', 'token_ref')
+                 'gb', 'tb', 'keep_keys', 'rec', 'device', 'versions', 'is_vis', 'stash', 'token_ref', 'need')
 
 
 _F32 = torch.float32
@@ -642,7 +656,7 @@ class _Rasterize(torch.autograd.Function):
                 j.planes = torch.empty((5, j.H, j.W), dtype=_F32, device=device)   # colour | depth | alpha
                 j.radii = torch.empty((j.P,), dtype=torch.int32, device=device)
                 j.is_vis = torch.empty((j.P,), dtype=torch.bool, device=device)      # (one byte each: 0 / 1 from the kernel)
-                j.stash = j.token_ref = None
+                j.stash = j.token_ref = j.need = None
                 sz = _sizes(j.P, j.W, j.H, 0)
                 j.gb, j.tb = int(sz.geom_bytes), int(sz.tile_bytes)
                 j.bins = None
@@ -674,6 +688,7 @@ class _Rasterize(torch.autograd.Function):
                 hdr = (rows[0] if K == 1 else torch.stack(rows)).cpu().view(K, 4)        # D2H + sync, as upstream does
                 for k, j in enumerate(jobs):
                     j.capacity = max(int(hdr[k, 0]), 64)          # header reports whole 64-instance batch slots
+                    j.need = int(hdr[k, 0])
                     _note(j.key, int(hdr[k, 0]))
                     j.bins = torch.empty(int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes), dtype=torch.uint8, device=device)
                     j.bin_ptr = j.bins.data_ptr()
@@ -873,6 +888,9 @@ class _Rasterize(torch.autograd.Function):
                     a.densify_grad_accum, a.densify_track_cnt, a.densify_radius_max = [_addr(t) for t in dens]
                 a.grad_first = nF
                 a.accumulate = 1 if fold else 0
+                a.used_slots = (j.need + 63) // 64 if j.need else 0
+                if _capture_used is not None and k < len(_capture_used[0]):
+                    a.used_slots = int(_capture_used[0][k])
                 if config.upstream_scale_grad and d_scales is not None and float(j.rs.scale_modifier) != 1.0:
                     keep.append((d_scales, float(j.rs.scale_modifier)))
                 ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
@@ -932,6 +950,9 @@ def _compose_launch(cjobs, store_ctx, device, capturing):
             r.tile_ptr = c.tile_ptr
             a.host_header, a.header_tag = dev_addr, r.tag
             c.report = r
+        elif capturing and _capture_report_c is not None and k < len(_capture_report_c) and _capture_report_c[k] is not None:
+            a.host_header = _hdr_pool.dev_base + 16 * _capture_report_c[k][0]
+            a.header_tag = _capture_report_c[k][1]
     _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx), ctypes.c_void_p(stream_obj.cuda_stream)))
 
 
@@ -1078,6 +1099,12 @@ class _Compose(torch.autograd.Function):
                 a.dL_dsh, a.dL_dcov3D = _addr(d_sh), _addr(d_cov)
                 a.grad_first = 0
                 a.compose_geom_a, a.compose_P_a, a.compose_capacity_b = ja.geom_ptr, ja.P, jb.capacity
+                # the composite's packed lists fill a fraction of its buffer (sized for both sources): its own report, written
+                # by the first kernel of its forward, says how many batch slots the backward has to visit
+                need_c = _landed_need(c.report)
+                a.used_slots = (need_c + 63) // 64 if need_c else 0
+                if _capture_used is not None and k < len(_capture_used[1]):
+                    a.used_slots = int(_capture_used[1][k])
                 me = (id(ctx), k)
                 if ctx.fold and (jb.stash is None or jb.stash[0] == me):
                     # leave them with B's job: B's own backward runs after this one (the token orders it) and adds its

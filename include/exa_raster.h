@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 133          /* 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 134          /* 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -243,6 +243,14 @@ typedef struct ExaRasterBackwardJob {
      * own to them: out = held + this render's, one read more per value and no separate summation pass.  dL_dmeans2D is
      * per render and always overwritten.  Not combinable with sum_shared. */
     int32_t accumulate;
+    /* Optional (0 = capacity / 64): how many 64-instance batch slots of the instance buffer the forward call actually used =
+     * ceil(header.num_rendered / 64), which a caller that has seen the header (or its zero-copy report) knows by now.  The
+     * backward blend launches one wave per batch slot; with a buffer sized generously (capacity = 1.5 x an earlier need, or
+     * capacity_a + capacity_b for a composite, whose packed lists typically fill a fifth of that) most of those waves only
+     * find out that their slot is past the end -- tens of thousands of dispatches (~0.24 ns each chip-wide, 24 us per
+     * five-render iteration for the two composites).  A value below the true count would skip batches: pass only what the
+     * header of THIS forward call said. */
+    uint32_t used_slots;
 } ExaRasterBackwardJob;
 
 /* Stores `n` (<= 16) pointers into `table` (device memory) with one tiny kernel, in stream order. */

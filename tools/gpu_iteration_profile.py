@@ -23,6 +23,10 @@ if how == 'graphed_loss':       # the same loss recorded into the graph: forward
     graphed = exa.GraphedIteration((H, W), dev, loss_fn=lambda out, G_: sum((out[k]['img'] * G_).sum() for k in exa.ITERATION_RENDERS))
 
 
+if graphed is not None:
+    graphed.tight_backward = os.environ.get('EXA_TIGHT', '1') != '0'      # A/B knob
+
+
 def iteration():
     if how == 'graphed_loss':
         for t in (scene, human, refined):
