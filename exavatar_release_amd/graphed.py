@@ -459,17 +459,28 @@ class GraphedIteration:
         self._last_needs = (cap.sizes[0] // 3, cap.sizes[5] // 3, n3)
         return needs if over else None
 
-    def _slot_needs(self, cap):
+    def _slot_needs(self, cap, patience=2.5e-4):
         """``num_rendered`` of every plain and composite render of the last forward replay, from their reports; None when one has
-        not landed (the host is ahead of the GPU) or reports are unavailable.  Never waits."""
+        not landed or reports are unavailable.  Waits at most ``patience`` seconds: the composites report ~0.15 ms into the forward
+        graph, and a caller that reaches its backward sooner (no loss kernels in between) loses nothing by spinning that long --
+        the backward graph could not start before the forward graph is through anyway."""
         if rz._hdr_pool is None:
             return None
-        w, out = rz._hdr_pool.words, []
-        for s in cap.slots + cap.slots_c:
-            if s is None or w[4 * s[0] + 3] != s[1] or w[4 * s[0] + 1] != 0:
-                return None
-            out.append(int(w[4 * s[0]]))
-        return out
+        w = rz._hdr_pool.words
+        slots = cap.slots + cap.slots_c
+        if any(s is None for s in slots):
+            return None
+        t_end = None
+        for s in slots:
+            i = 4 * s[0] + 3
+            while w[i] != s[1]:
+                if t_end is None:
+                    t_end = time.perf_counter() + patience
+                elif time.perf_counter() > t_end:
+                    return None
+        if any(w[4 * s[0] + 1] != 0 for s in slots):
+            return None
+        return [int(w[4 * s[0]]) for s in slots]
 
     def _device_header(self, cap, k):
         raise RuntimeError('exavatar_release_amd: GraphedIteration needs pinned host memory mapped for the device '
