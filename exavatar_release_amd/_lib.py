@@ -99,6 +99,8 @@ class ExaRasterBackwardJob(ctypes.Structure):
     ]
 
 
+STORE_CTX, STAGE_NO_BLEND, STAGE_BLEND_ONLY = 1, 2, 4       # bits of `store_ctx` (include/exa_raster.h, EXA_RASTER_STAGE_*)
+
 # symbol -> (restype, argtypes); must list every function include/exa_raster.h declares
 _I32 = ctypes.c_int32
 _U64 = ctypes.c_uint64
@@ -166,7 +168,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 134:
+    if lib.exa_raster_version() < 135:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

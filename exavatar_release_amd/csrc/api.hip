@@ -183,6 +183,11 @@ int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st, bo
     return 0;
 }
 
+// `store_ctx` of the batched forward calls: bit 0 = keep the backward context; the stage bits split a call in two so that a
+// caller can put other work between the sorted lists and the blend (include/exa_raster.h, EXA_RASTER_STAGE_*)
+inline bool stage_lists(int store_ctx) { return !(store_ctx & EXA_RASTER_STAGE_BLEND_ONLY); }
+inline bool stage_blend(int store_ctx) { return !(store_ctx & EXA_RASTER_STAGE_NO_BLEND); }
+
 int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, hipStream_t st, bool merged = false) {
     BinArgs ba[MAX_BATCH];
     RenderFwdArgs ra[MAX_BATCH];
@@ -194,20 +199,24 @@ int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, 
         RenderFwdArgs& r = ra[k];
         r.grid = ba[k].grid; r.splats = ba[k].splats; r.tw = ba[k].tw; r.bw = ba[k].bw; r.capacity = j.capacity;
         r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
-        r.store_ctx = store_ctx;
+        r.store_ctx = store_ctx & 1;
         r.keep_sorted_keys = j.keep_sorted_keys; r.splats2 = nullptr;
         r.src_color = r.src_depth = r.src_alpha = r.src_bg = nullptr;
     }
     int rc;
-    // (cell_scatter_kernel also clears the zero-filled section of the bin workspace: batch owners, blended masks, touched bytes)
-    EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(ba, K, st), "cell_scatter");
-    if ((rc = debug_sync(s0, st, "cell_scatter"))) return rc;
-    EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(ba, K, st), "subtile_bin");
-    if ((rc = debug_sync(s0, st, "subtile_bin"))) return rc;
-    EXA_TIMED(K_SORT, launch_sort_subtiles(ra, K, st), "sort_subtiles");
-    if ((rc = debug_sync(s0, st, "sort_subtiles"))) return rc;
-    EXA_TIMED(K_RENDER_FWD, launch_render_fwd(ra, K, st), "render_fwd");
-    if ((rc = debug_sync(s0, st, "render_fwd"))) return rc;
+    if (stage_lists(store_ctx)) {
+        // (cell_scatter_kernel also clears the zero-filled section of the bin workspace: batch owners, blended masks, touched bytes)
+        EXA_TIMED(K_CELL_SCATTER, launch_cell_scatter(ba, K, st), "cell_scatter");
+        if ((rc = debug_sync(s0, st, "cell_scatter"))) return rc;
+        EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(ba, K, st), "subtile_bin");
+        if ((rc = debug_sync(s0, st, "subtile_bin"))) return rc;
+        EXA_TIMED(K_SORT, launch_sort_subtiles(ra, K, st), "sort_subtiles");
+        if ((rc = debug_sync(s0, st, "sort_subtiles"))) return rc;
+    }
+    if (stage_blend(store_ctx)) {
+        EXA_TIMED(K_RENDER_FWD, launch_render_fwd(ra, K, st), "render_fwd");
+        if ((rc = debug_sync(s0, st, "render_fwd"))) return rc;
+    }
     return 0;
 }
 
@@ -228,7 +237,7 @@ int check_backward_job(const ExaRasterBackwardJob& j) {
     return 0;
 }
 
-int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int dens_shared, hipStream_t st) {
+int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int dens_shared, hipStream_t st, int stage = 0) {
     RenderBwdArgs ra[MAX_BATCH];
     PreprocessBwdArgs pa[MAX_BATCH];
     const ExaRasterSettings* s0 = jobs[0].settings;
@@ -276,10 +285,14 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
     }
     if (n == 0) return 0;
     int rc;
-    EXA_TIMED(K_RENDER_BWD, launch_render_bwd(ra, n, st), "render_bwd");
-    if ((rc = debug_sync(s0, st, "render_bwd"))) return rc;
-    EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(pa, n, sum_shared, dens_shared, st), "preprocess_bwd");
-    if ((rc = debug_sync(s0, st, "preprocess_bwd"))) return rc;
+    if (!(stage & EXA_RASTER_STAGE_NO_BLEND)) {          // (as in the forward: NO_BLEND skips the blend's backward ...)
+        EXA_TIMED(K_RENDER_BWD, launch_render_bwd(ra, n, st), "render_bwd");
+        if ((rc = debug_sync(s0, st, "render_bwd"))) return rc;
+    }
+    if (!(stage & EXA_RASTER_STAGE_BLEND_ONLY)) {      // (... BLEND_ONLY = stop before the per-Gaussian chain rule)
+        EXA_TIMED(K_PREPROCESS_BWD, launch_preprocess_bwd(pa, n, sum_shared, dens_shared, st), "preprocess_bwd");
+        if ((rc = debug_sync(s0, st, "preprocess_bwd"))) return rc;
+    }
     return 0;
 }
 
@@ -325,7 +338,7 @@ int exa_raster_forward_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t
     for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
         const int n = K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH;
         const bool merged = can_merge_scans(jobs + k0, n);
-        int rc = forward_bin_group(jobs + k0, n, st, merged);
+        int rc = stage_lists(store_ctx) ? forward_bin_group(jobs + k0, n, st, merged) : 0;
         if (rc) return rc;
         rc = forward_render_group(jobs + k0, n, store_ctx, st, merged);
         if (rc) return rc;
@@ -333,7 +346,8 @@ int exa_raster_forward_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t
     return 0;
 }
 
-int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32_t sum_shared, void* stream) {
+int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32_t flags, void* stream) {
+    const int32_t sum_shared = flags & 1, stage = flags & (EXA_RASTER_STAGE_NO_BLEND | EXA_RASTER_STAGE_BLEND_ONLY);
     if (K < 0 || (K > 0 && !jobs)) return fail(EXA_RASTER_E_INVALID, "bad job list");
     for (int k = 0; k < K; ++k) {
         const int rc = check_backward_job(jobs[k]);
@@ -380,7 +394,7 @@ int exa_raster_backward_batch(const ExaRasterBackwardJob* jobs, int32_t K, int32
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
-        const int rc = backward_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, sum_shared, dens_shared, st);
+        const int rc = backward_group(jobs + k0, K - k0 < MAX_BATCH ? K - k0 : MAX_BATCH, sum_shared, dens_shared, st, stage);
         if (rc) return rc;
     }
     return 0;
@@ -500,14 +514,18 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
             r.grid = g; r.splats = static_cast<const Splat*>(j.geom_a); r.splats2 = static_cast<const Splat*>(j.geom_b);
             r.tw = c.tw; r.bw = c.bw; r.capacity = j.capacity;
             r.bg = j.settings->bg; r.out_color = j.out_color; r.out_depth = j.out_depth; r.out_alpha = j.out_alpha;
-            r.store_ctx = store_ctx; r.keep_sorted_keys = 0;
+            r.store_ctx = store_ctx & 1; r.keep_sorted_keys = 0;
             r.src_color = j.a_color; r.src_depth = j.a_depth; r.src_alpha = j.a_alpha; r.src_bg = j.a_bg;
         }
         int rc;
-        EXA_TIMED(K_CELL_SCATTER, launch_compose(ca, n, st), "compose");
-        if ((rc = debug_sync(jobs[k0].settings, st, "compose"))) return rc;
-        EXA_TIMED(K_RENDER_FWD, launch_render_fwd(ra, n, st), "render_fwd (composite)");
-        if ((rc = debug_sync(jobs[k0].settings, st, "render_fwd (composite)"))) return rc;
+        if (stage_lists(store_ctx)) {
+            EXA_TIMED(K_CELL_SCATTER, launch_compose(ca, n, st), "compose");
+            if ((rc = debug_sync(jobs[k0].settings, st, "compose"))) return rc;
+        }
+        if (stage_blend(store_ctx)) {
+            EXA_TIMED(K_RENDER_FWD, launch_render_fwd(ra, n, st), "render_fwd (composite)");
+            if ((rc = debug_sync(jobs[k0].settings, st, "render_fwd (composite)"))) return rc;
+        }
     }
     return 0;
 }

@@ -343,7 +343,6 @@ class GraphedIteration:
         outs = [o for o, on in zip(cap.out_list, pattern) if on]
         gos = [g for g in g_in if g is not None]
         inputs = cap.in_list + cap.probes
-        flat = torch.zeros(sum(cap.sizes), **f32)
         saved = (rz.config.mode, rz.config.fixed_capacity)
         try:
             rz.config.mode, rz.config.fixed_capacity = 'capacity', list(cap.caps)
@@ -354,7 +353,11 @@ class GraphedIteration:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=cap.pool):
                     grads = torch.autograd.grad(outs, inputs, grad_outputs=gos, allow_unused=True, retain_graph=True)
-                    unused = self._pack(grads, cap, flat)
+                # The gradients stay where the recording left them (static tensors of the graph's pool); _backward gathers
+                # them into a fresh private buffer with ONE concatenation kernel after the replay -- packing inside the graph
+                # AND cloning the packed buffer afterwards moved the 14 MB twice.
+                unused = [gr is None for gr in grads]
+                flat = [None if gr is None else gr.reshape(-1) for gr in grads]
         finally:
             rz.config.mode, rz.config.fixed_capacity = saved
             rz._capture_grad_ind = rz._capture_used = None
@@ -649,4 +652,10 @@ class GraphedIteration:
                 _lib.check(_lib.load().exa_raster_store_pointers(
                     ctypes.c_void_p(self._ptr_table.data_ptr()), ptrs, 5, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
             g.replay()
-            return flat.clone()
+            with torch.no_grad():
+                if not any(v is None for v in flat):
+                    return torch.cat(flat)
+                out = torch.zeros(sum(cap.sizes), dtype=torch.float32, device=dev)
+                views = [torch.as_strided(out, (n,), (1,), o) for v, n, o in zip(flat, cap.sizes, cap.offsets) if v is not None]
+                torch._foreach_copy_(views, [v for v in flat if v is not None])
+                return out

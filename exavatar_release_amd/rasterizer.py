@@ -101,6 +101,9 @@ class _Config:
     overflow_check = 'forward'    # 'forward' | 'always' | 'adaptive': where the header report is looked at (module docstring)
     verify_calls = 4          # adaptive: the first calls of a shape wait for their report
     danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
+    overlap_composites = True     # INSIDE a stream capture: the composites' list merges run on a second stream while their sources
+    #                               blend (the calls are split at EXA_RASTER_STAGE_NO_BLEND; fork / join become graph edges).
+    #                               Eager calls never do this: the stream switches cost the host more than the overlap gives
     fold_composite_grads = True   # a composite's gradients for source B are handed to B's own render, whose backward adds them
     #                               inside its per-Gaussian kernel (ExaRasterBackwardJob.accumulate) instead of autograd
     #                               summing the two with one kernel per tensor (developer A/B knob; same values bit for bit)
@@ -118,6 +121,8 @@ _pending = []     # header reports nobody has consumed yet: _Pending records
 overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
 _capture_report = None   # [(slot, tag) | None per job]: reserved header-report slots baked into the batched call being
 #                          CAPTURED (set by GraphedRenderer / GraphedIteration around their capture)
+_overlap = {}             # device index -> (side stream, event recorded when the sources' sorted lists are complete): set by a
+#                           captured keep_keys batch, consumed by the composite call that follows it (config.overlap_composites)
 _capture_report_c = None  # the same for the composite jobs of the call being captured (GraphedIteration)
 _capture_used = None      # (used batch slots per plain job, per composite job) baked into the backward being RECORDED
 #                           (ExaRasterBackwardJob.used_slots; GraphedIteration checks them against every replay's reports)
@@ -695,7 +700,17 @@ class _Rasterize(torch.autograd.Function):
                     arr[k].bin_ws, arr[k].capacity = j.bin_ptr, j.capacity
                 _lib.check(lib.exa_raster_forward_render_batch(arr, K, int(need_ctx), stream))
             else:
-                _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
+                if capturing and keep_keys and config.overlap_composites:
+                    # lists first, an event, then the blend: the composites that follow merge these lists on a side stream
+                    # while this blend runs (_Compose.forward)
+                    _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx) | _lib.STAGE_NO_BLEND, stream))
+                    ev = torch.cuda.Event()
+                    ev.record(stream_obj)
+                    _overlap[device.index] = ev
+                    _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx) | _lib.STAGE_BLEND_ONLY, stream))
+                else:
+                    _overlap.pop(device.index, None)
+                    _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
                 if reports is not None:
                     if reports[0].event is not None:             # fallback: 16-byte read-backs + one event
                         hp = reports[0].host.data_ptr()
@@ -786,7 +801,7 @@ class _Rasterize(torch.autograd.Function):
             dead = [False] * K
         n_live = K - sum(dead)
         arr = (_lib.ExaRasterBackwardJob * max(n_live, 1))()
-        keep, ret, late, pos = [], [None, None, None, None, None, None, None], [], 0
+        keep, ret, late, pos, sides = [], [None, None, None, None, None, None, None], [], 0, set()
         rec = ctx.rec
         with _on_device(device):
             if rec is not None and not rec.done:
@@ -817,6 +832,8 @@ class _Rasterize(torch.autograd.Function):
                 g_color, g_depth, g_alpha = grads[4 * k], grads[4 * k + 2], grads[4 * k + 3]
                 if dead[k]:
                     st, j.stash = j.stash, None
+                    if st is not None and len(st) > 3:
+                        sides.add(st[3])
                     if st is None:
                         ret += [None] * N_IN
                     else:                              # only the composites of this render were differentiated
@@ -841,6 +858,8 @@ class _Rasterize(torch.autograd.Function):
                 want_sh = own and has_sh and nd[2]
                 # gradients a composite render left for these Gaussians (_Compose.backward): this call adds its own to them
                 st, j.stash = j.stash, None
+                if st is not None and len(st) > 3:
+                    sides.add(st[3])              # (recorded on a side stream inside a capture: joined before it is read)
                 fold = st is not None and not ctx.shared and nF == 0 and \
                     st[1] == _grad_pattern(want[0][0], want_sh, want[2][0], want[3][0], want[4][0], want[5][0], want[6][0])
                 if fold:
@@ -894,7 +913,17 @@ class _Rasterize(torch.autograd.Function):
                 if config.upstream_scale_grad and d_scales is not None and float(j.rs.scale_modifier) != 1.0:
                     keep.append((d_scales, float(j.rs.scale_modifier)))
                 ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
-            if n_live:
+            if sides:
+                # a composite's backward runs on a side stream (config.overlap_composites, inside a capture): this batch's
+                # blend backward overlaps it, the join comes before the chain rule that adds to the composite's gradients
+                main = torch.cuda.current_stream(device)
+                if n_live:
+                    _lib.check(lib.exa_raster_backward_batch(arr, n_live, int(ctx.shared) | _lib.STAGE_BLEND_ONLY, _stream_ptr(device)))
+                for side in sides:
+                    main.wait_stream(side)
+                if n_live:
+                    _lib.check(lib.exa_raster_backward_batch(arr, n_live, int(ctx.shared) | _lib.STAGE_NO_BLEND, _stream_ptr(device)))
+            elif n_live:
                 _lib.check(lib.exa_raster_backward_batch(arr, n_live, int(ctx.shared), _stream_ptr(device)))
             for item in keep:
                 if isinstance(item, tuple):        # upstream's dL/dscale quirk: gradient w.r.t. (modifier * scale)
@@ -910,8 +939,13 @@ class _CJob:
                  'src_ptrs', 'report', 'key')
 
 
-def _compose_launch(cjobs, store_ctx, device, capturing):
-    """(Re-)run the forward of the composite jobs against the CURRENT workspaces of their sources."""
+_side_streams = {}
+
+
+def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
+    """(Re-)run the forward of the composite jobs against the CURRENT workspaces of their sources.  ``sorted_event`` (inside a
+    stream capture): recorded when the sources' sorted lists were complete, BEFORE their blend was queued -- ranges and list
+    merges then run on a side stream concurrently with that blend, and the composites' own blend follows the join."""
     lib = _lib.load()
     K = len(cjobs)
     arr = (_lib.ExaRasterComposeJob * K)()
@@ -953,7 +987,17 @@ def _compose_launch(cjobs, store_ctx, device, capturing):
         elif capturing and _capture_report_c is not None and k < len(_capture_report_c) and _capture_report_c[k] is not None:
             a.host_header = _hdr_pool.dev_base + 16 * _capture_report_c[k][0]
             a.header_tag = _capture_report_c[k][1]
-    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx), ctypes.c_void_p(stream_obj.cuda_stream)))
+    if sorted_event is None:
+        _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx), ctypes.c_void_p(stream_obj.cuda_stream)))
+        return
+    side = _side_streams.get(device.index)
+    if side is None:
+        side = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    side.wait_event(sorted_event)
+    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_NO_BLEND, ctypes.c_void_p(side.cuda_stream)))
+    stream_obj.wait_stream(side)
+    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_BLEND_ONLY,
+                                                    ctypes.c_void_p(stream_obj.cuda_stream)))
 
 
 class _Compose(torch.autograd.Function):
@@ -998,7 +1042,8 @@ class _Compose(torch.autograd.Function):
                 c.radii = torch.cat((ja.radii, jb.radii)) if want_radii else None
                 c.key = ('compose', device.index, ja.P, jb.P, ja.H, ja.W)
                 cjobs.append(c)
-            _compose_launch(cjobs, need_ctx, device, capturing)
+            _compose_launch(cjobs, need_ctx, device, capturing,
+                            _overlap.pop(device.index, None) if capturing and config.overlap_composites else None)
         ctx.need_ctx = need_ctx
         outs = []
         for c in cjobs:
@@ -1057,6 +1102,11 @@ class _Compose(torch.autograd.Function):
                     redo = True
             if redo:
                 _compose_launch(cjobs, True, device, False)
+            side, n_stashed = None, 0
+            if ctx.fold and config.overlap_composites and torch.cuda.is_current_stream_capturing():
+                side = _side_streams.get(device.index)
+                if side is None:
+                    side = _side_streams[device.index] = torch.cuda.Stream(device=device)
             for k, c in enumerate(cjobs):
                 ja, jb = c.a, c.b
                 P, H, W, sh_M = jb.P, jb.H, jb.W, jb.sh_M
@@ -1111,13 +1161,27 @@ class _Compose(torch.autograd.Function):
                     # gradients to these buffers inside its per-Gaussian kernel, then returns them as the tensors' gradients
                     jb.stash = (me, _grad_pattern(nd[0], d_sh is not None, has_col and nd[3], nd[4], has_sc and nd[5],
                                                   has_rot and nd[6], has_cov and nd[7]),
-                                (d_means3D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov))
+                                (d_means3D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov)) + ((side,) if side is not None else ())
+                    n_stashed += 1
                     ret += [None, d_means2D, None, None, None, None, None, None]
                     if ret[5] is None:
                         ret[5] = torch.empty(0, dtype=_F32, device=device)
                 else:
                     ret += [d_means3D, d_means2D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov]
-            _lib.check(lib.exa_raster_backward_batch(arr, K, 0, _stream_ptr(device)))
+            if side is not None and n_stashed == K:
+                # every gradient of this call travels through the sources' own backward, which joins the side stream before
+                # it reads them: this whole backward overlaps the sources' blend backward (graph edges inside the capture)
+                side.wait_stream(torch.cuda.current_stream(device))
+                for t in keep:                    # scratch + incoming gradients: allocated on this stream, read on the other --
+                    if torch.is_tensor(t):        # their memory must not be handed out again before the join
+                        t.record_stream(side)
+                _lib.check(lib.exa_raster_backward_batch(arr, K, 0, ctypes.c_void_p(side.cuda_stream)))
+            else:
+                _lib.check(lib.exa_raster_backward_batch(arr, K, 0, _stream_ptr(device)))
+                if side is not None:              # (not all folded: nobody downstream would join the side stream)
+                    for c in cjobs:
+                        if c.b.stash is not None and len(c.b.stash) > 3:
+                            c.b.stash = c.b.stash[:3]
         return tuple(ret)
 
 

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 134          /* 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 135          /* 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -286,6 +286,20 @@ typedef struct ExaRasterComposeJob {
 /* tile_bytes / bin_bytes of a composite's workspaces, grad_bytes of its backward scratch (geom_bytes = 0) */
 int exa_raster_compose_sizes(int32_t W, int32_t H, uint64_t capacity, uint64_t capacity_b, ExaRasterWorkspaceSizes* out);
 int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K, int32_t store_ctx, void* stream);
+
+/* `store_ctx` of exa_raster_forward_batch / exa_raster_forward_render_batch / exa_raster_forward_compose_batch: bit 0 = keep the
+ * backward context (any caller that passes 0 / 1 is unaffected); the two stage bits split one call into two calls with the
+ * SAME job array, so that the caller can put other work between the sorted lists and the blend -- e.g. run the list merges of
+ * composite renders (which need their sources' sorted lists, not their images) on a second stream while the sources blend:
+ *   ..._STAGE_NO_BLEND    everything up to the sorted per-sub-tile lists (composite: ranges + merged lists), no blend
+ *   ..._STAGE_BLEND_ONLY  only the blend, on the lists an earlier NO_BLEND call with these jobs left in the workspaces
+ * exa_raster_backward_batch takes the same two bits in its `sum_shared` argument (bit 0 = sum_shared): BLEND_ONLY = the blend's
+ * backward (per-instance partial sums) without the per-Gaussian chain rule, NO_BLEND = only the chain rule, on the partial sums
+ * an earlier BLEND_ONLY call with these jobs left in grad_ws -- e.g. to let the blend's backward of one batch overlap another
+ * batch's on a second stream before a chain rule that adds to that batch's outputs (`accumulate`). */
+#define EXA_RASTER_STORE_CTX        1
+#define EXA_RASTER_STAGE_NO_BLEND   2
+#define EXA_RASTER_STAGE_BLEND_ONLY 4
 
 int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream);
 int exa_raster_forward_render_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);

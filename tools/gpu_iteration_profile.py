@@ -52,6 +52,7 @@ def iteration():
 
 
 exa.config.fold_composite_grads = os.environ.get('EXA_FOLD', '1') != '0'      # A/B knob
+exa.config.overlap_composites = os.environ.get('EXA_OVERLAP', '1') != '0'    # A/B knob
 exa.config.mode = 'exact'
 for _ in range(2):
     iteration()
