@@ -52,7 +52,9 @@ with open(os.path.join(out, prefix + '_iteration.md'), 'w') as f:
             'iteration).  Round 4: composites copy the scene render\'s pixels where the human has no entry; the backward reads dL/dimg\n'
             'through a pointer table; `is_vis` comes from the forward kernel, the composites\' `radius` / `is_vis` are built on first access\n'
             '(no comparison / concatenation kernels); a composite\'s gradients for the human are added inside the per-Gaussian kernel of\n'
-            'the human\'s own render (no `add` kernels from autograd).\n\n')
+            'the human\'s own render (no `add` kernels from autograd); backward launches bounded by the batch slots in use; inside the\n'
+            'captured graphs the composites\' list merges and backward run on a side stream next to their sources\' blend (so the kernel\n'
+            'times below overlap and add up to more than the iteration).\n\n')
     f.write('Sum of calls x average per iteration: GraphedIteration %s; eager %s (us).\n\n'
             % (', '.join('%s %.0f' % kv for kv in sorted(g_sum.items())), ', '.join('%s %.0f' % kv for kv in sorted(s_sum.items()))))
     f.write('## `extra_exavatar_iteration` of the bench line of this run (ms per iteration, median of three windows)\n\n')
