@@ -63,6 +63,7 @@ they were modified in place in between (``optimizer.step()``), the corrected ima
 values, and the ``RuntimeWarning`` says so.
 """
 import ctypes
+import os
 import threading
 import time
 import warnings
@@ -128,6 +129,7 @@ _capture_used = None      # (used batch slots per plain job, per composite job) 
 #                           (ExaRasterBackwardJob.used_slots; GraphedIteration checks them against every replay's reports)
 _capture_grad_ind = None  # {data_ptr of a static dL/dcolor buffer: device address of its pointer-table entry}: set by
 #                           GraphedIteration while it RECORDS a backward graph (ExaRasterBackwardJob.dL_dcolor_indirect)
+_COMPOSE_CAP_SCALE = float(os.environ['EXA_COMPOSE_CAP_SCALE']) if 'EXA_COMPOSE_CAP_SCALE' in os.environ else None   # developer knob
 _last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
 _tls = threading.local()  # .is_vis: the `radii > 0` tensors the per-Gaussian kernel of the most recent call of this thread wrote
 #                           (ExaRasterForwardJob.is_vis), picked up by the renderer's output dict via take_is_vis()
@@ -954,6 +956,8 @@ def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
     for k, c in enumerate(cjobs):
         ja, jb = c.a, c.b
         c.capacity = ja.capacity + jb.capacity
+        if _COMPOSE_CAP_SCALE is not None:     # developer knob (tools/gpu_r04_o.sh): a composite buffer smaller than the sum
+            c.capacity = max(64, int(c.capacity * _COMPOSE_CAP_SCALE) // 64 * 64)
         sz = _lib.ExaRasterWorkspaceSizes()
         _lib.check(lib.exa_raster_compose_sizes(c.rs.image_width, c.rs.image_height, c.capacity, jb.capacity, ctypes.byref(sz)))
         c.tb = int(sz.tile_bytes)
