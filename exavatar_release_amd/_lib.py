@@ -99,7 +99,7 @@ class ExaRasterBackwardJob(ctypes.Structure):
     ]
 
 
-STORE_CTX, STAGE_NO_BLEND, STAGE_BLEND_ONLY = 1, 2, 4       # bits of `store_ctx` (include/exa_raster.h, EXA_RASTER_STAGE_*)
+STORE_CTX, STAGE_NO_BLEND, STAGE_BLEND_ONLY, STAGE_NO_SORT, STAGE_SORT_ONLY = 1, 2, 4, 8, 16       # bits of `store_ctx` (include/exa_raster.h, EXA_RASTER_STAGE_*)
 
 # symbol -> (restype, argtypes); must list every function include/exa_raster.h declares
 _I32 = ctypes.c_int32

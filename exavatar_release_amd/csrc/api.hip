@@ -185,8 +185,9 @@ int forward_bin_group(const ExaRasterForwardJob* jobs, int K, hipStream_t st, bo
 
 // `store_ctx` of the batched forward calls: bit 0 = keep the backward context; the stage bits split a call in two so that a
 // caller can put other work between the sorted lists and the blend (include/exa_raster.h, EXA_RASTER_STAGE_*)
-inline bool stage_lists(int store_ctx) { return !(store_ctx & EXA_RASTER_STAGE_BLEND_ONLY); }
-inline bool stage_blend(int store_ctx) { return !(store_ctx & EXA_RASTER_STAGE_NO_BLEND); }
+inline bool stage_lists(int f) { return !(f & (EXA_RASTER_STAGE_BLEND_ONLY | EXA_RASTER_STAGE_SORT_ONLY)); }                // up to the unsorted lists
+inline bool stage_sort(int f) { return !(f & (EXA_RASTER_STAGE_BLEND_ONLY | EXA_RASTER_STAGE_NO_SORT)); }
+inline bool stage_blend(int f) { return !(f & (EXA_RASTER_STAGE_NO_BLEND | EXA_RASTER_STAGE_NO_SORT | EXA_RASTER_STAGE_SORT_ONLY)); }
 
 int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, hipStream_t st, bool merged = false) {
     BinArgs ba[MAX_BATCH];
@@ -210,6 +211,8 @@ int forward_render_group(const ExaRasterForwardJob* jobs, int K, int store_ctx, 
         if ((rc = debug_sync(s0, st, "cell_scatter"))) return rc;
         EXA_TIMED(K_SUBTILE_BIN, launch_subtile_bin(ba, K, st), "subtile_bin");
         if ((rc = debug_sync(s0, st, "subtile_bin"))) return rc;
+    }
+    if (stage_sort(store_ctx)) {
         EXA_TIMED(K_SORT, launch_sort_subtiles(ra, K, st), "sort_subtiles");
         if ((rc = debug_sync(s0, st, "sort_subtiles"))) return rc;
     }
@@ -518,8 +521,9 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
             r.src_color = j.a_color; r.src_depth = j.a_depth; r.src_alpha = j.a_alpha; r.src_bg = j.a_bg;
         }
         int rc;
-        if (stage_lists(store_ctx)) {
-            EXA_TIMED(K_CELL_SCATTER, launch_compose(ca, n, st), "compose");
+        const int parts = (stage_lists(store_ctx) ? 1 : 0) | (stage_sort(store_ctx) ? 2 : 0);
+        if (parts) {
+            EXA_TIMED(K_CELL_SCATTER, launch_compose(ca, n, st, parts), "compose");
             if ((rc = debug_sync(jobs[k0].settings, st, "compose"))) return rc;
         }
         if (stage_blend(store_ctx)) {

@@ -313,7 +313,7 @@ struct ComposeArgs {
     uint32_t* host_hdr; uint32_t hdr_tag;
     const float* src_color; const float* src_bg; const float* bg;    // see RenderFwdArgs.src_color
 };
-hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s);
+hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s, int parts = 3);
 // bin workspace of a composite: merged ids [cap] | zero-filled: owner [cap / 64 + 1], blended mask [cap / 64 + 1], touched
 // [capacity_b] (B's Gaussian-major instance numbering) | checkpoints [cap / 64 + 1][5][64]
 __host__ __device__ inline uint64_t compose_zero_bytes(uint64_t cap, uint64_t cap_b) {

@@ -44,13 +44,7 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         uint4* p = a.bw.owner;
         const size_t first = (size_t)((int)blockIdx.x - 1) * CBLOCK + tid, stride = (size_t)C_ZERO_WGS * CBLOCK;
         for (size_t i = first; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
-        // ---- launch order of the blend (heavy lists first, common.h): the order of the source with more instances.  In
-        // ExAvatar's composites that is the scene, whose lists dominate the merged ones; a histogram of the exact merged
-        // lengths cost a 27-88 us single-workgroup pass (two variants measured) for a launch that queues ~16 waves per SIMD
-        // anyway.  The records carry the sub-tile only: the blend reads its range from tw.ranges.
-        const uint4* __restrict__ src = a.tw_a.header->num_instances >= a.tw_b.header->num_instances ? a.tw_a.slots : a.tw_b.slots;
-        for (size_t i = first; i < (size_t)subtiles; i += stride) a.tw.slots[i] = make_uint4(0u, 0u, src[i].z, 0u);
-        return;
+        return;                                                  // (the launch order of the blend: merge_kernel writes it)
     }
     const uint2* __restrict__ ra = a.tw_a.ranges;
     const uint2* __restrict__ rb = a.tw_b.ranges;
@@ -147,6 +141,16 @@ __global__ __launch_bounds__(MBLOCK) void merge_kernel(Batch<ComposeArgs> batch)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int st = (int)blockIdx.x * (MBLOCK / 64) + wave;
     if (st >= a.grid.subtiles) return;
+    // ---- launch order of the blend (heavy lists first, common.h): the order of the source with more instances.  In
+    // ExAvatar's composites that is the scene, whose lists dominate the merged ones; a histogram of the exact merged
+    // lengths cost a 27-88 us single-workgroup pass (two variants measured) for a launch that queues ~16 waves per SIMD
+    // anyway.  The records carry the sub-tile only: the blend reads its range from tw.ranges.  Written HERE (record number
+    // `st` by the wave of sub-tile `st`) and not by compose_kernel, because the sources' order is a product of their SORT
+    // launch, which compose_kernel need not wait for (EXA_RASTER_STAGE_NO_SORT).
+    if (lane == 0) {
+        const uint4* __restrict__ src = a.tw_a.header->num_instances >= a.tw_b.header->num_instances ? a.tw_a.slots : a.tw_b.slots;
+        a.tw.slots[st] = make_uint4(0u, 0u, src[st].z, 0u);
+    }
     const uint2 rc = a.tw.ranges[st];
     const int n = (int)(rc.y - rc.x);
     if (n == 0) return;                                          // empty list (or overflow: every range is empty)
@@ -188,13 +192,14 @@ __global__ __launch_bounds__(MBLOCK) void merge_kernel(Batch<ComposeArgs> batch)
     }
 }
 
-hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s) {
+// parts: bit 0 = ranges (compose_kernel: needs the sources' ranges, i.e. their binning), bit 1 = merges (needs their sorts)
+hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s, int parts) {
     int subtiles = 0;
     for (int k = 0; k < K; ++k) subtiles = subtiles > a[k].grid.subtiles ? subtiles : a[k].grid.subtiles;
     if (subtiles == 0) return hipSuccess;
     const Batch<ComposeArgs> b = make_batch(a, K);
-    compose_kernel<<<dim3(1 + C_ZERO_WGS, K), CBLOCK, 0, s>>>(b);
-    merge_kernel<<<dim3((subtiles + MBLOCK / 64 - 1) / (MBLOCK / 64), K), MBLOCK, 0, s>>>(b);
+    if (parts & 1) compose_kernel<<<dim3(1 + C_ZERO_WGS, K), CBLOCK, 0, s>>>(b);
+    if (parts & 2) merge_kernel<<<dim3((subtiles + MBLOCK / 64 - 1) / (MBLOCK / 64), K), MBLOCK, 0, s>>>(b);
     return hipGetLastError();
 }
 

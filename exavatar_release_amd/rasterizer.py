@@ -705,10 +705,13 @@ class _Rasterize(torch.autograd.Function):
                 if capturing and keep_keys and config.overlap_composites:
                     # lists first, an event, then the blend: the composites that follow merge these lists on a side stream
                     # while this blend runs (_Compose.forward)
-                    _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx) | _lib.STAGE_NO_BLEND, stream))
-                    ev = torch.cuda.Event()
-                    ev.record(stream_obj)
-                    _overlap[device.index] = ev
+                    _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx) | _lib.STAGE_NO_SORT, stream))
+                    ev_binned = torch.cuda.Event()
+                    ev_binned.record(stream_obj)
+                    _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx) | _lib.STAGE_SORT_ONLY, stream))
+                    ev_sorted = torch.cuda.Event()
+                    ev_sorted.record(stream_obj)
+                    _overlap[device.index] = (ev_binned, ev_sorted)
                     _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx) | _lib.STAGE_BLEND_ONLY, stream))
                 else:
                     _overlap.pop(device.index, None)
@@ -997,8 +1000,11 @@ def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
     side = _side_streams.get(device.index)
     if side is None:
         side = _side_streams[device.index] = torch.cuda.Stream(device=device)
-    side.wait_event(sorted_event)
-    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_NO_BLEND, ctypes.c_void_p(side.cuda_stream)))
+    ev_binned, ev_sorted = sorted_event
+    side.wait_event(ev_binned)          # ranges + zero-fill next to the sources' sort ...
+    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_NO_SORT, ctypes.c_void_p(side.cuda_stream)))
+    side.wait_event(ev_sorted)          # ... list merges next to their blend
+    _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_SORT_ONLY, ctypes.c_void_p(side.cuda_stream)))
     stream_obj.wait_stream(side)
     _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_BLEND_ONLY,
                                                     ctypes.c_void_p(stream_obj.cuda_stream)))

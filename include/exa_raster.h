@@ -300,6 +300,10 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
 #define EXA_RASTER_STORE_CTX        1
 #define EXA_RASTER_STAGE_NO_BLEND   2
 #define EXA_RASTER_STAGE_BLEND_ONLY 4
+/* one more cut, in front of the sort (composite: in front of the list merges, which need the sources' sorted lists -- the
+ * ranges before them only need the sources' binning): NO_SORT = everything before it, SORT_ONLY = only the sort / the merges */
+#define EXA_RASTER_STAGE_NO_SORT    8
+#define EXA_RASTER_STAGE_SORT_ONLY  16
 
 int exa_raster_forward_bin_batch(const ExaRasterForwardJob* jobs, int32_t K, void* stream);
 int exa_raster_forward_render_batch(const ExaRasterForwardJob* jobs, int32_t K, int32_t store_ctx, void* stream);
