@@ -157,6 +157,7 @@ class GraphedIteration:
         self.shape, self.device = (int(img_shape[0]), int(img_shape[1])), device
         self.merge, self.growth, self.check = bool(merge), float(capacity_growth), bool(check)
         self.loss_fn = loss_fn
+        self._pool, self._keeper = None, None            # ONE memory pool for every recording of this object (see _release)
         self.tight_backward = True      # developer A/B knob: bake the batch slots in use into the backward launches (_backward)
         self._serial = 0                # number of forward replays: a backward must belong to the latest one
         self._cam = torch.zeros(38, dtype=torch.float32, device=device)   # viewmatrix 16 | projmatrix 16 | campos 3 | bg 3:
@@ -177,10 +178,21 @@ class GraphedIteration:
     # ---- capture ---------------------------------------------------------------------------------------------------
     def _release(self):
         cap, self._cap = self._cap, None
-        if cap is not None and rz._hdr_pool is not None:
+        if cap is None:
+            return
+        if rz._hdr_pool is not None:
             for s in (cap.slots or []) + (getattr(cap, 'slots_c', None) or []):
                 if s is not None:
                     rz._hdr_pool.release(s[0])
+        # Let go of the recordings and their static tensors NOW (not whenever the cyclic collector finds the old capture): their
+        # memory then goes back to this object's graph pool and the next recording re-uses it.  A pool of its own per capture
+        # made every change of P pay ~90 ms of hipFree for the previous capture's segments (tools/gpu_capture_cost.py).
+        for name in ('fwd', 'bwd', 'outs', 'out_list', 'radii', 'inputs', 'in_list', 'in_raw', 'probes', 'loss', 'loss_args', 'flat',
+                     'dens_backup'):
+            try:
+                setattr(cap, name, None)
+            except AttributeError:
+                pass
 
     def __del__(self):
         try:
@@ -293,7 +305,15 @@ class GraphedIteration:
                     for k in range(len(cap.slots_c)):
                         got = pool.reserve()
                         cap.slots_c[k] = None if got is None else (got[0], got[1])
-                cap.pool = torch.cuda.graph_pool_handle()
+                if self._pool is None:
+                    # a pool lives as long as a graph recorded into it: this one-kernel recording keeps it (and the memory
+                    # earlier captures gave back to it) across re-captures
+                    self._pool = torch.cuda.graph_pool_handle()
+                    keeper = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(keeper, pool=self._pool):
+                        k_t = torch.zeros(16, device=dev)
+                    self._keeper = (keeper, k_t)
+                cap.pool = self._pool
                 cap.fwd = torch.cuda.CUDAGraph()
                 rz._capture_report = cap.slots
                 rz._capture_report_c = cap.slots_c
@@ -329,8 +349,10 @@ class GraphedIteration:
             rz.config.mode, rz.config.fixed_capacity = saved
         # the backward graph of the usual case -- gradients for the five colour images only -- is
         # recorded right away; other patterns (depth / mask gradients, fewer images) on first use
-        if self.loss_fn is None:
+        if self.loss_fn is None and not self.tight_backward:
             self._capture_backward(cap, _IMG_ONLY)
+        # (with tight_backward the first backward records the tight graph from that iteration's reports; the full-size one is
+        #  recorded only if it is ever needed -- one recording less per change of P)
         self._cap = cap
         return cap
 

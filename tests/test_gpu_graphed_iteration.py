@@ -337,8 +337,9 @@ def test_tight_backward_recordings_follow_the_slots_in_use(dev):
         pc, rc, gc = _run(eager, sets, cam, bg, G)
         _same(pa, pc, 'plane'); _same(ga, gc, 'grad (tight recording)'); _same(gb, gc, 'grad (full-size recording)')
     assert tight.captures == full.captures == 1
-    # one full-size recording at capture time + tight ones: the first, and one more when the near views needed more slots
-    assert 2 <= tight.backward_captures <= 4, tight.backward_captures
+    # tight recordings only: the first, and one more when the near views needed more slots (a full-size one only if a report
+    # had not landed when its backward came)
+    assert 1 <= tight.backward_captures <= 4, tight.backward_captures
     assert full.backward_captures == 1
     w = exa.rasterizer._hdr_pool.words
     cap = tight._cap
