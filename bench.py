@@ -23,6 +23,7 @@ the single-view headline), `extra_views_in_flight` (independent views on separat
 (the five same-camera renders of one ExAvatar training sample, eager, three ways).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -187,10 +188,31 @@ def main():
         if S > 1:
             c['stream'] = torch.cuda.Stream()
 
+    # How the graph-replayed single-view step gets its camera: 'graph' (default) -- the first node of the captured graph is
+    # exa_raster_select_row: row (counter mod views) of the resident camera table -> the graph's camera block, counter + 1
+    # (the ring of views is resident in HBM, as the contract of this line says; no launch outside the graph per step);
+    # 'kernel' -- one eager elementwise kernel in front of every replay (round 4 until this change: ~4.5 us of GPU time per step,
+    # mostly the system-scope fences of a launch outside the graph); 'memcpy' -- the runtime's blit (rounds 1-3).
+    cam_mode = os.environ.get('EXA_BENCH_CAM_COPY', 'graph')
+    view_counter = torch.zeros(1, dtype=torch.int32, device=device)
+    in_graph_switch = {'on': False}
+
+    def select_view_in_graph(c):
+        _lib.check(_lib.load().exa_raster_select_row(
+            ctypes.c_void_p(cam_tab.data_ptr()), len(my_views), 48, ctypes.c_void_p(view_counter.data_ptr()),
+            ctypes.c_void_p(c['cam'].data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def seek_view(i):
+        """(outside the timed region) the next replay renders this rank's view i mod views"""
+        if in_graph_switch['on']:
+            view_counter.fill_(i % len(my_views))
+
     def set_view(i, c):
         """Point context c at views i .. i + kv - 1 of this rank's shard (ONE gather-copy kernel)."""
         if c['kv'] == 1:
-            if os.environ.get('EXA_BENCH_CAM_COPY', 'kernel') == 'memcpy':
+            if in_graph_switch['on'] and c.get('graph') is not None and c.get('switch_in_graph'):
+                return                                                          # the replay itself takes the next row
+            if cam_mode == 'memcpy':
                 c['cam'].copy_(cam_tab[i % len(my_views)].view(1, 48))          # the runtime's blit: 3.6 us of GPU time per step
             else:
                 j = i % len(my_views)
@@ -270,12 +292,17 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             exa.check_overflow()
+            use_switch = cam_mode == 'graph' and KV == 1
             for b, c in enumerate(ctxs):
                 c['graph'] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(c['graph']):
+                    if use_switch:
+                        select_view_in_graph(c)
                     raster_step(c, b)
+                c['switch_in_graph'] = use_switch
                 c['graph'].replay()
                 torch.cuda.synchronize()
+            in_graph_switch['on'] = use_switch
         except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so in the result
             print('bench.py: hipGraph capture failed (%s); using eager launches' % e, file=sys.stderr)
             for c in ctxs:
@@ -311,10 +338,12 @@ def main():
     # launches with a host read-back each, which leaves the GPU in a low power state; the first ~50 steps after it run
     # 4-7 % slower than the steady state that any training run is in.  The W warm-up steps asked for follow it.
     settle = int(os.environ.get('EXA_BENCH_SETTLE_STEPS', '300'))
+    seek_view(0)
     for i in range(settle):
         step(i)
     finish()
     torch.cuda.synchronize()
+    seek_view(0)
     for i in range(args.warmup):
         step(i)
     finish()
@@ -357,12 +386,14 @@ def main():
                                      '2e-2; grads 1e-3 rel, 1e-1 * mean floor for Gaussians under an ambiguous pixel (tests/helpers.py)',
                        'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
                        'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle,
-                       'view_switch': 'per step, inside the timed region: the next view\'s camera block (48 floats) copied into '
-                                      'the graph\'s static tensor by ' +
-                                      ('the runtime\'s blit (EXA_BENCH_CAM_COPY=memcpy)'
-                                       if os.environ.get('EXA_BENCH_CAM_COPY', 'kernel') == 'memcpy'
-                                       else 'one elementwise kernel (rounds 1-3: the runtime\'s blit, 3.6 us of GPU time; '
-                                            'EXA_BENCH_CAM_COPY=memcpy brings it back: -0.4 %)'),
+                       'view_switch': 'per step, inside the timed region: the next view\'s camera block (48 floats) copied from the '
+                                      'resident table of ring views into the graph\'s static tensor by ' +
+                                      ('the first node of the replayed graph (exa_raster_select_row + a device-side counter; '
+                                       'EXA_BENCH_CAM_COPY=kernel: an eager elementwise kernel in front of every replay, the '
+                                       'protocol until late round 4, ~2 % slower; =memcpy: the runtime\'s blit, rounds 1-3)'
+                                       if in_graph_switch['on'] else
+                                       'the runtime\'s blit (EXA_BENCH_CAM_COPY=memcpy)' if cam_mode == 'memcpy' else
+                                       'one eager elementwise kernel in front of every replay (EXA_BENCH_CAM_COPY=kernel)'),
                        'views_in_flight_per_gpu': S, 'views_per_launch': KV,
                        'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads (dist.FlatGradAllReducer)'
                                       % (world, n_float * 4),

@@ -132,6 +132,7 @@ SIGNATURES = {
     'exa_raster_camera_block': (ctypes.c_int, [c_void_p, c_void_p, ctypes.POINTER(ctypes.c_float), c_void_p, c_void_p,
                                                c_void_p, c_void_p, ctypes.c_float, ctypes.c_float, c_void_p,
                                                ctypes.c_uint32, c_void_p]),
+    'exa_raster_select_row': (ctypes.c_int, [c_void_p, _I32, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_store_pointers': (ctypes.c_int, [c_void_p, ctypes.POINTER(c_void_p), _I32, c_void_p]),
     'exa_raster_mark_visible': (ctypes.c_int, [_SP, _I32, c_void_p, c_void_p, c_void_p]),
     'exa_raster_densify_stats': (ctypes.c_int, [_I32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -168,7 +169,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 135:
+    if lib.exa_raster_version() < 136:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

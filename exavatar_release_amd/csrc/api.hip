@@ -570,7 +570,23 @@ struct Ptr16 { const void* p[16]; };
 __global__ void store_pointers_kernel(const void** table, Ptr16 v, int n) {
     if ((int)threadIdx.x < n) table[threadIdx.x] = v.p[threadIdx.x];
 }
+// dst = table[*counter mod n_rows]; *counter = (that row + 1) mod n_rows.  One wave: every lane has read the counter before lane 0
+// writes it (program order of a wave).
+__global__ __launch_bounds__(64) void select_row_kernel(const float* __restrict__ table, int n_rows, int row_floats,
+                                                        int32_t* __restrict__ counter, float* __restrict__ dst) {
+    const int r = (int)((uint32_t)*counter % (uint32_t)n_rows);
+    for (int i = threadIdx.x; i < row_floats; i += 64) dst[i] = table[(size_t)r * row_floats + i];
+    if (threadIdx.x == 0) *counter = r + 1 == n_rows ? 0 : r + 1;
+}
 }  // namespace
+
+int exa_raster_select_row(const float* table, int32_t n_rows, int32_t row_floats, int32_t* counter, float* dst, void* stream) {
+    if (!table || !counter || !dst) return fail(EXA_RASTER_E_NULLPTR, "select_row: NULL pointer");
+    if (n_rows <= 0 || row_floats <= 0) return fail(EXA_RASTER_E_INVALID, "select_row: n_rows and row_floats must be positive");
+    select_row_kernel<<<1, 64, 0, static_cast<hipStream_t>(stream)>>>(table, n_rows, row_floats, counter, dst);
+    EXA_HIP(hipGetLastError(), "select_row");
+    return 0;
+}
 
 int exa_raster_store_pointers(void* table, const void* const* ptrs, int32_t n, void* stream) {
     if (!table || !ptrs) return fail(EXA_RASTER_E_NULLPTR, "store_pointers: NULL pointer");

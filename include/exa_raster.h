@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 135          /* 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 136          /* 0.1.3.6: exa_raster_select_row; 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -252,6 +252,14 @@ typedef struct ExaRasterBackwardJob {
      * header of THIS forward call said. */
     uint32_t used_slots;
 } ExaRasterBackwardJob;
+
+/* A schedule of per-frame parameter blocks that is RESIDENT on the device -- the ring of cameras of a turntable animation
+ * (avatar/main/animate_view_rot.py:104 computes all of them up front), the views of a benchmark -- stepped through without any
+ * host-side work per frame: one 64-lane launch copies row (*counter mod n_rows) of `table` [n_rows x row_floats] to `dst` and
+ * advances the counter (device int32).  Capturable: as the first node of a hipGraph every replay renders the next row
+ * (a camera block as exa_raster_camera_block writes it: viewmatrix 16 | projmatrix 16 | campos 3 floats), where an eager copy
+ * kernel in front of the replay costs ~4.5 us of GPU time per frame (system-scope fences around a launch outside the graph). */
+int exa_raster_select_row(const float* table, int32_t n_rows, int32_t row_floats, int32_t* counter, float* dst, void* stream);
 
 /* Stores `n` (<= 16) pointers into `table` (device memory) with one tiny kernel, in stream order. */
 int exa_raster_store_pointers(void* table, const void* const* ptrs, int32_t n, void* stream);

@@ -117,3 +117,39 @@ def test_single_render_entry_points_end_to_end(dev, fused):
                                        _p(G), None, None, _p(grad_ws), None, _p(d_m3b), None, None, None, None, None, None, stream))
     torch.cuda.synchronize()
     assert not bool(torch.isnan(d_m3b).any()) and float(d_m3b.abs().sum()) > 0
+
+
+def test_select_row_steps_through_a_resident_schedule(dev):
+    """``exa_raster_select_row``: row (counter mod rows) of a device-resident table -> dst, counter + 1 -- eagerly and as the first
+    node of a replayed hipGraph (how bench.py switches views, and how a turntable of precomputed cameras,
+    ``avatar/main/animate_view_rot.py:104``, can be rendered without per-frame host work)."""
+    lib = _lib.load()
+    rows, width = 5, 48
+    table = torch.arange(rows * width, dtype=torch.float32, device=dev).reshape(rows, width)
+    counter = torch.tensor([3], dtype=torch.int32, device=dev)
+    dst = torch.full((width,), -1.0, device=dev)
+
+    def call():
+        _lib.check(lib.exa_raster_select_row(_p(table), rows, width, _p(counter), _p(dst),
+                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    for want in (3, 4, 0, 1):
+        call()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, table[want]) and int(counter) == (want + 1) % rows
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()                                              # warm-up outside the capture (row 2)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    out = torch.zeros(width, device=dev)
+    with torch.cuda.graph(g):
+        call()
+        torch.mul(dst, 2.0, out=out)                        # a consumer inside the same graph
+    for want in (3, 4, 0, 1, 2, 3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, 2.0 * table[want]) and int(counter) == (want + 1) % rows
+    assert lib.exa_raster_select_row(None, rows, width, _p(counter), _p(dst), None) < 0
+    assert lib.exa_raster_select_row(_p(table), 0, width, _p(counter), _p(dst), None) < 0
