@@ -390,7 +390,7 @@ def main():
                                       'resident table of ring views into the graph\'s static tensor by ' +
                                       ('the first node of the replayed graph (exa_raster_select_row + a device-side counter; '
                                        'EXA_BENCH_CAM_COPY=kernel: an eager elementwise kernel in front of every replay, the '
-                                       'protocol until late round 4, ~2 % slower; =memcpy: the runtime\'s blit, rounds 1-3)'
+                                       'protocol until late round 4, 0.5 % slower; =memcpy: the runtime\'s blit, rounds 1-3)'
                                        if in_graph_switch['on'] else
                                        'the runtime\'s blit (EXA_BENCH_CAM_COPY=memcpy)' if cam_mode == 'memcpy' else
                                        'one eager elementwise kernel in front of every replay (EXA_BENCH_CAM_COPY=kernel)'),
@@ -413,6 +413,36 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result[name] = {'error': str(e)[:200]}
         exa.check_overflow()
+        # what the gap BETWEEN two graph launches costs the headline (rocprofv3 kernel trace: ~8 us from the last kernel of one
+        # replay to the first of the next, of a 151 us step): the same step, four to a recorded graph
+        if in_graph_switch['on'] and train:
+            try:
+                U = 4
+                c4 = make_ctx(1)
+                g4 = torch.cuda.CUDAGraph()
+                set_view(0, c4)
+                raster_step(c4, 0)
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g4):
+                    for _ in range(U):
+                        select_view_in_graph(c4)
+                        raster_step(c4, 0)
+                n_rep = max(args.steps // U, 8)
+                for _ in range(8):
+                    g4.replay()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_rep):
+                    g4.replay()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                result['extra_steps_per_replay'] = {
+                    'steps_per_replay': U, 'value': n_rep * U / dt, 'unit': 'iters/s', 'ms_per_step': dt / (n_rep * U) * 1e3,
+                    'what': 'the headline step, %d of them (consecutive views) recorded into ONE hipGraph: what is left when the '
+                            'gap between two graph launches is paid once per %d steps; NOT the headline protocol' % (U, U)}
+                exa.check_overflow()
+            except Exception as e:  # noqa: BLE001
+                result['extra_steps_per_replay'] = {'error': str(e)[:200]}
 
     # ---- extra: one ExAvatar training sample = five same-camera renders fwd + bwd (model.py:119-167), eager ----
     if rank == 0 and single and not args.no_concurrent and args.config == 'c3' and train:
