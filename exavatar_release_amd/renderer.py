@@ -117,6 +117,20 @@ def camera_block_device(cam_param, img_shape, out38, expect=None, flag=None):
 _probe_cache = []      # most recent first: (P, device, zeros [P, 3]); treat the probes as read-only
 
 
+_white_bg = {}
+
+
+def _white(device):
+    """The default background (module.py:596 builds ``torch.ones(3)`` per call): one cached tensor per device -- the rasterizer
+    only reads it, and three of the five renders of an iteration use it (an allocation + a fill kernel each otherwise)."""
+    w = _white_bg.get(device)
+    if w is None:
+        w = torch.ones(3, dtype=torch.float32, device=device)
+        if device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():   # (allocated during a capture = that graph's pool)
+            _white_bg[device] = w
+    return w
+
+
 def _zero_probe(P, device):
     for i, (cp, cd, z) in enumerate(_probe_cache):
         if cp == P and cd == device:
@@ -158,7 +172,7 @@ def _raster_job(gaussian_assets, img_shape, cam_param, bg, densify_stats=None, f
     device = mean_3d.device
     sh_degree = _sh_degree(gaussian_assets)
     if bg is None:
-        bg = torch.ones((3), dtype=torch.float32, device=device)
+        bg = _white(device)
 
     tanfovx, tanfovy, view_matrix, full_proj_matrix, cam_pos = cam_block if cam_block is not None else \
         _camera_block(cam_param, img_shape, device)
@@ -396,6 +410,8 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
     if len(modes) != 1:
         raise ValueError('render_iteration: scene, human and refined human must all carry the same colour input (rgb or sh)')
     pr = probes if probes is not None else (None,) * 5
+    if cam_block is None:                    # the five renders share the camera: derive its matrices once
+        cam_block = _camera_block(cam_param, img_shape, device)
     kw = dict(cam_block=cam_block)
     if merge and scene_asset['mean_3d'].shape[0] > 0 \
             and human_asset['mean_3d'].shape[0] > 0 and human_asset_refined['mean_3d'].shape[0] > 0:
