@@ -515,6 +515,7 @@ class _Job:
 
 
 _F32 = torch.float32
+_PLANES = [3, 1, 1]         # colour | depth | alpha planes of one output arena
 
 
 def _fill_forward_job(a, j, report=None):
@@ -758,7 +759,7 @@ class _Rasterize(torch.autograd.Function):
         ctx.need_ctx = need_ctx
         outs = []
         for j in jobs:
-            c, d, a = j.planes.split((3, 1, 1))
+            c, d, a = torch.split_with_sizes(j.planes, _PLANES)       # (Tensor.split is a Python wrapper: ~4 us)
             outs += [c, j.radii, d, a]
         if keep_keys:
             # One more (empty) differentiable output: composites of these renders take it as an input, which orders their
@@ -872,7 +873,7 @@ class _Rasterize(torch.autograd.Function):
                     d_means2D = torch.empty((Pg, 3), dtype=_F32, device=device) if nd[1] else None
                 else:
                     widths = [w for on, w in want if on]
-                    pieces = iter(torch.empty(Pg * sum(widths), dtype=_F32, device=device).split([Pg * w for w in widths])) \
+                    pieces = iter(torch.split_with_sizes(torch.empty(Pg * sum(widths), dtype=_F32, device=device), [Pg * w for w in widths])) \
                         if widths else iter(())
                     d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
                         [next(pieces).view(Pg, w) if on else None for on, w in want]
@@ -1057,7 +1058,7 @@ class _Compose(torch.autograd.Function):
         ctx.need_ctx = need_ctx
         outs = []
         for c in cjobs:
-            col, d, al = c.planes.split((3, 1, 1))
+            col, d, al = torch.split_with_sizes(c.planes, _PLANES)
             outs += [col, c.radii, d, al]
         if need_ctx:
             ctx.K, ctx.cjobs, ctx.device = K, cjobs, device
@@ -1130,7 +1131,7 @@ class _Compose(torch.autograd.Function):
                 want = ((nd[0], 3), (nd[1], 3), (has_col and nd[3], 3), (nd[4], 1), (has_sc and nd[5], 3), (has_rot and nd[6], 4),
                         (has_cov and nd[7], 6))
                 widths = [w for on, w in want if on]
-                pieces = iter(torch.empty(P * sum(widths), dtype=_F32, device=device).split([P * w for w in widths])) \
+                pieces = iter(torch.split_with_sizes(torch.empty(P * sum(widths), dtype=_F32, device=device), [P * w for w in widths])) \
                     if widths else iter(())
                 d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
                     [next(pieces).view(P, w) if on else None for on, w in want]
