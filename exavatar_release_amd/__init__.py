@@ -5,7 +5,7 @@ Public surface (drop-in for ``diff_gaussian_rasterization_depth`` as used at ref
 
     from exavatar_release_amd import GaussianRasterizationSettings, GaussianRasterizer
 """
-from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, check_overflow, config,
+from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, config,
                          rasterize_gaussians, rasterize_gaussians_batch)
 from .densify import track_densify_stats
 from .losses import SSIM, PhotometricLoss, RGBLoss
@@ -13,6 +13,6 @@ from .renderer import ITERATION_RENDERS, GaussianRenderer, GraphedRenderer, rend
 from .graphed import GraphedIteration
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
-           'rasterize_gaussians_batch', 'config', 'check_overflow', 'track_densify_stats', 'render_many', 'render_views',
+           'rasterize_gaussians_batch', 'config', 'track_densify_stats', 'render_many', 'render_views',
            'render_iteration', 'ITERATION_RENDERS', 'GraphedRenderer', 'GraphedIteration',
            'SSIM', 'RGBLoss', 'PhotometricLoss']

@@ -649,9 +649,17 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     if ((int)blockIdx.x >= g.cells * PARTS) return;
     CellPart cp;
     if (!cell_part_of(w, a.capacity, cp)) return;
-    if (!cp.active) {                                                   // empty cell: its one workgroup publishes 64 empty ranges
-        if (threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
-        if (threadIdx.x == 0) w.cell_long[cp.rank] = 0u;
+    // empty cell: its one workgroup publishes 64 empty ranges.  So does part 0 of every cell of an OVERFLOWED render, and
+    // nothing else of it runs: cell_scatter left the buckets unwritten, and the cell's entry offsets (cp.lo) count entries of
+    // the render that did not fit -- they lie beyond the `capacity` entries the bucket array holds.  Until round 5 the
+    // prefetch below was issued all the same, `bucket[cp.lo - 1]` = up to (entries - capacity) * 16 bytes past the end of the
+    // bin workspace: harmless while the allocator has something mapped behind it, a GPU memory fault (SIGABRT of the
+    // process at its next runtime call) when it has not -- the round-4 GPUTEST abort.
+    if (!cp.active || cp.overflow) {
+        if (cp.part == 0) {
+            if (threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+            if (threadIdx.x == 0) w.cell_long[cp.rank] = 0u;
+        }
         return;
     }
     const int cell = cp.cell, tid = threadIdx.x;

@@ -27,7 +27,7 @@ a render needs more tile instances than its buffer holds (the plain renders repo
 pinned-host slots ~35 us into the replay; they are polled right after the replay is queued -- the GPU is busy with the
 rest of the forward meanwhile -- and an overflowed iteration is re-captured with enough room and rendered again BEFORE
 the call returns: the images handed out are always complete, same contract as the eager path's
-``config.overflow_check = 'forward'``), or the densification-statistics tensors are replaced.  Results are bit-identical
+report polling), or the densification-statistics tensors are replaced.  Results are bit-identical
 to eager :func:`renderer.render_iteration` (same kernels, same order; tests/test_gpu_graphed_iteration.py).
 
 The returned images alias the graph's static outputs: valid until the next call (clone what must survive).
@@ -289,7 +289,6 @@ class GraphedIteration:
                         del res
                     torch.cuda.current_stream(dev).wait_stream(side)
                     torch.cuda.synchronize(dev)
-                    rz.check_overflow_quiet()
                 # header reports of the plain renders go to reserved pinned-host slots (outside the ring eager calls use)
                 pool = rz._pool()
                 n_jobs = 3 if self.merge else 5

@@ -20,47 +20,29 @@ after the binning stage.  Policies (``config.mode``):
   allocate exactly, stage 2.
 * ``'capacity'``: one fused call with a buffer sized from the D of earlier calls of the same shape
   (x ``config.capacity_growth``; the first call of a shape runs in exact mode to measure D), or from
-  ``config.fixed_capacity``; no host sync and hipGraph-capturable.  Whether the buffer was large enough
-  comes back through a ZERO-COPY header report: the scatter stage stores ``{needed, overflow, visible, tag}``
-  into 16 bytes of pinned host memory (``ExaRasterForwardJob.host_header``) ~35 us into the forward,
-  and the host only looks at that word -- no runtime call, no copy, no synchronisation.
+  ``config.fixed_capacity``; no host sync and hipGraph-capturable.
 * ``'auto'`` (default): ``'capacity'`` for renders that will be differentiated and under stream
   capture, ``'exact'`` for ``torch.no_grad()`` renders.
 
-Overflow (a render needed more instances than its buffer held; upstream cannot overflow because it
-always takes the ``'exact'`` round trip).  The kernels latch it on the device: the render draws the
-background only and its backward writes zero gradients.  ``config.on_overflow``:
+Overflow (a capacity-mode render needed more instances than its buffer held; upstream cannot overflow
+because it always takes the ``'exact'`` round trip).  The kernels latch it on the device -- the render
+draws the background only, its backward would write zero gradients -- and report it through a ZERO-COPY
+header: the scatter stage stores ``{needed, overflow, visible, tag}`` into 16 bytes of pinned host memory
+(``ExaRasterForwardJob.host_header``) ~35 us into the forward, about when the host has finished queueing
+the forward's kernels.  ONE protocol: the render's own ``forward`` polls that word before it returns
+(a few microseconds, no runtime call, no synchronisation) and, per ``config.on_overflow``,
 
-* ``'retry'`` (default): the render's own ``backward`` -- which looks at the report BEFORE returning
-  gradients -- re-runs the forward with the capacity the report names (into the SAME output tensors,
-  so ``img`` is corrected in place for whatever reads it later in stream order) and then runs the
-  backward on the repaired context: gradients are those of the complete render for the incoming
-  dL/dimage.  What cannot be repaired is work that already consumed the incomplete image (the loss
-  value of that one step); a ``RuntimeWarning`` says so.  ``no_grad`` / never-differentiated renders
-  are re-rendered when their report is drained (next call or :func:`check_overflow`).
-* ``'raise'``: ``RuntimeError`` instead (from ``backward``, :func:`check_overflow` or a later call).
+* ``'retry'`` (default): re-runs the forward with the capacity the report names, into the SAME output
+  tensors, before anybody can have read them: a capacity-mode call returns exactly what ``'exact'``
+  returns, images, losses computed from them and gradients alike, always (tests/test_gpu_soak.py trains
+  300 iterations both ways to bit-identical parameters);
+* ``'raise'``: raises ``RuntimeError``.
 
-``config.overflow_check`` decides WHEN the report is looked at:
-
-* ``'forward'`` (default): at the end of the render's own ``forward`` -- the report is written ~35 us
-  into the forward's kernels, about when the host has finished queueing them, so the poll costs a
-  few microseconds and no synchronisation; an overflowed render is repaired THERE, before anybody
-  can read its outputs: capacity mode then returns exactly what ``'exact'`` returns, images,
-  losses computed from them and gradients alike, always (tests/test_gpu_soak.py trains 300
-  iterations both ways to bit-identical parameters).
-* ``'always'``: in the render's ``backward`` (the forward never waits): backward never returns the
-  gradients of an overflowed render, but a loss that was computed from the incomplete image is stale
-  for that step (warned about).
-* ``'adaptive'`` (opt-in, for loops that cannot afford any host wait): like ``'always'`` during the
-  first ``config.verify_calls`` calls of a shape and whenever the last known D filled more than
-  ``config.danger_fill`` of the buffer; otherwise the report is left to be drained later: an overflow
-  found after its backward has returned ZERO gradients can only be recorded -- the capacity memo
-  grows -- and warned about (``'late'`` in ``overflow_events``).
-
-A render that nobody differentiates (``no_grad``, a skipped step) is repaired when its report is
-drained -- by a later call or :func:`check_overflow` -- from the input tensors as they are THEN: if
-they were modified in place in between (``optimizer.step()``), the corrected image shows the new
-values, and the ``RuntimeWarning`` says so.
+Nothing is ever left pending: ``backward`` finds a complete context.  (Rounds 3-4 also had deferred
+protocols -- look at the report in ``backward`` or at a later call; they tripled the host state machine
+for a few microseconds per call and were removed in round 5.)  Under stream capture nothing can be
+polled: the report goes to a reserved slot the owner of the graph reads after each replay
+(``GraphedRenderer`` / ``GraphedIteration``), or the caller checks ``read_header`` itself.
 """
 import ctypes
 import os
@@ -98,10 +80,7 @@ class _Config:
     fixed_capacity = None     # capacity mode: use exactly this many instances (e.g. calibrated by a warm-up); a list /
     #                           tuple names one capacity per job of a batched call
     keep_debug = False        # developer probes: keep the workspaces of the most recent forward reachable
-    on_overflow = 'retry'     # 'retry' | 'raise'
-    overflow_check = 'forward'    # 'forward' | 'always' | 'adaptive': where the header report is looked at (module docstring)
-    verify_calls = 4          # adaptive: the first calls of a shape wait for their report
-    danger_fill = 0.8         # adaptive: ... and so does a call whose shape last filled more than this of its buffer
+    on_overflow = 'retry'     # 'retry' | 'raise' (module docstring)
     overlap_composites = True     # INSIDE a stream capture: the composites' list merges run on a second stream while their sources
     #                               blend (the calls are split at EXA_RASTER_STAGE_NO_BLEND; fork / join become graph edges).
     #                               Eager calls never do this: the stream switches cost the host more than the overlap gives
@@ -111,15 +90,15 @@ class _Config:
     compose_reuse_source = True   # composite renders copy source A's pixels where source B has no entry (developer A/B knob)
     upstream_scale_grad = False   # True: dL/dscale as upstream returns it (w.r.t. scale_modifier * scale, i.e. divided
     #                               by scale_modifier); identical for the reference, which passes 1.0 (module.py:615)
+    poison = False                # debug: fill every workspace with 0xFF before the kernels see it (the library promises to write
+    #                               every section before it reads it; tests run under it with EXA_TEST_POISON=1)
 
 
 config = _Config()
 
 _debug_last = {}  # only filled when config.keep_debug (tools/): workspaces of the most recent forward
 _seen_D = {}      # (device index, P, H, W) -> largest instance capacity a call of that shape needed
-_verified = {}    # same key -> number of calls whose report was looked at before their backward returned
-_pending = []     # header reports nobody has consumed yet: _Pending records
-overflow_events = []   # (key, needed, capacity, 'retried' | 'late') of every overflow seen (bounded; for tests / logs)
+overflow_events = []   # (key, needed, capacity, 'retried' | 'raised') of every overflow seen (bounded; for tests / logs)
 _capture_report = None   # [(slot, tag) | None per job]: reserved header-report slots baked into the batched call being
 #                          CAPTURED (set by GraphedRenderer / GraphedIteration around their capture)
 _overlap = {}             # device index -> (side stream, event recorded when the sources' sorted lists are complete): set by a
@@ -129,7 +108,6 @@ _capture_used = None      # (used batch slots per plain job, per composite job) 
 #                           (ExaRasterBackwardJob.used_slots; GraphedIteration checks them against every replay's reports)
 _capture_grad_ind = None  # {data_ptr of a static dL/dcolor buffer: device address of its pointer-table entry}: set by
 #                           GraphedIteration while it RECORDS a backward graph (ExaRasterBackwardJob.dL_dcolor_indirect)
-_COMPOSE_CAP_SCALE = float(os.environ['EXA_COMPOSE_CAP_SCALE']) if 'EXA_COMPOSE_CAP_SCALE' in os.environ else None   # developer knob
 _last_handles = None     # host job records of the most recent keep_keys call (handed to rasterize_gaussians_batch's caller)
 _tls = threading.local()  # .is_vis: the `radii > 0` tensors the per-Gaussian kernel of the most recent call of this thread wrote
 #                           (ExaRasterForwardJob.is_vis), picked up by the renderer's output dict via take_is_vis()
@@ -146,6 +124,15 @@ def take_is_vis():
 
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _workspace(nbytes, device):
+    """Uninitialised byte workspace (``config.poison``: filled with 0xFF, so that a kernel reading a section nobody
+    wrote sees the worst garbage instead of whatever the allocator left there)."""
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    if config.poison:
+        ws.fill_(255)
+    return ws
 
 
 def _addr(t):
@@ -242,12 +229,12 @@ def _make_settings(rs, device, keep):
 # ---- zero-copy header reports ------------------------------------------------------------------------------------
 class _HdrPool:
     """16-byte slots in pinned host memory the scatter kernel writes its header report into: a ring of N slots for eager
-    calls (one per render job, composite or focal-length flag; ``owner`` remembers the tag of the latest taker, so a
-    report whose slot was handed out again knows it was recycled) and RESERVED slots outside the ring for reports that
-    are baked into a captured hipGraph (``GraphedRenderer``, ``GraphedIteration``): a graph rewrites its slot on every
+    calls (one per render job, composite or focal-length flag; a report is consumed inside the call that took its slot,
+    so a slot comes round again long after its report was read) and RESERVED slots outside the ring for reports that are
+    baked into a captured hipGraph (``GraphedRenderer``, ``GraphedIteration``): a graph rewrites its slot on every
     replay for as long as it lives, so it must never be dealt to anybody else."""
     N = 2048
-    RESERVED = 256
+    RESERVED = 1024
 
     def __init__(self):
         total = self.N + self.RESERVED
@@ -258,7 +245,6 @@ class _HdrPool:
         self.words = (ctypes.c_uint32 * (4 * total)).from_address(self.buf.data_ptr())
         self.next = 0
         self.tag = 1
-        self.owner = [0] * total
         self.free_reserved = list(range(total - 1, self.N - 1, -1))
 
     def _next_tag(self):
@@ -270,23 +256,19 @@ class _HdrPool:
         """(slot, tag, device address) of the next ring slot."""
         i = self.next
         self.next = (i + 1) % self.N
-        tag = self._next_tag()
-        self.owner[i] = tag
-        return i, tag, self.dev_base + 16 * i
+        return i, self._next_tag(), self.dev_base + 16 * i
 
     def reserve(self):
-        """(slot, tag, device address) of a slot outside the ring, held until :meth:`release`; None when all are taken."""
+        """(slot, tag, device address) of a slot outside the ring, held until :meth:`release`."""
         if not self.free_reserved:
-            return None
+            raise RuntimeError('exavatar_release_amd: all %d reserved header-report slots are taken: too many live '
+                               'GraphedRenderer / GraphedIteration objects (close() the ones no longer used)' % self.RESERVED)
         i = self.free_reserved.pop()
-        tag = self._next_tag()
-        self.owner[i] = tag
         self.words[4 * i + 3] = 0
-        return i, tag, self.dev_base + 16 * i
+        return i, self._next_tag(), self.dev_base + 16 * i
 
     def release(self, slot):
         if slot >= self.N and slot not in self.free_reserved:
-            self.owner[slot] = 0
             self.free_reserved.append(slot)
 
 
@@ -295,8 +277,8 @@ _hdr_pool_failed = False
 
 
 def _pool():
-    """The pool, or None when pinned host memory cannot be mapped for the device (then reports fall back to an
-    asynchronous 16-byte read-back + event per call)."""
+    """The pool, or None when pinned host memory cannot be mapped for the device (then the header is read back with a
+    16-byte copy + a stream synchronisation per call)."""
     global _hdr_pool, _hdr_pool_failed
     if _hdr_pool is None and not _hdr_pool_failed:
         try:
@@ -306,59 +288,29 @@ def _pool():
     return _hdr_pool
 
 
-class _Report:
-    """Header report of one job of a capacity-mode call."""
-    __slots__ = ('slot', 'tag', 'event', 'host', 'row', 'stream', 'tile_ptr')
-
-    def ready(self):
-        if self.event is not None:
-            return self.event.query()
-        # a slot that was dealt again (> N renders later) will never show this report's tag: treat it as landed --
-        # values() then reads the header from the device
-        return _hdr_pool.words[4 * self.slot + 3] == self.tag or _hdr_pool.owner[self.slot] != self.tag
-
-    def wait(self):
-        if self.event is not None:
-            self.event.synchronize()
-            return
-        w = _hdr_pool.words
-        i, tag = 4 * self.slot + 3, self.tag
-        if _hdr_pool.owner[self.slot] == tag:
-            t_end = time.perf_counter() + 2e-3
-            while w[i] != tag and time.perf_counter() < t_end:
-                pass
+def _await_report(slot, tag, stream):
+    """(needed capacity, overflow flag) of the report with ``tag`` in pool slot ``slot``.  The scatter stage writes it
+    ~35 us into the forward: the host spins on the word (no runtime call); a stream that is far behind is waited for."""
+    w, i = _hdr_pool.words, 4 * slot + 3
+    if w[i] != tag:
+        t_end = time.perf_counter() + 2e-3
+        while w[i] != tag and time.perf_counter() < t_end:
+            pass
         if w[i] != tag:
-            self.stream.synchronize()       # far behind (or slot recycled): let the stream reach the scatter stage
-
-    def values(self):
-        """(needed capacity, overflow flag); call after ready() / wait()."""
-        if self.event is not None:
-            r = self.host[self.row].tolist()
-            return int(r[0]), int(r[1])
-        w = _hdr_pool.words
-        b = 4 * self.slot
-        if w[b + 3] != self.tag:            # slot recycled by a much later call (> N renders in flight): read the device
-            h = torch.empty(4, dtype=torch.int32)
-            _lib.check(_lib.load().exa_raster_read_header_async(self.tile_ptr, h.data_ptr(), ctypes.c_void_p(self.stream.cuda_stream)))
-            self.stream.synchronize()
-            r = h.tolist()
-            return int(r[0]), int(r[1])
-        return int(w[b]), int(w[b + 1])
+            stream.synchronize()
+            if w[i] != tag:
+                raise RuntimeError('exavatar_release_amd: the header report of a render never arrived')
+    return int(w[i - 3]), int(w[i - 2])
 
 
-def _landed_need(rep):
-    """``num_rendered`` of a pool-slot report that has landed and did not overflow, else None; never waits or synchronises."""
-    if rep is None or rep.event is not None or _hdr_pool is None:
+def _landed_need(report):
+    """``num_rendered`` of a ``(slot, tag)`` report that has landed and did not overflow, else None; never waits."""
+    if report is None or _hdr_pool is None:
         return None
-    w, b = _hdr_pool.words, 4 * rep.slot
-    if w[b + 3] != rep.tag or w[b + 1] != 0:
+    w, b = _hdr_pool.words, 4 * report[0]
+    if w[b + 3] != report[1] or w[b + 1] != 0:
         return None
     return int(w[b])
-
-
-class _Pending:
-    """One capacity-mode call whose reports have not all been consumed: enough to re-render an overflowed job."""
-    __slots__ = ('jobs', 'reports', 'store_ctx', 'device', 'done', 'backward_done', '__weakref__')
 
 
 def _record_overflow(key, need, cap, how):
@@ -372,110 +324,50 @@ def _note(key, need):
 
 
 def _overflow_error(need, cap):
-    return RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d); the outputs '
-                        'of that render are invalid and its gradients are zero. Use config.on_overflow="retry", '
-                        'config.mode="exact" or raise config.capacity_growth.' % (need, cap))
+    return RuntimeError('exavatar_release_amd: tile-instance buffer overflow (needed %d, capacity %d). '
+                        'Use config.on_overflow="retry", config.mode="exact" or raise config.capacity_growth.' % (need, cap))
 
 
 def _rerender(j, need, store_ctx, device):
     """Run job ``j``'s forward again with room for ``need`` instances, into the same output tensors."""
     lib = _lib.load()
-    cap = (max(int(need * 1.0), 64) + 63) // 64 * 64
+    cap = (max(int(need), 64) + 63) // 64 * 64
     j.capacity = cap
-    j.ws = torch.empty(j.gb + j.tb + int(_sizes(j.P, j.W, j.H, cap).bin_bytes), dtype=torch.uint8, device=device)
+    j.ws = _workspace(j.gb + j.tb + int(_sizes(j.P, j.W, j.H, cap).bin_bytes), device)
     j.bins = None
     j.geom_ptr = j.ws.data_ptr()
     j.tile_ptr = j.geom_ptr + j.gb
     j.bin_ptr = j.tile_ptr + j.tb
     arr = (_lib.ExaRasterForwardJob * 1)()
     _fill_forward_job(arr[0], j)
-    with _on_device(device):
-        _lib.check(lib.exa_raster_forward_batch(arr, 1, int(store_ctx), _stream_ptr(device)))
+    _lib.check(lib.exa_raster_forward_batch(arr, 1, int(store_ctx), _stream_ptr(device)))
 
 
-def _consume(rec, block, from_backward=False, in_forward=False):
-    """Look at the reports of ``rec``; handle overflows.  Returns True when every report was consumed.
-    ``from_backward``: the caller is the render's own backward (it may still repair the context); ``in_forward``: its own
-    forward, before the outputs were handed out (nothing can have read the incomplete image)."""
-    all_done = True
-    msgs = []
-    for k, (j, rep) in enumerate(zip(rec.jobs, rec.reports)):
-        if rep is None:
-            continue
-        if not rep.ready():
-            if not block:
-                all_done = False
-                continue
-            rep.wait()
-        need, overflow = rep.values()
-        rec.reports[k] = None
+def _settle(jobs, reports, store_ctx, device, stream):
+    """Read the header reports of a capacity-mode call that was just queued (``reports``: one ``(slot, tag)`` per job, or
+    None without a pool: the headers are read back) and deal with overflowed jobs (``config.on_overflow``) before the
+    call's outputs leave ``forward``.  Every report is consumed before anything is raised."""
+    if reports is None:
+        rows = [j.ws[j.gb:j.gb + 16].view(torch.int32) for j in jobs]
+        hdr = (rows[0] if len(jobs) == 1 else torch.stack(rows)).cpu().view(len(jobs), 4)
+        got = [(int(hdr[k, 0]), int(hdr[k, 1])) for k in range(len(jobs))]
+    else:
+        got = [_await_report(r[0], r[1], stream) for r in reports]
+    err = None
+    for j, (need, overflow) in zip(jobs, got):
         _note(j.key, need)
         j.need = need                # (the backward launches one wave per batch slot IN USE: ExaRasterBackwardJob.used_slots)
         if not overflow:
             continue
         if config.on_overflow == 'raise':
             _record_overflow(j.key, need, j.capacity, 'raised')
-            msgs.append(_overflow_error(need, j.capacity))
-            continue
-        if rec.backward_done and not from_backward:
-            # found after its backward returned zeros: nothing left to repair but the memo (already grown above)
-            _record_overflow(j.key, need, j.capacity, 'late')
-            warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d; this was '
-                          'found after its backward had returned zero gradients (config.overflow_check="adaptive"). '
-                          'The capacity memo has grown; set config.overflow_check="always" to wait for every report.'
-                          % (need, j.capacity), RuntimeWarning)
+            err = err or _overflow_error(need, j.capacity)
             continue
         old = j.capacity
-        stale = tuple(t._version for t in (j.means3D, j.sh, j.colors, j.opac, j.scales, j.rot, j.cov) if t is not None) != j.versions
-        _rerender(j, need, rec.store_ctx, rec.device)
+        _rerender(j, need, store_ctx, device)
         _record_overflow(j.key, need, old, 'retried')
-        if not in_forward:       # (repaired inside its own forward: nobody saw the incomplete outputs, nothing to warn about)
-            warnings.warn('exavatar_release_amd: a render needed %d tile instances but its buffer held %d: re-rendered with '
-                          'enough room (outputs corrected in place; work that already read the incomplete image -- the loss '
-                          'value of this step -- is not).%s' % (need, old, ' Its input tensors were modified in place since '
-                          'the forward: the corrected image shows their CURRENT values.' if stale else ''), RuntimeWarning)
-    if all_done:
-        rec.done = True
-    if msgs:
-        raise msgs[0]
-    return all_done
-
-
-def _drain_pending(block=False):
-    """Process the header reports that have landed (all of them with ``block``).  Every completed record is processed
-    before anything is raised (``config.on_overflow == 'raise'``), so no report is lost to an earlier one's error."""
-    global _pending
-    if not _pending:
-        return
-    rest, err = [], None
-    for rec in _pending:
-        if rec.done:
-            continue
-        try:
-            if not _consume(rec, block):
-                rest.append(rec)
-        except RuntimeError as e:
-            err = err or e
-            if not rec.done and any(r is not None for r in rec.reports):
-                rest.append(rec)
-    _pending = rest
     if err is not None:
         raise err
-
-
-def check_overflow():
-    """Wait for all outstanding capacity-mode calls; re-render (``config.on_overflow == 'retry'``) or raise for any
-    that overflowed its buffer."""
-    _drain_pending(block=True)
-
-
-def check_overflow_quiet():
-    """Drain the outstanding reports like :func:`check_overflow` but never raise (``on_overflow == 'raise'`` callers that
-    handle an overflow themselves); the instance counts still feed the capacity memo."""
-    try:
-        _drain_pending(block=True)
-    except RuntimeError:
-        pass
 
 
 HEADER_FIELDS = ('num_rendered', 'overflow', 'max_tile_list', 'num_visible', 'num_instances', 'active_cells',
@@ -511,7 +403,7 @@ class _Job:
     """Host-side record of one render of a batch."""
     __slots__ = ('rs', 'P', 'nF', 'H', 'W', 'sh_M', 'key', 'means3D', 'sh', 'colors', 'opac', 'scales', 'rot', 'cov',
                  'settings', 'keep', 'planes', 'radii', 'ws', 'bins', 'geom_ptr', 'tile_ptr', 'bin_ptr', 'capacity',
-                 'gb', 'tb', 'keep_keys', 'rec', 'device', 'versions', 'is_vis', 'stash', 'token_ref', 'need')
+                 'gb', 'tb', 'keep_keys', 'device', 'is_vis', 'stash', 'token_ref', 'need')
 
 
 _F32 = torch.float32
@@ -530,8 +422,8 @@ def _fill_forward_job(a, j, report=None):
     base = j.planes.data_ptr()
     a.out_color, a.out_depth, a.out_alpha = base, base + 12 * j.H * j.W, base + 16 * j.H * j.W
     a.keep_sorted_keys = 1 if j.keep_keys else 0
-    if report is not None and report.event is None:
-        a.host_header, a.header_tag = _hdr_pool.dev_base + 16 * report.slot, report.tag
+    if report is not None:           # (slot, tag) of a pool slot
+        a.host_header, a.header_tag = _hdr_pool.dev_base + 16 * report[0], report[1]
     else:
         a.host_header, a.header_tag = None, 0
 
@@ -609,8 +501,7 @@ class _Rasterize(torch.autograd.Function):
             j.cov = inp(cov, 7, 'cov3D_precomp')
             j.sh_M = int(j.sh.shape[1]) if j.sh is not None else 0
             j.key = (device.index, j.P, j.H, j.W)
-            j.keep_keys, j.rec, j.device = keep_keys, None, device
-            j.versions = tuple(t._version for t in (j.means3D, j.sh, j.colors, j.opac, j.scales, j.rot, j.cov) if t is not None)
+            j.keep_keys, j.device = keep_keys, device
             jobs.append(j)
         if shared and K > 1:
             # "K views of the same Gaussians" is decided on what the kernels will see: the converted tensors
@@ -621,7 +512,6 @@ class _Rasterize(torch.autograd.Function):
 
         if len(_seen_D) > 4096:       # P changes with every densification step: keep the capacity memo bounded
             _seen_D.clear()             # (here, before any key of this call is looked up; cleared shapes re-measure once)
-            _verified.clear()
         mode = config.mode
         capturing = torch.cuda.is_current_stream_capturing()
         if mode == 'auto':
@@ -634,30 +524,13 @@ class _Rasterize(torch.autograd.Function):
                                    'earlier un-captured call of the same shape) before stream capture')
             mode = 'exact'            # first call of this shape: measure D once, like upstream does
 
-        rec = None
         with _on_device(device):
             stream_obj = torch.cuda.current_stream(device)
             stream = ctypes.c_void_p(stream_obj.cuda_stream)
-            if mode == 'capacity' and not capturing and _pending:
-                _drain_pending()          # (reads host memory / queries events: not legal during stream capture)
             arr = (_lib.ExaRasterForwardJob * K)()
-            reports = None
-            if mode == 'capacity' and not capturing:
-                pool = _pool()
-                reports = []
-                ev_host = None
-                for k in range(K):
-                    r = _Report()
-                    r.stream = stream_obj
-                    if pool is not None:
-                        r.slot, r.tag, _dev = pool.take()
-                        r.event = r.host = r.row = None
-                    else:
-                        if ev_host is None:
-                            ev_host = (torch.cuda.Event(), torch.empty((K, 4), dtype=torch.int32, pin_memory=True))
-                        r.slot = r.tag = None
-                        r.event, r.host, r.row = ev_host[0], ev_host[1], k
-                    reports.append(r)
+            # capacity mode outside a capture: every job reports its header into a pinned-host slot (module docstring)
+            polled = mode == 'capacity' and not capturing
+            reports = [_hdr_pool.take()[:2] for _ in range(K)] if polled and _pool() is not None else None
             for k, j in enumerate(jobs):
                 j.keep = []
                 j.settings = _make_settings(j.rs, device, j.keep)
@@ -676,19 +549,18 @@ class _Rasterize(torch.autograd.Function):
                         cap = max(int(_seen_D[j.key] * config.capacity_growth), config.min_capacity)
                     j.capacity = (cap + 63) // 64 * 64
                     # ONE arena per render: splat records | tile workspace | bin workspace
-                    j.ws = torch.empty(j.gb + j.tb + int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes),
-                                       dtype=torch.uint8, device=device)
+                    j.ws = _workspace(j.gb + j.tb + int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes), device)
                     j.bin_ptr = j.ws.data_ptr() + j.gb + j.tb
                 else:
                     j.capacity = 0
-                    j.ws = torch.empty(j.gb + j.tb, dtype=torch.uint8, device=device)
+                    j.ws = _workspace(j.gb + j.tb, device)
                     j.bin_ptr = None
                 j.geom_ptr = j.ws.data_ptr()
                 j.tile_ptr = j.geom_ptr + j.gb
-                _fill_forward_job(arr[k], j, reports[k] if reports is not None else None)
-                if capturing and _capture_report is not None and k < len(_capture_report) and _capture_report[k] is not None:
-                    arr[k].host_header = _hdr_pool.dev_base + 16 * _capture_report[k][0]
-                    arr[k].header_tag = _capture_report[k][1]
+                rep = reports[k] if reports is not None else None
+                if capturing and _capture_report is not None and k < len(_capture_report):
+                    rep = _capture_report[k]          # a reserved slot, read by the owner of the graph after each replay
+                _fill_forward_job(arr[k], j, rep)
 
             if mode == 'exact':
                 _lib.check(lib.exa_raster_forward_bin_batch(arr, K, stream))
@@ -698,7 +570,7 @@ class _Rasterize(torch.autograd.Function):
                     j.capacity = max(int(hdr[k, 0]), 64)          # header reports whole 64-instance batch slots
                     j.need = int(hdr[k, 0])
                     _note(j.key, int(hdr[k, 0]))
-                    j.bins = torch.empty(int(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes), dtype=torch.uint8, device=device)
+                    j.bins = _workspace(_sizes(j.P, j.W, j.H, j.capacity).bin_bytes, device)
                     j.bin_ptr = j.bins.data_ptr()
                     arr[k].bin_ws, arr[k].capacity = j.bin_ptr, j.capacity
                 _lib.check(lib.exa_raster_forward_render_batch(arr, K, int(need_ctx), stream))
@@ -717,36 +589,10 @@ class _Rasterize(torch.autograd.Function):
                 else:
                     _overlap.pop(device.index, None)
                     _lib.check(lib.exa_raster_forward_batch(arr, K, int(need_ctx), stream))
-                if reports is not None:
-                    if reports[0].event is not None:             # fallback: 16-byte read-backs + one event
-                        hp = reports[0].host.data_ptr()
-                        for k, j in enumerate(jobs):
-                            _lib.check(lib.exa_raster_read_header_async(j.tile_ptr, hp + 16 * k, stream))
-                        reports[0].event.record(stream_obj)
-                    for r, j in zip(reports, jobs):
-                        r.tile_ptr = j.tile_ptr
-                    # every capacity-mode call is on the pending list until its reports are consumed -- by its own
-                    # backward, or by a later drain when no backward ever runs (no_grad, a skipped step, an unused output)
-                    rec = _Pending()
-                    rec.jobs, rec.reports, rec.store_ctx, rec.device = jobs, reports, need_ctx, device
-                    rec.done = rec.backward_done = False
-                    _pending.append(rec)
-                    if keep_keys:                 # (weak: rec.jobs -> job -> rec would be a cycle that keeps ~100 MB of
-                        wr = weakref.ref(rec)     #  workspaces alive until the cyclic collector runs)
-                        for j in jobs:
-                            j.rec = wr
-
-        if rec is not None and config.overflow_check == 'forward':
-            # the report landed about when the last launch above was queued: poll it now and repair an overflowed render
-            # before its outputs leave this function
-            with _on_device(device):
-                if _consume(rec, True, from_backward=True, in_forward=True):
-                    for j in rec.jobs:
-                        _verified[j.key] = _verified.get(j.key, 0) + 1
-                    try:
-                        _pending.remove(rec)
-                    except ValueError:
-                        pass
+                if polled:
+                    # the reports land about when the last launch above was queued: an overflowed render is repaired (or
+                    # raised about) HERE, before its outputs leave this function
+                    _settle(jobs, reports, need_ctx, device, stream_obj)
         if config.keep_debug:
             j = jobs[-1]
             _debug_last['tile'] = j.ws[j.gb:j.gb + j.tb]
@@ -771,7 +617,6 @@ class _Rasterize(torch.autograd.Function):
             ctx.K = K
             ctx.densify = densify
             ctx.shared = bool(shared) and K > 1
-            ctx.rec = rec
             ctx.jobs = jobs
             ctx.has = [tuple(t is not None for t in (j.sh, j.colors, j.scales, j.rot, j.cov)) for j in jobs]
             saved = []
@@ -808,27 +653,7 @@ class _Rasterize(torch.autograd.Function):
         n_live = K - sum(dead)
         arr = (_lib.ExaRasterBackwardJob * max(n_live, 1))()
         keep, ret, late, pos, sides = [], [None, None, None, None, None, None, None], [], 0, set()
-        rec = ctx.rec
         with _on_device(device):
-            if rec is not None and not rec.done:
-                # Capacity mode: did this render's forward have room?  Its report was written ~35 us into the forward, so
-                # it has normally landed by now; if not, wait for it or leave it to a later drain (config.overflow_check).
-                # An overflowed job is re-rendered HERE, before the backward kernels are queued on the repaired context.
-                block = config.overflow_check == 'always' or config.fixed_capacity is not None
-                if not block:
-                    for j in rec.jobs:
-                        if _verified.get(j.key, 0) < config.verify_calls or \
-                                _seen_D.get(j.key, 0) > config.danger_fill * j.capacity:
-                            block = True
-                            break
-                if _consume(rec, block, from_backward=True):
-                    for j in rec.jobs:
-                        _verified[j.key] = _verified.get(j.key, 0) + 1
-                    try:
-                        _pending.remove(rec)       # consumed: release its references now, not at the next drain
-                    except ValueError:
-                        pass
-                rec.backward_done = True
             for k in range(K):
                 j = ctx.jobs[k]
                 P, H, W, sh_M, nF = j.P, j.H, j.W, j.sh_M, j.nF
@@ -881,7 +706,7 @@ class _Rasterize(torch.autograd.Function):
                     if st is not None:          # (a pattern this kernel path does not add in place: summed below)
                         late += [(d, h) for d, h in zip((d_means3D, d_sh, d_colors, d_opac, d_scales, d_rot, d_cov), st[2])
                                  if d is not None and h is not None]
-                grad_ws = torch.empty(int(_sizes(P, W, H, j.capacity).grad_bytes), dtype=torch.uint8, device=device)
+                grad_ws = _workspace(_sizes(P, W, H, j.capacity).grad_bytes, device)
                 keep += [g_color, g_depth, g_alpha, grad_ws]
                 a = arr[pos]
                 pos += 1
@@ -942,14 +767,14 @@ class _Rasterize(torch.autograd.Function):
 class _CJob:
     """Host-side record of one composite render."""
     __slots__ = ('a', 'b', 'rs', 'settings', 'keep', 'planes', 'radii', 'ws', 'tile_ptr', 'bin_ptr', 'capacity', 'tb',
-                 'src_ptrs', 'report', 'key')
+                 'report', 'key')
 
 
 _side_streams = {}
 
 
 def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
-    """(Re-)run the forward of the composite jobs against the CURRENT workspaces of their sources.  ``sorted_event`` (inside a
+    """Run the forward of the composite jobs against the workspaces of their sources.  ``sorted_event`` (inside a
     stream capture): recorded when the sources' sorted lists were complete, BEFORE their blend was queued -- ranges and list
     merges then run on a side stream concurrently with that blend, and the composites' own blend follows the join."""
     lib = _lib.load()
@@ -960,15 +785,12 @@ def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
     for k, c in enumerate(cjobs):
         ja, jb = c.a, c.b
         c.capacity = ja.capacity + jb.capacity
-        if _COMPOSE_CAP_SCALE is not None:     # developer knob (tools/gpu_r04_o.sh): a composite buffer smaller than the sum
-            c.capacity = max(64, int(c.capacity * _COMPOSE_CAP_SCALE) // 64 * 64)
         sz = _lib.ExaRasterWorkspaceSizes()
         _lib.check(lib.exa_raster_compose_sizes(c.rs.image_width, c.rs.image_height, c.capacity, jb.capacity, ctypes.byref(sz)))
         c.tb = int(sz.tile_bytes)
-        c.ws = torch.empty(c.tb + int(sz.bin_bytes), dtype=torch.uint8, device=device)
+        c.ws = _workspace(c.tb + int(sz.bin_bytes), device)
         c.tile_ptr = c.ws.data_ptr()
         c.bin_ptr = c.tile_ptr + c.tb
-        c.src_ptrs = (ja.geom_ptr, jb.geom_ptr, ja.bin_ptr, jb.bin_ptr)
         a = arr[k]
         a.settings = ctypes.pointer(c.settings)
         a.P_a, a.P_b = ja.P, jb.P
@@ -986,12 +808,11 @@ def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
         c.report = None
         a.host_header, a.header_tag = None, 0
         if pool is not None:
-            r = _Report()
-            r.stream, r.event, r.host, r.row = stream_obj, None, None, None
-            r.slot, r.tag, dev_addr = pool.take()
-            r.tile_ptr = c.tile_ptr
-            a.host_header, a.header_tag = dev_addr, r.tag
-            c.report = r
+            # (the composite's report is never waited for: its buffer holds both sources' capacities, so it cannot overflow
+            #  once they did not; its backward reads the slot count from it if it has landed, _landed_need)
+            slot, tag, dev_addr = pool.take()
+            a.host_header, a.header_tag = dev_addr, tag
+            c.report = (slot, tag)
         elif capturing and _capture_report_c is not None and k < len(_capture_report_c) and _capture_report_c[k] is not None:
             a.host_header = _hdr_pool.dev_base + 16 * _capture_report_c[k][0]
             a.header_tag = _capture_report_c[k][1]
@@ -1091,28 +912,6 @@ class _Compose(torch.autograd.Function):
         arr = (_lib.ExaRasterBackwardJob * K)()
         keep, ret = [], [None, None, None, None, None, None]
         with _on_device(device):
-            # A composite cannot overflow by itself (its buffer holds both sources' capacities); it is incomplete exactly
-            # when a source overflowed.  The sources' reports are older than this render's, so they are looked at first;
-            # a source that gets re-rendered (config.on_overflow == 'retry') moves its workspaces, and the composite is
-            # then rendered again from the repaired lists before its backward kernels are queued.
-            redo = False
-            for c in cjobs:
-                for j in (c.a, c.b):
-                    rec = j.rec() if j.rec is not None else None
-                    if rec is not None and not rec.done:
-                        block = config.overflow_check == 'always' or config.fixed_capacity is not None or \
-                            _verified.get(j.key, 0) < config.verify_calls or _seen_D.get(j.key, 0) > config.danger_fill * j.capacity
-                        if _consume(rec, block, from_backward=True):
-                            for jj in rec.jobs:
-                                _verified[jj.key] = _verified.get(jj.key, 0) + 1
-                            try:
-                                _pending.remove(rec)
-                            except ValueError:
-                                pass
-                if c.src_ptrs != (c.a.geom_ptr, c.b.geom_ptr, c.a.bin_ptr, c.b.bin_ptr):
-                    redo = True
-            if redo:
-                _compose_launch(cjobs, True, device, False)
             side, n_stashed = None, 0
             if ctx.fold and config.overlap_composites and torch.cuda.is_current_stream_capturing():
                 side = _side_streams.get(device.index)

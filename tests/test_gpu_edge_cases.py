@@ -255,52 +255,14 @@ def _reset_config():
     exa.config.mode = 'exact'
     exa.config.fixed_capacity = None
     exa.config.on_overflow = 'retry'
-    exa.config.overflow_check = 'forward'       # the module default
 
 
-def test_overflowed_render_is_retried_in_backward_with_correct_gradients(dev):
-    """Capacity mode with a buffer that is far too small: the render's own backward finds the overflow in the header report,
-    re-runs the forward with the capacity the report names (outputs corrected in place) and returns the gradients of the
-    complete render -- equal to an exact-mode render bit for bit (the pipeline is deterministic)."""
-    assets, shape, cam = scenes.make_config('c1')
-    camd = {k: v.to(dev) for k, v in cam.items()}
-    G = torch.randn(3, *shape, generator=torch.Generator().manual_seed(5)).to(dev)
-    a_ref = _to(assets, dev)
-    ref = exa.GaussianRenderer()(a_ref, shape, camd, torch.ones(3, device=dev))
-    (ref['img'] * G).sum().backward()
-    try:
-        exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
-        exa.config.overflow_check = 'always'        # look at the report in backward (the forward never waits)
-        n0 = len(rz.overflow_events)
-        a = _to(assets, dev)
-        out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter('always')
-            (out['img'] * G).sum().backward()
-        assert any('re-rendered' in str(x.message) for x in w)
-        assert len(rz.overflow_events) == n0 + 1 and rz.overflow_events[-1][3] == 'retried'
-        torch.cuda.synchronize()
-        assert torch.equal(out['img'].detach(), ref['img'].detach())          # corrected in place
-        assert torch.equal(out['radius'], ref['radius'])
-        for k in KEYS:
-            assert torch.equal(a[k].grad, a_ref[k].grad), k
-        assert torch.equal(out['mean_2d'].grad, ref['mean_2d'].grad)
-        # strict mode: the same situation raises from backward, as before
-        exa.config.on_overflow = 'raise'
-        a2 = _to(assets, dev)
-        out2 = exa.GaussianRenderer()(a2, shape, camd, torch.ones(3, device=dev))
-        with pytest.raises(RuntimeError, match='overflow'):
-            out2['img'].sum().backward()
-        torch.cuda.synchronize()
-    finally:
-        _reset_config()
-
-
-def test_overflow_is_repaired_inside_forward_by_default(dev):
-    """``config.overflow_check = 'forward'`` (the default): the report is polled at the end of the render's own forward and an
-    overflowed render is repaired there -- the image the caller gets, a loss computed from it and the gradients are those of
-    the exact-mode render bit for bit, without any warning (nobody saw incomplete outputs); ``on_overflow = 'raise'`` raises
-    from the forward call."""
+@pytest.mark.parametrize('capacity', [64, 1024, -64])          # (-64: 64 instances short of what the render needs)
+def test_overflow_is_repaired_inside_forward(dev, capacity):
+    """Capacity mode with a buffer that is too small -- by far, or by one batch slot: the header report is polled at the end of
+    the render's own forward and the render is repaired there -- the image the caller gets, a loss computed from it and the
+    gradients are those of the exact-mode render bit for bit, without any warning (nobody saw incomplete outputs);
+    ``on_overflow = 'raise'`` raises from the forward call.  Training and ``no_grad`` renders alike."""
     assets, shape, cam = scenes.make_config('c1')
     camd = {k: v.to(dev) for k, v in cam.items()}
     G = torch.randn(3, *shape, generator=torch.Generator().manual_seed(5)).to(dev)
@@ -308,56 +270,63 @@ def test_overflow_is_repaired_inside_forward_by_default(dev):
     ref = exa.GaussianRenderer()(a_ref, shape, camd, torch.ones(3, device=dev))
     loss_ref = ((ref['img'] - G) ** 2).mean()          # a loss whose gradient depends on the image itself
     loss_ref.backward()
+    need = rz._seen_D[(dev.index or 0, assets['mean_3d'].shape[0], shape[0], shape[1])]
+    cap = capacity if capacity > 0 else need + capacity
     try:
-        assert exa.config.overflow_check == 'forward'
-        exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
+        exa.config.mode, exa.config.fixed_capacity = 'capacity', cap
         n0 = len(rz.overflow_events)
         a = _to(assets, dev)
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter('always')
             out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
             assert torch.equal(out['img'].detach(), ref['img'].detach())      # complete when the call returns
+            assert torch.equal(out['radius'], ref['radius'])
             loss = ((out['img'] - G) ** 2).mean()
             loss.backward()
         assert not [x for x in w if issubclass(x.category, RuntimeWarning)]
-        assert len(rz.overflow_events) == n0 + 1 and rz.overflow_events[-1][3] == 'retried'
+        assert len(rz.overflow_events) == n0 + 1 and rz.overflow_events[-1][1:] == (need, cap, 'retried')
         assert float(loss) == float(loss_ref)
         for k in KEYS:
             assert torch.equal(a[k].grad, a_ref[k].grad), k
         assert torch.equal(out['mean_2d'].grad, ref['mean_2d'].grad)
-        assert not rz._pending
         with torch.no_grad():                                                  # also without autograd
             out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
-        assert torch.equal(out['img'], ref['img'].detach())
+        assert torch.equal(out['img'], ref['img'].detach()) and torch.equal(out['depthmap'], ref['depthmap'].detach())
         exa.config.on_overflow = 'raise'
         with pytest.raises(RuntimeError, match='overflow'):
             exa.GaussianRenderer()(_to(assets, dev), shape, camd, torch.ones(3, device=dev))
+        with pytest.raises(RuntimeError, match='overflow'), torch.no_grad():
+            exa.GaussianRenderer()(_to(assets, dev, grad=False), shape, camd, torch.ones(3, device=dev))
+        assert rz.overflow_events[-1][3] == 'raised'
         torch.cuda.synchronize()
     finally:
         _reset_config()
 
 
-def test_overflowed_no_grad_render_is_rerendered_when_drained(dev):
-    assets, shape, cam = scenes.make_config('c1')
-    camd = {k: v.to(dev) for k, v in cam.items()}
-    a = _to(assets, dev, grad=False)
-    with torch.no_grad():
-        ref = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
+def test_overflow_of_one_job_of_a_batch_is_repaired(dev):
+    """A batched call (three views of one model, one launch per stage) whose SECOND job alone overflows: that job is
+    re-rendered by itself, the batch's images and the summed gradients equal three exact-mode renders bit for bit."""
+    H, W, f, P = 160, 192, 220.0, 6000
+    assets = scenes.dist_a_random(P, H, W, seed=51, focal=f)
+    cams = [{k: v.to(dev) for k, v in scenes.ring_camera(H, W, k, 8, focal=f).items()} for k in range(3)]
+    G = torch.randn(3, H, W, generator=torch.Generator().manual_seed(52)).to(dev)
+    a_ref = _to(assets, dev)
+    refs = exa.render_views(exa.GaussianRenderer(), a_ref, (H, W), cams)
+    sum((o['img'] * G).sum() for o in refs).backward()
+    need = rz._seen_D[(dev.index or 0, P, H, W)]
     try:
-        exa.config.mode, exa.config.fixed_capacity = 'capacity', 1024
-        exa.config.overflow_check = 'always'        # (the default repairs it inside the forward call already)
-        with torch.no_grad():
-            out = exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
-        with warnings.catch_warnings(record=True):
-            warnings.simplefilter('always')
-            exa.check_overflow()
-        torch.cuda.synchronize()
-        assert torch.equal(out['img'], ref['img']) and torch.equal(out['depthmap'], ref['depthmap'])
-        exa.config.on_overflow = 'raise'
-        with torch.no_grad():
-            exa.GaussianRenderer()(a, shape, camd, torch.ones(3, device=dev))
-        with pytest.raises(RuntimeError, match='overflow'):
-            exa.check_overflow()
+        exa.config.mode, exa.config.fixed_capacity = 'capacity', [2 * need, 64, 2 * need]
+        n0 = len(rz.overflow_events)
+        a = _to(assets, dev)
+        outs = exa.render_views(exa.GaussianRenderer(), a, (H, W), cams)
+        assert len(rz.overflow_events) == n0 + 1 and rz.overflow_events[-1][3] == 'retried'
+        for o, r in zip(outs, refs):
+            assert torch.equal(o['img'].detach(), r['img'].detach())
+        sum((o['img'] * G).sum() for o in outs).backward()
+        for k in KEYS:
+            assert torch.equal(a[k].grad, a_ref[k].grad), k
+        for o, r in zip(outs, refs):
+            assert torch.equal(o['mean_2d'].grad, r['mean_2d'].grad)
     finally:
         _reset_config()
 
@@ -365,7 +334,7 @@ def test_overflowed_no_grad_render_is_rerendered_when_drained(dev):
 def test_two_sets_of_equal_size_alternate_without_errors(dev):
     """Two Gaussian sets with the SAME P (so they share the capacity memo keyed on (P, H, W)) whose instance counts differ
     by > 3x, rendered alternately in 'auto' mode: the first render of the dense set overflows the memo of the sparse one,
-    is retried inside its backward, and from then on the memo covers both -- no RuntimeError, gradients always those of
+    is repaired inside its forward, and from then on the memo covers both -- no RuntimeError, gradients always those of
     the exact-mode render."""
     H, W, f, P = 160, 192, 220.0, 6000
     sparse = scenes.dist_a_random(P, H, W, seed=51, focal=f)
@@ -383,7 +352,6 @@ def test_two_sets_of_equal_size_alternate_without_errors(dev):
     try:
         exa.config.mode = 'auto'
         rz._seen_D.clear()
-        rz._verified.clear()
         n0 = len(rz.overflow_events)
         with warnings.catch_warnings(record=True):
             warnings.simplefilter('always')
