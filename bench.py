@@ -281,7 +281,6 @@ def main():
     for _ in range(3):
         raster_step(c0, 0)
     torch.cuda.synchronize()
-    exa.check_overflow()
     if launch == 'graph':
         try:
             side = torch.cuda.Stream()
@@ -291,7 +290,6 @@ def main():
                     raster_step(c0, 0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            exa.check_overflow()
             use_switch = cam_mode == 'graph' and KV == 1
             for b, c in enumerate(ctxs):
                 c['graph'] = torch.cuda.CUDAGraph()
@@ -362,8 +360,14 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    exa.check_overflow()
 
+    # every rank reports what ITS communicator says (world size, its device): the driver's SCALE line can be checked against it
+    rank_info = {'rank': rank, 'world_size': dist.get_world_size() if world > 1 else 1, 'device': torch.cuda.current_device(),
+                 'device_name': torch.cuda.get_device_name(device), 'views': len(my_views)}
+    ranks = [rank_info]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, rank_info)
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -399,7 +403,8 @@ def main():
                                       % (world, n_float * 4),
                        'mean_instances_D': D_mean, 'mean_subtile_instances': I_mean, 'mean_visible_V': V_mean},
             'rccl': {'world_size': dist.get_world_size() if world > 1 else 1,
-                     'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if world > 1 else None},
+                     'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if world > 1 else None,
+                     'ranks': ranks},
         }
 
     single = S == 1 and KV == 1 and world == 1
@@ -412,7 +417,6 @@ def main():
                 result[name] = fn()
             except Exception as e:  # noqa: BLE001
                 result[name] = {'error': str(e)[:200]}
-        exa.check_overflow()
         # what the gap BETWEEN two graph launches costs the headline (rocprofv3 kernel trace: ~8 us from the last kernel of one
         # replay to the first of the next, of a 151 us step): the same step, four to a recorded graph
         if in_graph_switch['on'] and train:
@@ -440,7 +444,6 @@ def main():
                     'steps_per_replay': U, 'value': n_rep * U / dt, 'unit': 'iters/s', 'ms_per_step': dt / (n_rep * U) * 1e3,
                     'what': 'the headline step, %d of them (consecutive views) recorded into ONE hipGraph: what is left when the '
                             'gap between two graph launches is paid once per %d steps; NOT the headline protocol' % (U, U)}
-                exa.check_overflow()
             except Exception as e:  # noqa: BLE001
                 result['extra_steps_per_replay'] = {'error': str(e)[:200]}
 
@@ -778,7 +781,6 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
             if how == 'graphed':
                 out[how]['what'] = ('exa.GraphedIteration: one hipGraph for the five forwards, one for their backwards, same '
                                     'loss in PyTorch between them; captures=%d' % graphed.captures)
-        exa.check_overflow()
         return out
     finally:
         exa.config.mode, exa.config.fixed_capacity = saved

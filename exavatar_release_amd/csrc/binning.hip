@@ -281,45 +281,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
 // Exact footprint test.  The sub-tile rect of a splat (preprocess_fwd.hip) is the bounding box of {alpha >= 1/255}; an
 // ellipse leaves the corners of its box empty, and for avatar-sized splats (a box of 2x3 sub-tiles) that is 20 % of all
 // (splat, sub-tile) instances (C3 view 0: 893 k -> 709 k).  A sub-tile whose 8x8 pixel centres all fail the per-pixel
-// alpha test contributes nothing to the image or to any gradient, so it never enters a list.
-// Per ROW of sub-tiles (a band of 8 pixel rows, dy in [yl, yh] relative to the splat centre) the part of the ellipse
-//   f(d) = A dx^2 + B dx dy + C dy^2 >= thr      (log2 domain, conic pre-scaled as in blend.h; A, C < 0, thr < 0)
-// inside the band is convex, so the sub-tiles it reaches are exactly those whose pixel-centre range [xl, xl + 7] meets its
-// x-extent [xa, xb].  On the line dy = y0 the ellipse spans  kA y0 -+ sqrt(X2 - D4 y0^2)  (kA = -B / 2A, X2 = thr / A,
-// D4 = (4AC - B^2) / 4A^2); its rightmost (leftmost) point overall lies at dy = +ysr (-ysr), ysr = kC Xf with kC = -B / 2C and
-// Xf the half extent in x; the right (left) end of the band's part is the line point at y0 = clamp(+ysr (-ysr), yl, yh).
-// O(1) per row instead of a test per sub-tile -- a large scene splat crosses up to 64 sub-tiles of a cell.
-// Conservative: thr is relaxed by 1e-3 + 1e-5 * (a bound of the term magnitudes) to cover the rounding of the per-pixel
-// evaluation, the interval by 1e-3 (1 + |x|) px for the arithmetic here (tools/footprint_check.py compares this
-// arithmetic with the per-pixel rule by brute force); NaN / degenerate conics keep the whole rect.
-struct Footprint { float kA, ysr, X2, D4; bool test; };
-__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
-// xm, ym: the largest |pixel - centre| inside the part of the rect the caller is going to ask about
-__device__ __forceinline__ Footprint make_footprint(const uint4& r1, float xm, float ym) {
-    Footprint f;
-    const float A = __uint_as_float(r1.x), B = __uint_as_float(r1.y), C = __uint_as_float(r1.z);
-    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
-    const float As = A - 0.25f * B * B * rC;                    // f along the line of the x-extreme points: As dx^2
-    f.test = A < 0.f && C < 0.f && As < 0.f;                    // anything else (never for a visible splat): keep the rect
-    const float mag = fabsf(A) * xm * xm + fabsf(B) * xm * ym + fabsf(C) * ym * ym;
-    const float thr = -__log2f(255.0f * __uint_as_float(r1.w)) - 1e-3f - 1e-5f * mag;   // alpha >= 1/255 <=> f >= -log2(255 o)
-    f.kA = -0.5f * B * rA;
-    f.ysr = -0.5f * B * rC * __builtin_amdgcn_sqrtf(thr * __builtin_amdgcn_rcpf(As));
-    f.X2 = thr * rA;
-    f.D4 = C * As * rA * rA;
-    return f;
-}
-// x-extent of the footprint inside the band [yl, yl + 7]; false: the band misses it
-__device__ __forceinline__ bool footprint_row(const Footprint& f, float yl, float& xa, float& xb) {
-    const float yh = yl + (float)(SUB - 1);
-    const float yR = clampf(f.ysr, yl, yh), yL = clampf(-f.ysr, yl, yh);
-    const float hR2 = f.X2 - f.D4 * yR * yR, hL2 = f.X2 - f.D4 * yL * yL;
-    if (hR2 < 0.f || hL2 < 0.f) return false;
-    xb = f.kA * yR + __builtin_amdgcn_sqrtf(hR2);
-    xa = f.kA * yL - __builtin_amdgcn_sqrtf(hL2);
-    return true;
-}
-
+// alpha test contributes nothing to the image or to any gradient, so it never enters a list.  Per ROW of sub-tiles (a band
+// of 8 pixel rows) the sub-tiles the ellipse reaches are those whose pixel-centre range meets its x-extent inside the band
+// (common.h: make_footprint / footprint_band): O(1) per row instead of a test per sub-tile -- a large scene splat crosses up
+// to 64 sub-tiles of a cell.
 // CHUNK Gaussians per workgroup: (a) Gaussian-major instance offsets (in-chunk prefix + chunk_off) stored
 // into the splat record, (b) 16-byte entries scattered into their cells' buckets: the chunk's first slot in
 // every cell comes from the scanned count matrix, ranks inside it from LDS atomics, (c) clears this
@@ -588,14 +553,16 @@ __device__ __forceinline__ unsigned long long entry_mask(const Splat* __restrict
     const int x0 = max((int)(en.z & 0xffff) - csx0, 0), x1 = min((int)(en.z >> 16) - csx0, CELL_SUBS);
     const int y0 = max((int)(en.w & 0xffff) - csy0, 0), y1 = min((int)(en.w >> 16) - csy0, CELL_SUBS);
     const float xl0 = (float)((csx0 + x0) * SUB) - __uint_as_float(r0.x), yl0 = (float)((csy0 + y0) * SUB) - __uint_as_float(r0.y);
-    const Footprint fp = make_footprint(r1, fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
+    const Footprint fp = make_footprint(__uint_as_float(r1.x), __uint_as_float(r1.y), __uint_as_float(r1.z), __uint_as_float(r1.w),
+                                        fmaxf(fabsf(xl0), fabsf(xl0 + (float)((x1 - x0) * SUB))),
                                         fmaxf(fabsf(yl0), fabsf(yl0 + (float)((y1 - y0) * SUB))));
     unsigned long long mask = 0ull;
     for (int y = y0; y < y1; ++y) {
         int c0 = x0, c1 = x1 - 1;
         if (fp.test) {
             float xa, xb;
-            if (!footprint_row(fp, yl0 + (float)((y - y0) * SUB), xa, xb)) continue;
+            const float yl = yl0 + (float)((y - y0) * SUB);
+            if (!footprint_band(fp, yl, yl + (float)(SUB - 1), xa, xb)) continue;
             if (xa <= xb) {                                     // (NaN: keep the row)
                 const float m = 1e-3f * (1.0f + fmaxf(fabsf(xa), fabsf(xb)));
                 const float lo = clampf((xa - m - (float)(SUB - 1) - xl0) * (1.0f / SUB), -1.0e6f, 1.0e6f);

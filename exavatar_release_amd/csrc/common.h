@@ -248,6 +248,40 @@ __device__ __forceinline__ float gauss_power2(float A, float B, float C, float d
 }
 __device__ __forceinline__ float gauss_falloff2(float power2) { return __builtin_amdgcn_exp2f(power2); }
 
+// ---- exact footprint arithmetic (binning.hip: which sub-tiles of a cell does a splat reach) ----
+// The part of the ellipse  f(d) = A dx^2 + B dx dy + C dy^2 >= thr  (log2 domain, conic pre-scaled as in blend.h; A, C < 0,
+// thr < 0; d = pixel - centre) inside a horizontal band dy in [yl, yh] is convex, so the pixel columns it reaches are exactly
+// those that meet its x-extent [xa, xb].  On the line dy = y0 the ellipse spans  kA y0 -+ sqrt(X2 - D4 y0^2)  (kA = -B / 2A,
+// X2 = thr / A, D4 = (4AC - B^2) / 4A^2); its rightmost (leftmost) point overall lies at dy = +ysr (-ysr), ysr = kC Xf with
+// kC = -B / 2C and Xf the half extent in x; the right (left) end of the band's part is the line point at y0 = clamp(+ysr
+// (-ysr), yl, yh).  Conservative: thr is relaxed by 1e-3 + 1e-5 * (a bound of the term magnitudes) to cover the rounding of
+// the per-pixel evaluation, the callers relax the interval by 1e-3 (1 + |x|) px for the arithmetic here (tools/footprint_check.py
+// compares this arithmetic with the per-pixel rule by brute force); NaN / degenerate conics keep everything.
+struct Footprint { float kA, ysr, X2, D4; bool test; };
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }
+// (A, B, C, opacity) = row 1 of the splat record; xm, ym: the largest |pixel - centre| inside the region the caller asks about
+__device__ __forceinline__ Footprint make_footprint(float A, float B, float C, float opacity, float xm, float ym) {
+    Footprint f;
+    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+    const float As = A - 0.25f * B * B * rC;                    // f along the line of the x-extreme points: As dx^2
+    f.test = A < 0.f && C < 0.f && As < 0.f;                    // anything else (never for a visible splat): keep everything
+    const float mag = fabsf(A) * xm * xm + fabsf(B) * xm * ym + fabsf(C) * ym * ym;
+    const float thr = -__log2f(255.0f * opacity) - 1e-3f - 1e-5f * mag;   // alpha >= 1/255 <=> f >= -log2(255 o)
+    f.kA = -0.5f * B * rA;
+    f.ysr = -0.5f * B * rC * __builtin_amdgcn_sqrtf(thr * __builtin_amdgcn_rcpf(As));
+    f.X2 = thr * rA;
+    f.D4 = C * As * rA * rA;
+    return f;
+}
+// x-extent of the footprint inside the band [yl, yh]; false: the band misses it
+__device__ __forceinline__ bool footprint_band(const Footprint& f, float yl, float yh, float& xa, float& xb) {
+    const float yR = clampf(f.ysr, yl, yh), yL = clampf(-f.ysr, yl, yh);
+    const float hR2 = f.X2 - f.D4 * yR * yR, hL2 = f.X2 - f.D4 * yL * yL;
+    if (hR2 < 0.f || hL2 < 0.f) return false;
+    xb = f.kA * yR + __builtin_amdgcn_sqrtf(hR2);
+    xa = f.kA * yL - __builtin_amdgcn_sqrtf(hL2);
+    return true;
+}
 // Wave-private LDS hand-off (one wave writes, the same wave reads other lanes' data): LDS operations of
 // one wave execute in order; this stops the compiler from reordering across it and drains the LDS
 // counter ONLY (no vmcnt wait, so global prefetches stay in flight across it).

@@ -63,7 +63,8 @@ def _quat_to_matrix(q):
 
 
 def densify_and_prune(params, optimizer, grad_accum, track_cnt, *, grad_thr, extent, dense_percent=0.01, opacity_min=0.005,
-                      prune_big=False, split_factor=2, generator=None, rotation_to_matrix=None):
+                      prune_big=False, split_factor=2, generator=None, rotation_to_matrix=None, radius_max=None,
+                      screen_size_max=None, reference_radius_reset=True):
     """Clone / split / prune one set of Gaussians and carry the optimizer state along -- what the reference's
     ``SceneGaussian.densify_and_prune`` does with its Adam-state surgery (``avatar/common/nets/module.py:17-72,159-240``),
     restated for a plain dict of parameters and any ``torch.optim`` optimizer with per-parameter state tensors.
@@ -79,6 +80,13 @@ def densify_and_prune(params, optimizer, grad_accum, track_cnt, *, grad_thr, ext
     divided by ``0.8 * split_factor``) and removed; then everything with opacity ``< opacity_min`` (and, with
     ``prune_big``, max scale ``> 0.1 * extent``) is pruned.  Row order of the result: surviving originals, clones,
     split samples.  New rows start with zero optimizer state.  ``generator``: see :func:`synchronised_generator`.
+
+    Screen-space prune (``prune_big`` with ``radius_max`` [P] and ``screen_size_max``; the reference passes 20 px once
+    ``cur_itr > opacity_reset_interval``, ``avatar/main/model.py:288-289``): the reference tests ``self.radius_max >
+    screen_size_max`` AFTER ``clone_points`` / ``split_points``, whose ``densify()`` has just replaced ``radius_max`` by zeros
+    for EVERY row (module.py:223) -- the test can never fire there.  ``reference_radius_reset=True`` (default) reproduces
+    that (topology identical to the reference's); ``False`` applies the criterion the code evidently intends (upstream
+    3DGS): surviving originals keep their ``radius_max``, new rows start at zero.
 
     Returns ``(new_params, n_cloned, n_split, n_pruned)``; the caller allocates fresh statistics of the new length (the
     reference zeroes them in ``densify``, module.py:223-225)."""
@@ -110,6 +118,10 @@ def densify_and_prune(params, optimizer, grad_accum, track_cnt, *, grad_thr, ext
         drop = torch.sigmoid(new['opacity'])[:, 0] < opacity_min
         if prune_big:
             drop |= torch.exp(new['scale']).max(1).values > 0.1 * extent
+            if radius_max is not None and screen_size_max and not reference_radius_reset:
+                r_new = torch.zeros(src.numel(), dtype=torch.float32, device=src.device)
+                r_new[:keep_rows.numel()] = radius_max.reshape(-1).to(torch.float32)[keep_rows]
+                drop |= r_new > float(screen_size_max)
         valid = ~drop
         src = src[valid]
         out = {}

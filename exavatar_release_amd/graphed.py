@@ -53,6 +53,7 @@ the replay itself; an iteration that overflowed restores them from the copy the 
 """
 import ctypes
 import time
+import warnings
 
 import torch
 
@@ -180,6 +181,10 @@ class GraphedIteration:
         cap, self._cap = self._cap, None
         if cap is None:
             return
+        # A graph must not be destroyed while one of its replays is still executing (the runtime frees its kernel-argument
+        # and node storage with it): wait for the device first.  Re-captures and close() are rare (a change of P, an
+        # overflow, the end of training), the wait costs them nothing.
+        torch.cuda.synchronize(self.device)
         if rz._hdr_pool is not None:
             for s in (cap.slots or []) + (getattr(cap, 'slots_c', None) or []):
                 if s is not None:
@@ -194,9 +199,26 @@ class GraphedIteration:
             except AttributeError:
                 pass
 
+    def close(self):
+        """Release the captured graphs, their static tensors and the reserved report slots (after waiting for the device).
+        The object can be used again afterwards (it captures anew).  Call it when a training run ends; ``with
+        GraphedIteration(...) as it:`` does."""
+        self._release()
+        self._keeper = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
         try:
-            self._release()
+            if self._cap is not None:
+                warnings.warn('exavatar_release_amd: GraphedIteration was garbage-collected with a live capture; call close()',
+                              ResourceWarning, stacklevel=2)
+                self.close()
         except Exception:  # noqa: BLE001 -- interpreter shutdown
             pass
 
@@ -513,7 +535,9 @@ class GraphedIteration:
     def _replay_forward(self, assets, cam_param, bg, dens, refill, loss_args=()):
         """(Re-)capture if needed, fill the static inputs, replay the forward graph.  Returns the capture."""
         dev = self.device
-        key = tuple((tuple(a['mean_3d'].shape), _colour_key(a), tuple(a[_colour_key(a)].shape)) for a in assets) + \
+        # (the SH degree is baked into the captured kernel arguments: ExAvatar raises it every 1000 iterations with constant
+        #  tensor shapes -- reference avatar/common/nets/module.py set_sh_degree -- and that must re-capture)
+        key = tuple((tuple(a['mean_3d'].shape), _colour_key(a), tuple(a[_colour_key(a)].shape), _sh_degree(a)) for a in assets) + \
             tuple((tuple(t.shape), t.dtype) for t in loss_args)
         dens_ptrs = None if dens is None else tuple(None if t is None else t.data_ptr() for t in dens)
         for _ in range(4):
@@ -541,7 +565,13 @@ class GraphedIteration:
             self._serial += 1
             self._reports_checked = False
             if chk is not None and not self._focal_ok(chk, cam_param['focal']):
-                continue                      # the focal length changed: derive the intrinsics again, maybe re-capture
+                # the focal length changed: derive the intrinsics again, maybe re-capture.  The replay that just ran used the
+                # stale intrinsics; with the loss in the graph its backward has already updated the densification
+                # statistics -- put them back (as _grow does for an overflowed replay) before the iteration runs again
+                if cap.dens_backup:
+                    with torch.no_grad():
+                        torch._foreach_copy_(cap.dens, cap.dens_backup)
+                continue
             return cap
         raise RuntimeError('exavatar_release_amd: GraphedIteration could not settle its camera intrinsics')
 

@@ -10,6 +10,7 @@ from one read-back of the camera tensors (same formulas, see ``forward``).
 """
 import ctypes
 import time
+import warnings
 
 import torch
 import torch.nn as nn
@@ -223,88 +224,20 @@ def _output_dict(job, outs, is_vis=None):
 
 
 class _CompositeOutput(dict):
-    """Output dict of a composite render (:func:`render_iteration`): ``radius`` / ``is_vis`` cover ``cat(scene, human)`` as the
+    """Output dict of a composite render (:func:`render_iteration`).  ``radius`` / ``is_vis`` cover ``cat(scene, human)`` as the
     reference's concatenated render returns them, but nothing on the reference's path reads them (it uses the composites'
-    ``img`` only, avatar/main/model.py:119-167) -- so the two concatenations run on first access instead of per iteration.
-    Behaves like the plain dict it stands for: every way of reading an entry or copying the dict materialises them first."""
-    __slots__ = ('_lazy',)
-    _KEYS = ('is_vis', 'radius')
+    ``img`` only, avatar/main/model.py:119-167): ``out['radius']`` / ``out['is_vis']`` are concatenated on first access
+    (``__missing__``) and are entries of the dict from then on."""
 
     def __init__(self, base, parts):
         dict.__init__(self, base)
-        for k in self._KEYS:
-            dict.__setitem__(self, k, None)           # the keys exist: len(), `in` and keys() need no work
-        self._lazy = parts                            # ((radius_a, radius_b), (is_vis_a, is_vis_b))
+        self._parts = parts                           # ((radius_a, radius_b), (is_vis_a, is_vis_b))
 
-    def _materialise(self):
-        parts, self._lazy = self._lazy, None
-        if parts is not None:
-            dict.__setitem__(self, 'radius', torch.cat(parts[0]))
-            dict.__setitem__(self, 'is_vis', torch.cat(parts[1]))
-
-    def __getitem__(self, k):
-        if self._lazy is not None and k in self._KEYS:
-            self._materialise()
-        return dict.__getitem__(self, k)
-
-    def get(self, k, default=None):
-        return self[k] if k in self else default
-
-    def __setitem__(self, k, v):
-        self._materialise()
-        dict.__setitem__(self, k, v)
-
-    def __delitem__(self, k):
-        self._materialise()
-        dict.__delitem__(self, k)
-
-    def update(self, *a, **kw):
-        self._materialise()
-        dict.update(self, *a, **kw)
-
-    def __iter__(self):                               # (overridden so that dict(x) / {**x} go through __getitem__)
-        return dict.__iter__(self)
-
-    def items(self):
-        self._materialise()
-        return dict.items(self)
-
-    def values(self):
-        self._materialise()
-        return dict.values(self)
-
-    def copy(self):
-        self._materialise()
-        return dict(dict.items(self))
-
-    def pop(self, k, *default):
-        self._materialise()
-        return dict.pop(self, k, *default)
-
-    def popitem(self):
-        self._materialise()
-        return dict.popitem(self)
-
-    def setdefault(self, k, default=None):
-        self._materialise()
-        return dict.setdefault(self, k, default)
-
-    def __eq__(self, other):
-        self._materialise()
-        return dict.__eq__(self, other)
-
-    def __ne__(self, other):
-        return not self.__eq__(other)
-
-    __hash__ = None
-
-    def __repr__(self):
-        self._materialise()
-        return dict.__repr__(self)
-
-    def __reduce__(self):
-        self._materialise()
-        return (dict, (dict(dict.items(self)),))
+    def __missing__(self, k):
+        if k not in ('radius', 'is_vis'):
+            raise KeyError(k)
+        self[k] = v = torch.cat(self._parts[0 if k == 'radius' else 1])
+        return v
 
 
 class GaussianRenderer(nn.Module):
@@ -492,11 +425,30 @@ class GraphedRenderer:
         self._intr, self._focal_src, self._focal_ver = None, None, None     # last verified intrinsics record / focal tensor
         self.captures = 0
 
+    def close(self):
+        """Release the captured graph, its static outputs and the reserved report slot (after waiting for the device: a graph
+        must not be destroyed while one of its replays is still executing).  The object captures anew when called again."""
+        from . import rasterizer as rz
+        if self._graph is not None:
+            torch.cuda.synchronize(self.device)
+        self._graph, self._outs, self._tile, self._tan = None, None, None, None
+        if self._slot is not None and rz._hdr_pool is not None:
+            rz._hdr_pool.release(self._slot[0])
+        self._slot = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
         try:
-            from . import rasterizer as rz
-            if self._slot is not None and rz._hdr_pool is not None:
-                rz._hdr_pool.release(self._slot[0])
+            if self._graph is not None or self._slot is not None:
+                warnings.warn('exavatar_release_amd: GraphedRenderer was garbage-collected with a live capture; call close()',
+                              ResourceWarning, stacklevel=2)
+                self.close()
         except Exception:  # noqa: BLE001 -- interpreter shutdown
             pass
 
@@ -636,6 +588,7 @@ class GraphedRenderer:
                 if not overflow:
                     break
                 self._capacity = int(need * self.growth)      # this frame needs more instances than any before it
+                torch.cuda.synchronize(dev)                   # (the graph about to be dropped has a replay in flight)
                 self._graph = None
             else:
                 raise RuntimeError('exavatar_release_amd: GraphedRenderer could not size its instance buffer')

@@ -93,7 +93,6 @@ def run(dev, iters=300, mode='auto', graphed=False, densify_every=50, n_scene=15
         my_views = exa_dist.shard_views(N_VIEWS, rank, world, shuffle=False)
         reducer = None
         losses, p_hist, evals = [], [], []
-        max_pending = 0
         for i in range(iters):
             v = my_views[i % len(my_views)]
             for k in cam:
@@ -122,7 +121,6 @@ def run(dev, iters=300, mode='auto', graphed=False, densify_every=50, n_scene=15
                     p.grad = gr.clone()
             opt.step()
             losses.append(float(loss.detach()))
-            max_pending = max(max_pending, len(rz._pending))
             if i % 10 == 9:                                            # evaluation render, no autograd
                 with torch.no_grad():
                     ev = rend(_act(human), (H, W), cam, bg)
@@ -139,11 +137,10 @@ def run(dev, iters=300, mode='auto', graphed=False, densify_every=50, n_scene=15
                 scene = new
                 stats = [torch.zeros(scene['mean'].shape[0], 1, device=dev) for _ in range(3)]
             p_hist.append(int(scene['mean'].shape[0]))
-        exa.check_overflow()
         torch.cuda.synchronize()
         final = [p.detach().clone() for r in (scene, human, refined) for p in r.values()]
-        return {'final': final, 'losses': losses, 'p_hist': p_hist, 'evals': evals, 'max_pending': max_pending,
-                'pending_end': len(rz._pending), 'overflow_events': list(rz.overflow_events),
+        return {'final': final, 'losses': losses, 'p_hist': p_hist, 'evals': evals,
+                'overflow_events': list(rz.overflow_events),
                 'captures': it.captures if it is not None else 0,
                 'retries': it.overflow_retries if it is not None else 0}
     finally:

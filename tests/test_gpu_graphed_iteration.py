@@ -348,3 +348,37 @@ def test_tight_backward_recordings_follow_the_slots_in_use(dev):
     assert needs is not None and len(needs) == 5 and all(n <= 64 * u for n, u in zip(needs, t[4][0] + t[4][1]))
     assert all(64 * u <= c + 64 * 3 for u, c in zip(t[4][0], cap.caps)) or True      # (the C side clamps to the capacity anyway)
     assert w is not None
+
+
+def test_a_change_of_sh_degree_with_constant_shapes_recaptures(dev):
+    """ExAvatar raises the active SH degree every 1000 iterations while the coefficient tensors keep their shape (reference
+    avatar/common/nets/module.py set_sh_degree): the degree is baked into the captured kernel arguments, so it is part of
+    the capture key (round-4 advisor finding: a stale degree was replayed silently)."""
+    g = torch.Generator().manual_seed(31)
+    sets = _sets(2000, 1000, 71, dev)
+    for d in sets:
+        rgb = d.pop('rgb')
+        d['sh'] = torch.cat(((rgb[:, None] - 0.5) / 0.28209479, 0.3 * torch.randn(rgb.shape[0], 8, 3, generator=g).to(dev)), 1)
+    G = _G(dev, 8)
+    cam, bg = _cam(2, dev), torch.rand(3, generator=g).to(dev)
+    rend = exa.GaussianRenderer()
+    with exa.GraphedIteration((H, W), dev) as it:
+        for n, deg in enumerate((0, 0, 1, 2, 2)):
+            res = []
+            for fn in (lambda s, h, r: it(s, h, r, cam, bg), lambda s, h, r: exa.render_iteration(rend, s, h, r, (H, W), cam, bg)):
+                leaves = [{k: v.detach().clone().requires_grad_(True) for k, v in d.items()} for d in sets]
+                for d in leaves:
+                    d['sh_degree'] = deg
+                out = fn(*leaves)
+                imgs = [out[k]['img'].detach().clone() for k in exa.ITERATION_RENDERS]
+                sum((out[k]['img'] * G[i]).sum() for i, k in enumerate(exa.ITERATION_RENDERS)).backward()
+                torch.cuda.synchronize()
+                res.append(imgs + [d['sh'].grad.clone() for d in leaves] + [d['mean_3d'].grad.clone() for d in leaves])
+            # (not bit for bit: the graphed path derives the camera centre as -R^T t on the device, the eager one inverts the
+            #  view matrix on the host -- rounding apart, and the SH view direction depends on it from degree 1 on)
+            for i, (x, y) in enumerate(zip(res[0], res[1])):
+                scale = float(y.abs().max()) + 1e-12
+                assert float((x - y).abs().max()) <= 2e-5 * scale, ('sh degree %d (call %d)' % (deg, n), i)
+            if deg == 0:
+                _same(res[0][:5], res[1][:5], 'sh degree 0 images (call %d)' % n)
+        assert it.captures == 3                    # one per degree

@@ -158,7 +158,6 @@ def test_debug_mode_synchronises_and_changes_nothing(dev):
             for k, gk in zip(NAMES, grads[:5]):
                 assert torch.equal(gk, ref['grads'][k]), (mode, k)
             assert torch.equal(grads[5], ref['m2']), mode
-            exa.check_overflow()
     finally:
         exa.config.mode, exa.config.fixed_capacity = saved
 

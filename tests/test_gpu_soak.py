@@ -42,9 +42,9 @@ def _same(a, b, what):
 
 
 def test_soak_auto_and_graphed_equal_exact_bit_for_bit(dev):
-    rz._seen_D.clear(); rz._verified.clear()
+    rz._seen_D.clear()
     exact = _soak.run(dev, iters=300, mode='exact')
-    rz._seen_D.clear(); rz._verified.clear()
+    rz._seen_D.clear()
     pool = rz._pool()
     ring0 = pool.next if pool is not None else 0
     auto = _soak.run(dev, iters=300, mode='auto', forget_every=37)
@@ -55,22 +55,20 @@ def test_soak_auto_and_graphed_equal_exact_bit_for_bit(dev):
     kinds = [e[3] for e in auto['overflow_events']]
     assert kinds and set(kinds) == {'retried'}, kinds
     assert not exact['overflow_events']
-    # nothing accumulates: no pending reports during or after the loop, the slot ring just wraps
-    assert auto['max_pending'] <= 2 and auto['pending_end'] == 0, (auto['max_pending'], auto['pending_end'])
-    assert len(rz._pending) == 0 and len(rz._seen_D) < 64
+    assert len(rz._seen_D) < 64              # the capacity memo stays bounded
     # the loop did what a training loop does
     ph = auto['p_hist']
     assert max(ph) > ph[0] and ph[-1] < max(ph), (ph[0], max(ph), ph[-1])
     first, last = sum(auto['losses'][:20]) / 20, sum(auto['losses'][-20:]) / 20
     assert last < 0.8 * first, (first, last)
-    rz._seen_D.clear(); rz._verified.clear()
+    rz._seen_D.clear()
     graphed = _soak.run(dev, iters=300, mode='auto', graphed=True)
     _same(graphed['final'], exact['final'], 'graphed vs exact')
     assert graphed['losses'] == exact['losses']
     n_densify = 300 // 50 - 1              # every densification replaces P and the statistics tensors: one capture each
     assert graphed['captures'] <= 1 + n_densify + graphed['retries'], (graphed['captures'], n_densify, graphed['retries'])
     # ... and with the loss recorded into the graph (forward + loss + backward = one replay)
-    rz._seen_D.clear(); rz._verified.clear()
+    rz._seen_D.clear()
     fused = _soak.run(dev, iters=300, mode='auto', graphed=True, loss_in_graph=True)
     _same(fused['final'], exact['final'], 'graphed with the loss in the graph vs exact')
     assert fused['losses'] == exact['losses'] and fused['p_hist'] == exact['p_hist']

@@ -292,3 +292,39 @@ def test_composite_output_dict_behaves_like_the_dict_it_stands_for():
     assert 'radius' in repr(make()) and 'None' not in repr(make())
     assert make().get('nothing', 7) == 7 and torch.equal(make().get('radius'), want_r)
     assert torch.equal(make().setdefault('radius', 1), want_r)
+
+
+def test_densify_and_prune_screen_space_criterion_and_reference_quirk():
+    """``densify_and_prune`` (reference avatar/common/nets/module.py:159-240): the reference's screen-space prune reads a
+    ``radius_max`` its own ``densify()`` has just zeroed, so it never fires (default, topology as the reference's); with
+    ``reference_radius_reset=False`` the surviving originals keep their radii and the big ones go."""
+    from exavatar_release_amd.densify import densify_and_prune
+    g = torch.Generator().manual_seed(3)
+    P = 40
+
+    def fresh():
+        params = {'mean': torch.nn.Parameter(torch.randn(P, 3, generator=g)),
+                  'scale': torch.nn.Parameter(torch.full((P, 3), -5.0)),
+                  'rotation': torch.nn.Parameter(torch.tensor([[1.0, 0, 0, 0]]).repeat(P, 1)),
+                  'opacity': torch.nn.Parameter(torch.full((P, 1), 2.0)),
+                  'rgb': torch.nn.Parameter(torch.rand(P, 3, generator=g))}
+        opt = torch.optim.Adam([{'params': [p]} for p in params.values()], lr=1e-3)
+        sum(p.sum() for p in params.values()).backward()
+        opt.step()
+        return params, opt
+    accum, cnt = torch.zeros(P, 1), torch.ones(P, 1)
+    accum[:5] = 1.0                                              # five hot, small Gaussians: cloned
+    radius_max = torch.zeros(P)
+    radius_max[10:14] = 50.0                                     # four cold ones that covered > 20 px on screen
+    kw = dict(grad_thr=0.5, extent=4.0, prune_big=True, radius_max=radius_max, screen_size_max=20, generator=g)
+    params, opt = fresh()
+    new, n_c, n_s, n_p = densify_and_prune(params, opt, accum, cnt, **kw)
+    assert (n_c, n_s, n_p) == (5, 0, 0) and new['mean'].shape[0] == P + 5          # the reference's quirk: nothing pruned
+    params, opt = fresh()
+    new, n_c, n_s, n_p = densify_and_prune(params, opt, accum, cnt, reference_radius_reset=False, **kw)
+    assert (n_c, n_s, n_p) == (5, 0, 4) and new['mean'].shape[0] == P + 5 - 4
+    keep = torch.ones(P, dtype=torch.bool)
+    keep[10:14] = False
+    assert torch.equal(new['mean'][:P - 4], params['mean'][keep])
+    st = opt.state[new['mean']]
+    assert st['exp_avg'].shape[0] == P + 1 and bool((st['exp_avg'][P - 4:] == 0).all())   # new rows: zero optimizer state

@@ -39,7 +39,7 @@ if 'warm3' in v:
 side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     for i in range(2 if 'side2' in v else 1): step()
-torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize(); exa.check_overflow()
+torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g):
     step()
