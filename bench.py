@@ -36,7 +36,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_VIEWS = 200
 VIEW_STRIDE = 123      # step i renders ring view (i * VIEW_STRIDE) mod N_VIEWS (coprime: a permutation)
-PROFILE_PREFIXES = ('r04', 'r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
+PROFILE_PREFIXES = ('r05', 'r04', 'r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
 
 
 def parse():
@@ -454,12 +454,24 @@ def main():
         except Exception as e:  # noqa: BLE001
             result['extra_exavatar_iteration'] = {'error': str(e)[:200]}
 
+    # ---- extra: BASELINE configs[2] as worded -- "~150k Gaussians + SMPL-X LBS": the rasterizer behind a PyTorch LBS ----
+    if rank == 0 and single and not args.no_concurrent and args.config == 'c3' and train:
+        try:
+            result['extra_c3_lbs'] = lbs_throughput(device)
+        except Exception as e:  # noqa: BLE001
+            result['extra_c3_lbs'] = {'error': str(e)[:200]}
+
     # ---- per-kernel HIP-event timing (eager, on torch's stream = the stream the kernels run on) -----
     if rank == 0 and not args.no_kernel_timing:
         c1 = make_ctx(1)
         _lib.timing_enable(True)
         acc = {}
         reps = 0
+        # work counters of the measured views ("record P, V, D, per-tile list-length histogram with every
+        # result"; the pixel-Gaussian evaluations feed the secondary roofline): read back from the workspaces of each render
+        from exavatar_release_amd import rasterizer as rz_, stats as exa_stats
+        work = []
+        exa.config.keep_debug = train and not use_sh
         n_t = min(len(my_views), 20)
         for i in range(n_t + 2):
             set_view(i, c1)
@@ -474,7 +486,12 @@ def main():
                 reps += 1
                 for k, v in tm.items():
                     acc[k] = acc.get(k, 0.0) + v
+                if exa.config.keep_debug and rz_._debug_last:
+                    work.append(exa_stats.render_stats(rz_._debug_last['tile'], rz_._debug_last['bin'], P, W, H,
+                                                       rz_._debug_last['capacity']))
         _lib.timing_enable(False)
+        exa.config.keep_debug = False
+        rz_._debug_last.clear()
         avg_us = {k: v / reps * 1e3 for k, v in acc.items()}
         V, D, WH = V_mean, D_mean, W * H
         sh_bytes = 12 * 16 * P if use_sh else 0
@@ -510,6 +527,14 @@ def main():
         if rp is not None:      # the committed rocprofv3 average of the same kernel (kernel begin -> end, no launch gap in the bracket)
             result['roofline']['rocprof'] = {'avg_launch_us': rp[0], 'frac': alg[dom] / (rp[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                              'source': rp[1]}
+        if work:
+            result['roofline']['secondary'] = valu_roofline(work, avg_us)
+            n_w = len(work)
+            result['config']['list_length_histogram'] = {
+                'what': 'non-empty 8x8-pixel sub-tile lists by length, mean over the %d measured views; bins start at' % n_w,
+                'bin_starts': list(exa_stats.LIST_BINS)[1:], 'lists': [sum(w['list_hist'][b] for w in work) / n_w for b in range(1, len(exa_stats.LIST_BINS))],
+                'lists_total': sum(w['lists'] for w in work) / n_w, 'longest': max(w['list_max'] for w in work),
+                'subtile_instances': sum(w['instances'] for w in work) / n_w}
         eb = result.get('extra_batched_views')
         if isinstance(eb, dict) and 'ms_per_launch' in eb:
             kb = eb['views_per_launch']
@@ -544,6 +569,74 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# Issue cost of one wave64 instruction on one SIMD, MEASURED on MI355X with tools/probe/valu_probe.hip at 8 waves per SIMD
+# (profiles/r05_valu_probe.txt): v_fma_f32 1.07 ns, v_exp_f32 3.51 ns (v_rcp_f32: the same pipe); a packed v_pk_fma_f32 costs
+# 2.17 ns = two plain ones (two results per lane: no extra throughput), a v_cmp + v_cndmask pair ~3.6 ns.
+# (MI355X_MICROARCH.md's 157.3 TFLOP/s vector peak = 1024 SIMDs x 64 lanes x 2 FLOP / 1.07 ns x 1.28: spec clock and spec
+#  issue rate; the probe's sustained rate is what the blends can be held against.)
+N_SIMD = 1024
+VALU_NS, TRANS_NS = 1.07, 3.51
+
+
+def valu_roofline(work, avg_us):
+    """SURVEY.md 8(d) secondary bound: "fp32 vector + v_exp_f32 throughput for the pixel-Gaussian evaluations per pass" --
+    the one that binds the two blends (profiles/*_pmc.md: VALU-issue bound, a sixth of the HBM roofline).  Per kernel: the
+    pixel-Gaussian pairs it evaluated in the measured views (from the workspaces), the VALU and transcendental
+    wave-instructions per dispatch (SQ_INSTS_VALU of the committed PMC pass of the same workload; transcendentals: one
+    v_exp_f32 per pair in the forward, v_exp_f32 + v_rcp_f32 in the backward, from the ISA), the issue time those
+    instructions need on 1024 SIMDs, and the fraction of the measured launch that is."""
+    n = len(work)
+    pairs = {'render_fwd': sum(w['fwd_pairs'] for w in work) / n, 'render_bwd': sum(w['bwd_pairs'] for w in work) / n}
+    trans_per_pair = {'render_fwd': 1, 'render_bwd': 2}
+    pmc, src = pmc_counters()
+    out = {'bound': 'valu', 'unit': 'G wave-instructions/s',
+           'peak': N_SIMD / VALU_NS,
+           'peak_what': '%d SIMDs / %.2f ns per wave64 fp32 instruction (v_exp_f32 / v_rcp_f32: %.2f ns), measured: '
+                        'tools/probe/valu_probe.hip, profiles/r05_valu_probe.txt.  Every VALU instruction is priced as a plain '
+                        'one except the transcendentals, so `frac` is a LOWER bound of the share of the launch the VALU pipes '
+                        'need: packed (v_pk_*), compare and DPP instructions take two passes -- SQ_ACTIVE_INST_VALU (valu_busy) '
+                        'counts those' % (N_SIMD, VALU_NS, TRANS_NS),
+           'counters_source': src, 'kernels': {}}
+    for k in ('render_fwd', 'render_bwd'):
+        if k not in avg_us:
+            continue
+        ent = {'pixel_gaussian_pairs': pairs[k], 'avg_launch_us': avg_us[k],
+               'pairs_per_s': pairs[k] / (avg_us[k] * 1e-6)}
+        insts = pmc.get(k, {}).get('SQ_INSTS_VALU') if pmc else None
+        if insts:
+            trans = pairs[k] / 64.0 * trans_per_pair[k]              # wave-instructions
+            t_issue_us = ((insts - trans) * VALU_NS + trans * TRANS_NS) / N_SIMD * 1e-3
+            ent.update({'valu_wave_insts_per_launch': insts, 'transcendental_wave_insts_per_launch': trans,
+                        'valu_lane_ops_per_pair': insts * 64.0 / max(pairs[k], 1.0),
+                        'achieved': insts / (avg_us[k] * 1e-6) / 1e9,
+                        'issue_time_us_at_peak': t_issue_us, 'frac': t_issue_us / avg_us[k]})
+            c = pmc.get(k, {})
+            if c.get('SQ_ACTIVE_INST_VALU') and c.get('SQ_BUSY_CYCLES'):
+                # quad-cycles the VALU pipes of the chip were executing / (4 SIMDs per CU x the kernel's busy quad-cycles per CU ...):
+                # reported as the counter ratio the PMC summary uses: VALU-active quad-cycles per wave quad-cycle x resident waves
+                ent['valu_active_per_wave_cycle'] = c['SQ_ACTIVE_INST_VALU'] / c['SQ_WAVE_CYCLES'] if c.get('SQ_WAVE_CYCLES') else None
+        out['kernels'][k] = ent
+    dom = max(out['kernels'], key=lambda k: out['kernels'][k]['avg_launch_us']) if out['kernels'] else None
+    if dom and 'frac' in out['kernels'][dom]:
+        out['kernel'], out['achieved'], out['frac'] = dom, out['kernels'][dom]['achieved'], out['kernels'][dom]['frac']
+    return out
+
+
+def pmc_counters():
+    """(per-kernel SQ counters of the committed PMC pass of the newest round that has one, source) -- builder-side
+    rocprofv3 --pmc passes of the same C3 workload, NOT collected in this run; ({}, None) if unavailable."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    for prefix in PROFILE_PREFIXES:
+        try:
+            name = prefix + '_pmc.json'
+            with open(os.path.join(here, 'profiles', name)) as f:
+                d = json.load(f)
+            return d['kernels'], 'profiles/%s (%s; not collected in this run)' % (name, d.get('what', ''))
+        except Exception:  # noqa: BLE001
+            pass
+    return {}, None
 
 
 def pmc_traffic(kernel):
@@ -782,6 +875,75 @@ def iteration_throughput(device, n_scene=100_000, n_human=50_000, H=1024, W=1024
                 out[how]['what'] = ('exa.GraphedIteration: one hipGraph for the five forwards, one for their backwards, same '
                                     'loss in PyTorch between them; captures=%d' % graphed.captures)
         return out
+    finally:
+        exa.config.mode, exa.config.fixed_capacity = saved
+
+
+def lbs_throughput(device, P=150_000, H=1024, W=1024, iters=40):
+    """BASELINE configs[2] as it is worded: "~150k Gaussians + SMPL-X LBS, 1024x1024".  The rasterizer's inputs are the
+    outputs of a PyTorch-ROCm linear blend skinning (exavatar_release_amd.lbs.SyntheticAvatar: 55-joint tree, <= 4 skinning
+    weights per vertex, per-vertex offsets, isotropic scales; reference avatar/common/nets/module.py:413-422, 516-586 -- the LBS
+    stays in PyTorch, north_star), non-leaf tensors, and its gradients flow on into pose / translation / offsets.  Eager,
+    through the drop-in GaussianRenderer: the whole chain, the LBS alone (forward + backward from synthetic gradients at its
+    outputs) and the rasterizer alone on detached copies of the same tensors."""
+    import exavatar_release_amd as exa
+    from exavatar_release_amd import lbs, scenes
+    saved = (exa.config.mode, exa.config.fixed_capacity)
+    exa.config.mode, exa.config.fixed_capacity = 'auto', None
+    try:
+        model = lbs.SyntheticAvatar(scenes.dist_b_avatar(P, seed=0)).to(device)
+        cam = {k: t.to(device) for k, t in scenes.ring_camera(H, W, 7, N_VIEWS).items()}
+        bg = torch.ones(3, device=device)
+        G = torch.randn(3, H, W, device=device)
+        rend = exa.GaussianRenderer()
+        gm, gs, gc = (torch.randn(P, 3, device=device) for _ in range(3))
+
+        def zero():
+            for p in model.parameters():
+                p.grad = None
+
+        def full():
+            zero()
+            out = rend(model(), (H, W), cam, bg)
+            torch.autograd.backward([out['img']], [G])
+
+        def lbs_only():
+            zero()
+            a = model()
+            torch.autograd.backward([a['mean_3d'], a['scale'], a['rgb']], [gm, gs, gc])
+
+        with torch.no_grad():
+            frozen = {k: v.detach().clone() for k, v in model().items()}
+
+        def raster_only():
+            a = {k: v.requires_grad_(True) for k, v in frozen.items()}
+            for v in a.values():
+                v.grad = None
+            out = rend(a, (H, W), cam, bg)
+            torch.autograd.backward([out['img']], [G])
+
+        res = {'workload': '%d k avatar-like Gaussians behind a synthetic SMPL-X-shaped LBS (55 joints), %dx%d, fwd+bwd, eager' % (P // 1000, W, H)}
+        for name, fn in (('lbs_plus_raster', full), ('lbs_only', lbs_only), ('raster_only', raster_only)):
+            exa.config.mode = 'exact'
+            fn()
+            exa.config.mode = 'auto'
+            for _ in range(8):
+                fn()
+            windows = []
+            for _w in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                torch.cuda.synchronize()
+                windows.append((time.perf_counter() - t0) / iters * 1e3)
+            res[name] = {'ms_per_iteration': sorted(windows)[1], 'windows_ms': [round(w, 4) for w in windows]}
+            if name == 'lbs_plus_raster':     # the rasterizer's gradients really arrive at the pose
+                res['pose_grad_nonzero'] = model.pose.grad is not None and float(model.pose.grad.abs().max()) > 0
+        res['rasterizer_share'] = res['raster_only']['ms_per_iteration'] / res['lbs_plus_raster']['ms_per_iteration']
+        res['value'] = 1e3 / res['lbs_plus_raster']['ms_per_iteration']
+        res['unit'] = 'iters/s'
+        return res
     finally:
         exa.config.mode, exa.config.fixed_capacity = saved
 

@@ -128,4 +128,9 @@ with open(os.path.join(out, prefix + '_pmc.md'), 'w') as f:
             f.write('| %s | %.0f %% | %.0f %% | %.0f %% | %.0f %% |\n' % (
                 k, 100 * s1[k].get('SQ_ACTIVE_INST_VALU', 0) / wc, 100 * s1[k].get('SQ_WAIT_ANY', 0) / wc,
                 100 * s1[k].get('SQ_WAIT_INST_ANY', 0) / wc, 100 * s2.get(k, {}).get('SQ_ACTIVE_INST_LDS', 0) / wc))
+# machine-readable copy of the SQ counters (bench.py: roofline.secondary prices the blends' VALU instruction counts)
+with open(os.path.join(out, prefix + '_pmc.json'), 'w') as f:
+    merged = {k: dict(s1.get(k, {}), **s2.get(k, {})) for k in SHORT.values() if k in s1 or k in s2}
+    json.dump({'what': 'rocprofv3 --kernel-trace --pmc SQ_* passes of `python tools/gpu_kernel_times.py 0` (C3, ring view 0, eager), '
+                       'mean per dispatch', 'kernels': merged}, f, indent=1)
 print('wrote profiles/%s_*' % prefix)
