@@ -277,7 +277,7 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         b.means3D = j.means3D; b.shs = j.shs; b.opacities = j.opacities; b.scales = j.scales; b.rotations = j.rotations;
         b.cov3D_precomp = j.cov3D_precomp; b.radii = j.radii; b.splats = static_cast<const Splat*>(j.geom_ws);   // (composite: B's records)
         b.partials = r.partials; b.touched = r.bw.touched; b.header = r.tw.header;
-        b.partial_bytes = 48ull * (j.compose_geom_a ? j.compose_capacity_b : j.capacity);
+        b.partial_bytes = (uint64_t)PARTIAL_BYTES * (j.compose_geom_a ? j.compose_capacity_b : j.capacity);
         b.dL_dmeans2D = j.dL_dmeans2D; b.dL_dmeans3D = j.dL_dmeans3D; b.dL_dcolors = j.dL_dcolors;
         b.dL_dopacity = j.dL_dopacity; b.dL_dscales = j.dL_dscales; b.dL_drotations = j.dL_drotations;
         b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;

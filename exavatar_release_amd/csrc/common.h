@@ -63,11 +63,20 @@ static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 // Per-instance partial gradients written (plain stores, no atomics) by render-backward: the sums over the 64 pixels
 // of one sub-tile, for every instance the forward pass actually blended somewhere (its `touched` byte is set; the
 // records of all other instances are never written and never read).  Indexed Gaussian-major:
-// inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).  One 48-byte record = three 16-byte rows (one or two cache lines:
-// three separate arrays dirtied twice as many 32-byte sectors, profiles/r02_hbm_traffic.md):
+// inst_off + (sy - sy0) * (sx1 - sx0) + (sx - sx0).  Ten floats in 16-byte rows:
 //   row 0 = (sum s dx, sum s dy, sum s dx^2, sum s dx dy)        s = dL/dG * G
 //   row 1 = (sum s dy^2, sum G dL/dalpha, sum w dL/dC_r, sum w dL/dC_g)    w = alpha T
 //   row 2 = (sum w dL/dC_b, sum w dL/dDepth, -, -)
+// PARTIAL_BYTES = 48: three rows packed (one or two cache lines; three separate arrays dirtied twice as many 32-byte
+// sectors, profiles/r02_hbm_traffic.md).  Round 5 measured the alternative -- one record = ONE 64-byte line, written whole
+// (row 3 = zeros: no straddled sector, no half-written line; EXA_PARTIAL_BYTES=64) -- three interleaved runs each on one box:
+// C3 6 597 / 6 623 / 6 609 it/s against 6 646 / 6 637 / 6 650 with 48 bytes (preprocess_bwd 19.6-20.0 vs 19.0 us by events,
+// render_bwd the same): the extra 16 bytes per record cost more than the alignment gives.  48 stays.
+#ifndef EXA_PARTIAL_BYTES
+#define EXA_PARTIAL_BYTES 48
+#endif
+constexpr int PARTIAL_BYTES = EXA_PARTIAL_BYTES, PARTIAL_ROWS = PARTIAL_BYTES / 16;
+static_assert(PARTIAL_BYTES == 48 || PARTIAL_BYTES == 64, "partial records: three rows packed, or one 64-byte line");
 struct PartialWs { float4* rec; };
 
 struct Grid {
@@ -205,8 +214,8 @@ __host__ __device__ inline uint32_t cell_slots(uint32_t inst) {
     return inst ? (inst + BATCH - 1) / BATCH + 2 * SUBS_PER_CELL : 0u;
 }
 
-// backward scratch: one 48-byte partial record per instance.
-__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * 48); }
+// backward scratch: one partial record per instance.
+__host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * PARTIAL_BYTES); }
 __host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t) {
     PartialWs w;
     w.rec = reinterpret_cast<float4*>(base);
@@ -390,7 +399,7 @@ struct PreprocessBwdArgs {
     const float* means3D; const float* shs; const float* opacities;
     const float* scales; const float* rotations; const float* cov3D_precomp;
     const int32_t* radii; const Splat* splats; PartialWs partials; const uint8_t* touched;
-    uint64_t partial_bytes;                                    // size of partials.rec (48 B x capacity): bound of the buffer loads
+    uint64_t partial_bytes;                                    // size of partials.rec (PARTIAL_BYTES x capacity): bound of the buffer loads
     const ExaRasterHeader* header;
     float* dL_dmeans2D; float* dL_dmeans3D; float* dL_dcolors; float* dL_dopacity;
     float* dL_dscales; float* dL_drotations; float* dL_dsh; float* dL_dcov3D;

@@ -57,7 +57,7 @@ constexpr uint32_t BUF_OOB = 0xffffff00u;          // + 32 does not wrap; >= any
 __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const uint8_t* __restrict__ touched,
                                               const float4* __restrict__ prec, uint64_t prec_bytes, float (&sum)[10],
                                               GatherLds& L, int lane) {
-    const bool use_buf = prec_bytes < (uint64_t)BUF_OOB;               // (a 4 GiB record array takes the pointer path)
+    const bool use_buf = prec_bytes < (uint64_t)BUF_OOB;               // (a 4 GiB record array takes the pointer path: 32-bit byte offsets)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float4*>(prec), 0, use_buf ? (int)(uint32_t)prec_bytes : 0, 0x00020000);
     uint32_t incl = n;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const ui
         if (use_buf) {
 #pragma unroll
             for (int u = 0; u < GCH / 64; ++u) {                        // only the flagged records are fetched
-                const uint32_t bo = ((fl >> u) & 1u) ? slot[u] * 48u : BUF_OOB;
+                const uint32_t bo = ((fl >> u) & 1u) ? slot[u] * (uint32_t)PARTIAL_BYTES : BUF_OOB;
                 q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo, 0, 0));
                 q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 16u, 0, 0));
                 q2[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 32u, 0, 0));
@@ -110,7 +110,7 @@ __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const ui
 #pragma unroll
             for (int u = 0; u < GCH / 64; ++u) {
                 if ((fl >> u) & 1u) {
-                    const float4* src = prec + (size_t)slot[u] * 3;
+                    const float4* src = prec + (size_t)slot[u] * PARTIAL_ROWS;
                     q0[u] = src[0]; q1[u] = src[1]; q2[u] = src[2];
                 }
             }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
                     float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
                         if (touched[off + j]) {
-                            const float4* src = prec + (size_t)(off + j) * 3;
+                            const float4* src = prec + (size_t)(off + j) * PARTIAL_ROWS;
                             const float4 q0 = src[0], q1 = src[1], q2 = src[2];
                             acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
                             acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;

@@ -420,10 +420,11 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
                 const uint32_t ps = s_pslot[kk];
                 if (!PREFIX || ps != NO_SLOT) {
-                    float4* dst = prec + (size_t)ps * 3;
+                    float4* dst = prec + (size_t)ps * PARTIAL_ROWS;
                     dst[0] = make_float4(o * mx, o * my, o * mxx, o * mxy);
                     dst[1] = make_float4(o * myy, dop, dr, dg);
                     dst[2] = make_float4(db, dz, 0.f, 0.f);
+                    if (PARTIAL_ROWS == 4) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);      // (the whole line: no partial sector)
                     touched[ps] = (uint8_t)1;
                 }
             }

@@ -935,7 +935,7 @@ class _Compose(torch.autograd.Function):
                 d_means3D, d_means2D, d_colors, d_opac, d_scales, d_rot, d_cov = \
                     [next(pieces).view(P, w) if on else None for on, w in want]
                 d_sh = torch.empty((P, sh_M, 3), dtype=_F32, device=device) if has_sh and nd[2] else None
-                grad_ws = torch.empty(48 * jb.capacity + 256, dtype=torch.uint8, device=device)
+                grad_ws = _workspace(_sizes(P, W, H, jb.capacity).grad_bytes, device)      # (B's Gaussian-major instance numbering)
                 keep += [g_color, g_depth, g_alpha, grad_ws]
                 a = arr[k]
                 a.settings = ctypes.pointer(c.settings)

@@ -229,7 +229,7 @@ typedef struct ExaRasterBackwardJob {
     int32_t grad_first;
     /* Composite render (exa_raster_forward_compose_batch): compose_geom_a != NULL makes this the backward of a composite.
      * Then P, the input tensors, radii and every gradient array describe source B (the trainable Gaussians), geom_ws is B's
-     * splat workspace, tile_ws / bin_ws / capacity are the COMPOSITE's workspaces, grad_ws holds 48 B x compose_capacity_b,
+     * splat workspace, tile_ws / bin_ws / capacity are the COMPOSITE's workspaces, grad_ws holds exa_raster_compose_sizes().grad_bytes (48 B x compose_capacity_b),
      * compose_geom_a / compose_P_a name source A's records (constants: no gradient) and grad_first must be 0. */
     const void* compose_geom_a; int32_t compose_P_a; uint64_t compose_capacity_b;
     /* Optional (NULL = off): DEVICE address of one pointer that the kernels load at EXECUTION time and read dL/dcolor from,
