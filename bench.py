@@ -181,23 +181,22 @@ def main():
 
     # N > 1: gradients go through the product's double-buffered flat all-reducer: two launch contexts on the SAME
     # stream, context i packs into buffer i (captured in its graph), the all-reduce of step i overlaps step i + 1
-    # N = 1, one view at a time: two launch contexts as well (two camera blocks: while the graph of step i renders from
-    # block i mod 2, a forked branch of the same graph fetches the camera of step i + 1 into the other block, see cam_mode)
-    cam_mode = os.environ.get('EXA_BENCH_CAM_COPY', 'prefetch')
-    prefetch = cam_mode == 'prefetch' and S == 1 and KV == 1 and args.launch == 'graph'
-    n_ctx = 2 if (world > 1 or prefetch) else S
+    n_ctx = S if world == 1 else 2
     reducer = exa_dist.FlatGradAllReducer(params, average=False, n_buffers=2) if world > 1 else None
     ctxs = [make_ctx(KV) for _ in range(n_ctx)]
     for c in ctxs:
         if S > 1:
             c['stream'] = torch.cuda.Stream()
 
-    # How the graph-replayed single-view step gets its camera (always inside the timed region, from the ring of views resident
-    # in HBM): 'prefetch' (default, round 5) -- exa_raster_select_row (row (counter mod views) of the camera table -> a camera
-    # block, counter + 1) runs on a FORKED BRANCH of the step's graph and fills the block the NEXT step renders from, the way a
-    # training loop prefetches its next sample: the 4.6 us one-workgroup launch overlaps the step instead of heading its
-    # dependency chain; 'graph' (round 4) -- the same kernel as the first node of the chain; 'kernel' -- one eager elementwise
-    # kernel in front of every replay; 'memcpy' -- the runtime's blit (rounds 1-3).
+    # How the graph-replayed single-view step gets its camera: 'graph' (default) -- the first node of the captured graph is
+    # exa_raster_select_row: row (counter mod views) of the resident camera table -> the graph's camera block, counter + 1
+    # (the ring of views is resident in HBM, as the contract of this line says; no launch outside the graph per step);
+    # 'kernel' -- one eager elementwise kernel in front of every replay (round 4 until this change: ~4.5 us of GPU time per step,
+    # mostly the system-scope fences of a launch outside the graph); 'memcpy' -- the runtime's blit (rounds 1-3).
+    # (Round 5 tried to take the 4.6 us of that first node off the chain: select_row on a FORKED branch of the step's graph,
+    #  filling the camera block of the NEXT step while this one runs, two blocks / two graphs alternating.  A graph with two
+    #  branches costs this runtime ~30 us per replay: 5 500 against 6 640 it/s, twice each on one box.  Not kept.)
+    cam_mode = os.environ.get('EXA_BENCH_CAM_COPY', 'graph')
     view_counter = torch.zeros(1, dtype=torch.int32, device=device)
     in_graph_switch = {'on': False}
 
@@ -208,11 +207,7 @@ def main():
 
     def seek_view(i):
         """(outside the timed region) the next replay renders this rank's view i mod views"""
-        if in_graph_switch['on'] == 'prefetch':
-            j = i % len(my_views)
-            torch.mul(cam_tab[j:j + 1], 1.0, out=ctxs[i % 2]['cam'])       # the block step i reads; its successors are prefetched
-            view_counter.fill_((i + 1) % len(my_views))
-        elif in_graph_switch['on']:
+        if in_graph_switch['on']:
             view_counter.fill_(i % len(my_views))
 
     def set_view(i, c):
@@ -298,23 +293,14 @@ def main():
                     raster_step(c0, 0)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            use_switch = 'prefetch' if prefetch else (cam_mode in ('graph', 'prefetch') and KV == 1)
-            fork = torch.cuda.Stream() if prefetch else None
+            use_switch = cam_mode == 'graph' and KV == 1
             for b, c in enumerate(ctxs):
                 c['graph'] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(c['graph']):
-                    if prefetch:
-                        # fork: the camera of the NEXT step -> the other context's block (nobody reads that block during this
-                        # graph: its last reader, the previous replay, is complete in stream order); join at the end
-                        fork.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(fork):
-                            select_view_in_graph(ctxs[1 - b])
-                    elif use_switch:
+                    if use_switch:
                         select_view_in_graph(c)
                     raster_step(c, b)
-                    if prefetch:
-                        torch.cuda.current_stream().wait_stream(fork)
-                c['switch_in_graph'] = bool(use_switch)
+                c['switch_in_graph'] = use_switch
                 c['graph'].replay()
                 torch.cuda.synchronize()
             in_graph_switch['on'] = use_switch
@@ -409,11 +395,7 @@ def main():
                        'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle,
                        'view_switch': 'per step, inside the timed region: the next view\'s camera block (48 floats) copied from the '
                                       'resident table of ring views into the graph\'s static tensor by ' +
-                                      ('exa_raster_select_row + a device-side counter on a forked branch of the replayed graph: it fills '
-                                       'the camera block the NEXT step reads while this step runs (two blocks, two graphs alternate; '
-                                       'EXA_BENCH_CAM_COPY=graph: the same kernel as the FIRST node of the step\'s chain, the round-4 '
-                                       'protocol, ~4.6 us per step slower)' if in_graph_switch['on'] == 'prefetch' else
-                                       'the first node of the replayed graph (exa_raster_select_row + a device-side counter; '
+                                      ('the first node of the replayed graph (exa_raster_select_row + a device-side counter; '
                                        'EXA_BENCH_CAM_COPY=kernel: an eager elementwise kernel in front of every replay, the '
                                        'protocol until late round 4, 0.5 % slower; =memcpy: the runtime\'s blit, rounds 1-3)'
                                        if in_graph_switch['on'] else

@@ -94,7 +94,7 @@ with open(os.path.join(out, prefix + '_host.md'), 'w') as f:
     f.write('# %s: host side of the drop-in surface (1 x MI355X box of the round)\n\n' % prefix)
     hp = read('host_profile.log').splitlines()
     keep = [ln for ln in hp if ln.startswith(('eager render', 'host:'))]
-    f.write('## `tools/gpu_host_profile.py` (eager `GaussianRenderer` fwd + bwd, C3, `config.mode = \'auto\'`, `overflow_check = \'forward\'`)\n\n```\n'
+    f.write('## `tools/gpu_host_profile.py` (eager `GaussianRenderer` fwd + bwd, C3, `config.mode = \'auto\'`)\n\n```\n'
             + '\n'.join(keep) + '\n```\n\n')
     f.write('## `tools/gpu_graphed_times.py` (`GraphedRenderer`, C5)\n\n```\n' + read('graphed.log') + '```\n')
 print('wrote profiles/%s_{iteration,c5_kernel_stats,host}.md' % prefix)
