@@ -43,40 +43,45 @@ def axis_angle_to_matrix(aa):
     return eye + a * K + b * (K @ K)
 
 
-def _levels(parents):
-    """Joints grouped by depth in the tree: all joints of one level compose with their parents in ONE batched matmul
-    (ten matmuls for SMPL-X instead of the reference's 54 sequential ones)."""
+def _level_plan(parents):
+    """Joints grouped by depth in the tree: ``[(joint ids of the level, position of each one's parent inside the PREVIOUS
+    level)]`` + the permutation that puts the concatenated levels back into joint order.  All joints of a level compose with
+    their parents in ONE batched matmul (eleven for SMPL-X instead of the reference's 54 sequential ones)."""
     depth = [0] * len(parents)
     for i, p in enumerate(parents):
         depth[i] = 0 if p < 0 else depth[p] + 1
-    return [[i for i, d in enumerate(depth) if d == lv] for lv in range(1, max(depth) + 1)]
+    levels = [[i for i, d in enumerate(depth) if d == lv] for lv in range(max(depth) + 1)]
+    plan = [(levels[lv], [levels[lv - 1].index(parents[i]) for i in levels[lv]]) for lv in range(1, len(levels))]
+    order = [i for lv in levels for i in lv]
+    inverse = [order.index(i) for i in range(len(parents))]
+    return plan, inverse
+
+
+_plans = {}
 
 
 def joint_transforms(rot, joints, parents=SMPLX_PARENTS):
     """Relative rigid transforms of the joints, rest pose -> posed ([J, 4, 4]): the composition of per-joint transforms
     along the kinematic tree with the rest joint location removed (``smplx/lbs.py:361-417``, second return value)."""
-    J = rot.shape[0]
-    par = torch.tensor([max(p, 0) for p in parents], device=rot.device)
+    J, dev = rot.shape[0], rot.device
+    key = (tuple(parents), dev)
+    if key not in _plans:
+        plan, inverse = _level_plan(parents)
+        _plans[key] = ([(torch.tensor(ids, device=dev), torch.tensor(ppos, device=dev)) for ids, ppos in plan],
+                       torch.tensor(inverse, device=dev), torch.tensor([max(p, 0) for p in parents], device=dev))
+    plan, inverse, par = _plans[key]
     rel = joints - joints[par]
     rel = torch.cat((joints[:1], rel[1:]))
-    local = torch.zeros(J, 4, 4, dtype=rot.dtype, device=rot.device)
-    local[:, :3, :3] = rot
-    local[:, :3, 3] = rel
-    local[:, 3, 3] = 1.0
-    world = [None] * J
-    world[0] = local[0]
-    for level in _levels(parents):
-        pw = torch.stack([world[parents[i]] for i in level])
-        cw = pw @ local[level]
-        for k, i in enumerate(level):
-            world[i] = cw[k]
-    world = torch.stack(world)
+    bottom = torch.zeros(J, 1, 4, dtype=rot.dtype, device=dev)
+    bottom[:, 0, 3] = 1.0
+    local = torch.cat((torch.cat((rot, rel[:, :, None]), 2), bottom), 1)          # [J, 4, 4]
+    levels = [local[:1]]
+    for ids, ppos in plan:
+        levels.append(levels[-1][ppos] @ local[ids])
+    world = torch.cat(levels)[inverse]
     # remove the rest-pose joint location: T' = T - [0 | T [j, 0]]  (column 3)
-    jh = torch.cat((joints, torch.zeros_like(joints[:, :1])), 1)[:, :, None]
-    shift = (world @ jh)[:, :, 0]
-    out = world.clone()
-    out[:, :, 3] = world[:, :, 3] - shift
-    return out
+    shift = (world[:, :, :3] @ joints[:, :, None])[:, :, 0]
+    return torch.cat((world[:, :, :3], (world[:, :, 3] - shift)[:, :, None]), 2)
 
 
 class SyntheticAvatar(nn.Module):
