@@ -45,10 +45,8 @@ polled: the report goes to a reserved slot the owner of the graph reads after ea
 (``GraphedRenderer`` / ``GraphedIteration``), or the caller checks ``read_header`` itself.
 """
 import ctypes
-import os
 import threading
 import time
-import warnings
 import weakref
 from typing import NamedTuple
 
@@ -823,6 +821,8 @@ def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
     if side is None:
         side = _side_streams[device.index] = torch.cuda.Stream(device=device)
     ev_binned, ev_sorted = sorted_event
+    if config.poison:                   # (the 0xFF fill of the workspaces above was queued on THIS stream, behind the events)
+        side.wait_stream(stream_obj)
     side.wait_event(ev_binned)          # ranges + zero-fill next to the sources' sort ...
     _lib.check(lib.exa_raster_forward_compose_batch(arr, K, int(store_ctx) | _lib.STAGE_NO_SORT, ctypes.c_void_p(side.cuda_stream)))
     side.wait_event(ev_sorted)          # ... list merges next to their blend
