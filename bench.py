@@ -925,7 +925,8 @@ def lbs_throughput(device, P=150_000, H=1024, W=1024, iters=40):
             out = rend(a, (H, W), cam, bg)
             torch.autograd.backward([out['img']], [G])
 
-        res = {'workload': '%d k avatar-like Gaussians behind a synthetic SMPL-X-shaped LBS (55 joints), %dx%d, fwd+bwd, eager' % (P // 1000, W, H)}
+        res = {'workload': '%d k avatar-like Gaussians behind a synthetic SMPL-X-shaped LBS (55 joints), %dx%d, fwd+bwd; eager through the drop-in '
+                           'renderer, and the whole chain replayed from one hipGraph (lbs_plus_raster_graphed)' % (P // 1000, W, H)}
         for name, fn in (('lbs_plus_raster', full), ('lbs_only', lbs_only), ('raster_only', raster_only)):
             exa.config.mode = 'exact'
             fn()
@@ -943,6 +944,44 @@ def lbs_throughput(device, P=150_000, H=1024, W=1024, iters=40):
             res[name] = {'ms_per_iteration': sorted(windows)[1], 'windows_ms': [round(w, 4) for w in windows]}
             if name == 'lbs_plus_raster':     # the rasterizer's gradients really arrive at the pose
                 res['pose_grad_nonzero'] = model.pose.grad is not None and float(model.pose.grad.abs().max()) > 0
+        # the same chain -- LBS, render, backward of both -- captured in ONE hipGraph (static parameters in, static gradients
+        # out; capacity mode with the capacity the eager calls measured): what is left when the ~300 small PyTorch launches
+        # of the LBS no longer go through the host one by one
+        try:
+            params = list(model.parameters())
+            static_grads = [torch.zeros_like(p) for p in params]
+
+            def graph_step():
+                out = rend(model(), (H, W), cam, bg)
+                grads = torch.autograd.grad([out['img']], params, grad_outputs=[G])
+                for o, g_ in zip(static_grads, grads):
+                    torch.add(g_, 0.0, out=o)            # (elementwise kernels: memcpy nodes do not replay reliably here)
+            exa.config.mode = 'capacity'
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    graph_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_step()
+            for _ in range(5):
+                graph.replay()
+            windows = []
+            for _w in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    graph.replay()
+                torch.cuda.synchronize()
+                windows.append((time.perf_counter() - t0) / iters * 1e3)
+            res['lbs_plus_raster_graphed'] = {'ms_per_iteration': sorted(windows)[1], 'windows_ms': [round(w, 4) for w in windows],
+                                              'pose_grad_nonzero': float(static_grads[[i for i, p_ in enumerate(params) if p_ is model.pose][0]].abs().max()) > 0}
+            del graph
+        except Exception as e:  # noqa: BLE001
+            res['lbs_plus_raster_graphed'] = {'error': str(e)[:200]}
         res['rasterizer_share'] = res['raster_only']['ms_per_iteration'] / res['lbs_plus_raster']['ms_per_iteration']
         res['value'] = 1e3 / res['lbs_plus_raster']['ms_per_iteration']
         res['unit'] = 'iters/s'
