@@ -60,7 +60,7 @@ import torch
 from . import _lib
 
 from . import rasterizer as rz
-from .renderer import ITERATION_RENDERS, _CompositeOutput, _sh_degree, camera_block_device, render_iteration
+from .renderer import ITERATION_RENDERS, _sh_degree, camera_block_device, render_iteration
 
 _ASSET_KEYS = ('mean_3d', 'scale', 'rotation', 'opacity')
 _IMG_ONLY = (True, False, False) * 5
@@ -360,10 +360,9 @@ class GraphedIteration:
                     rz._capture_report = rz._capture_report_c = None
                 cap.outs = res
                 cap.out_list = [res[k][n] for k in ITERATION_RENDERS for n in ('img', 'depthmap', 'mask')]
-                # radius / is_vis of the three plain renders: static tensors the forward kernel rewrites per replay; the
-                # composites' are concatenations of them, built when somebody reads them (renderer._CompositeOutput)
-                plain = ('scene', 'human', 'human_refined') if self.merge else ITERATION_RENDERS
-                cap.radii = {k: (res[k]['radius'], res[k]['is_vis']) for k in plain}
+                # radius / is_vis of the five renders: static tensors the replay rewrites (the composites' are concatenations
+                # recorded in the forward graph)
+                cap.radii = {k: (res[k]['radius'], res[k]['is_vis']) for k in ITERATION_RENDERS}
                 cap.bwd = {}
                 self.captures += 1
         finally:
@@ -628,13 +627,8 @@ class GraphedIteration:
         self._args = None
         out = {}
         for i, name in enumerate(ITERATION_RENDERS):
-            base = {'img': outs[3 * i], 'depthmap': outs[3 * i + 1], 'mask': outs[3 * i + 2], 'mean_2d': probes[i]}
-            if name in cap.radii:
-                base['is_vis'], base['radius'] = cap.radii[name][1], cap.radii[name][0]
-                out[name] = base
-            else:
-                rs, rb = cap.radii['scene'], cap.radii['human' if name == 'scene_human' else 'human_refined']
-                out[name] = _CompositeOutput(base, ((rs[0], rb[0]), (rs[1], rb[1])))
+            out[name] = {'img': outs[3 * i], 'depthmap': outs[3 * i + 1], 'mask': outs[3 * i + 2], 'mean_2d': probes[i],
+                         'is_vis': cap.radii[name][1], 'radius': cap.radii[name][0]}
         if loss is not None:
             out['loss'] = loss
         return out

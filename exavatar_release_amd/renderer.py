@@ -223,23 +223,6 @@ def _output_dict(job, outs, is_vis=None):
             'radius': radius}
 
 
-class _CompositeOutput(dict):
-    """Output dict of a composite render (:func:`render_iteration`).  ``radius`` / ``is_vis`` cover ``cat(scene, human)`` as the
-    reference's concatenated render returns them, but nothing on the reference's path reads them (it uses the composites'
-    ``img`` only, avatar/main/model.py:119-167): ``out['radius']`` / ``out['is_vis']`` are concatenated on first access
-    (``__missing__``) and are entries of the dict from then on."""
-
-    def __init__(self, base, parts):
-        dict.__init__(self, base)
-        self._parts = parts                           # ((radius_a, radius_b), (is_vis_a, is_vis_b))
-
-    def __missing__(self, k):
-        if k not in ('radius', 'is_vis'):
-            raise KeyError(k)
-        self[k] = v = torch.cat(self._parts[0 if k == 'radius' else 1])
-        return v
-
-
 class GaussianRenderer(nn.Module):
     def __init__(self):
         super(GaussianRenderer, self).__init__()
@@ -362,10 +345,12 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
         res = [_output_dict(plain[k], outs[k], vis[k]) for k in range(3)]
 
         def composite(k, b):
+            # radius / is_vis cover cat(scene, human), as the reference's concatenated render returns them (two small
+            # concatenations per composite; inside a captured iteration they are nodes of the forward graph)
             img, _none, depth, mask = couts[k]
-            radii = (outs[0][1], outs[b][1])
-            return _CompositeOutput({'img': img, 'depthmap': depth, 'mask': mask, 'mean_2d': comp[k]['means2D']},
-                                    (radii, tuple(v if v is not None else r > 0 for v, r in zip((vis[0], vis[b]), radii))))
+            radius = torch.cat((outs[0][1], outs[b][1]))
+            is_vis = torch.cat((vis[0], vis[b])) if vis[0] is not None and vis[b] is not None else radius > 0
+            return {'img': img, 'depthmap': depth, 'mask': mask, 'mean_2d': comp[k]['means2D'], 'is_vis': is_vis, 'radius': radius}
         return dict(zip(ITERATION_RENDERS, [res[0], res[1], composite(0, 1), res[2], composite(1, 2)]))
     rj = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats, mean_2d=pr[0], **kw),
           _raster_job(human_asset, img_shape, cam_param, bg, mean_2d=pr[1], **kw),

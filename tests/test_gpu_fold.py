@@ -90,7 +90,7 @@ def test_is_vis_is_written_by_the_forward_kernel(dev):
 
 
 @pytest.mark.parametrize('merge', [True, False])
-def test_iteration_is_vis_and_lazy_composite_entries(dev, merge):
+def test_iteration_is_vis_and_composite_entries(dev, merge):
     rend = exa.GaussianRenderer()
     s, h, r = _sets(800, 600, 11, dev)
     cam, bg = _cam(5, dev), torch.rand(3, device=dev)
@@ -98,16 +98,13 @@ def test_iteration_is_vis_and_lazy_composite_entries(dev, merge):
     out = exa.render_iteration(rend, s, h, r, (H, W), cam, bg, merge=merge)
     for name in exa.ITERATION_RENDERS:
         o = out[name]
-        assert list(o.keys())[:4] == ['img', 'depthmap', 'mask', 'mean_2d'], name
-        assert torch.equal(o['is_vis'], o['radius'] > 0), name           # (a merged composite concatenates them on first access)
+        assert type(o) is dict and list(o.keys()) == ['img', 'depthmap', 'mask', 'mean_2d', 'is_vis', 'radius'], name
+        assert torch.equal(o['is_vis'], o['radius'] > 0), name
         assert o['is_vis'].dtype == torch.bool
-        assert sorted(o.keys()) == sorted(['img', 'depthmap', 'mask', 'mean_2d', 'is_vis', 'radius']) and len(o) == 6
     for comp, b in (('scene_human', 'human'), ('scene_human_refined', 'human_refined')):
         assert torch.equal(out[comp]['radius'], torch.cat((out['scene']['radius'], out[b]['radius'])))
         assert out[comp]['radius'].shape == (1400,)
-        plain = dict(out[comp])                       # once read they are plain entries: a copy holds real tensors
-        assert type(plain) is dict and torch.is_tensor(plain['is_vis']) and torch.is_tensor(plain['radius'])
-        assert all(torch.is_tensor(v) for v in {**out[comp]}.values())
+        assert all(torch.is_tensor(v) for v in out[comp].values())
 
 
 def _iteration(sets, cam, bg, G, which, dev, fold, second=False):

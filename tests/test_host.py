@@ -260,40 +260,6 @@ def test_renderer_plumbing_of_sh_assets(monkeypatch):
     assert j['frozen']['shs'] is sh and j['frozen']['colors_precomp'] is None
 
 
-def test_composite_output_dict_behaves_like_the_dict_it_stands_for():
-    """renderer._CompositeOutput: radius / is_vis of a composite render are concatenated on first access; every way of
-    reading or copying the dict must see real tensors, in the reference's key order (module.py:641-647)."""
-    import copy
-    import pickle
-    from exavatar_release_amd.renderer import _CompositeOutput
-    ra, rb = torch.tensor([3, 0, 2], dtype=torch.int32), torch.tensor([0, 5], dtype=torch.int32)
-
-    def make():
-        base = {'img': torch.zeros(3, 2, 2), 'depthmap': torch.zeros(1, 2, 2), 'mask': torch.zeros(1, 2, 2), 'mean_2d': torch.zeros(2, 3)}
-        return _CompositeOutput(base, ((ra, rb), (ra > 0, rb > 0)))
-    want_r, want_v = torch.cat((ra, rb)), torch.cat((ra, rb)) > 0
-    o = make()
-    assert list(o.keys()) == ['img', 'depthmap', 'mask', 'mean_2d', 'is_vis', 'radius'] and len(o) == 6 and 'radius' in o
-    assert o._lazy is not None and torch.equal(o['img'], torch.zeros(3, 2, 2)) and o._lazy is not None   # other keys: no work
-    assert torch.equal(o['radius'], want_r) and torch.equal(o['is_vis'], want_v) and o['is_vis'].dtype == torch.bool
-    assert o._lazy is None and o['radius'] is o['radius']
-    for how in (dict, lambda d: {**d}, lambda d: d.copy(), copy.copy, lambda d: dict(d.items()), lambda d: pickle.loads(pickle.dumps(d)),
-                lambda d: {k: d[k] for k in d}, lambda d: dict(zip(d.keys(), d.values())), lambda d: {k: d.get(k) for k in d}):
-        c = how(make())
-        assert torch.equal(c['radius'], want_r) and torch.equal(c['is_vis'], want_v), how
-    o = make()
-    o['radius'] = 'mine'
-    assert o['radius'] == 'mine' and torch.equal(o['is_vis'], want_v)
-    o = make()
-    o.update(radius='mine')
-    assert o['radius'] == 'mine'
-    o = make()
-    assert torch.equal(o.pop('radius'), want_r) and 'radius' not in o and len(o) == 5
-    assert 'radius' in repr(make()) and 'None' not in repr(make())
-    assert make().get('nothing', 7) == 7 and torch.equal(make().get('radius'), want_r)
-    assert torch.equal(make().setdefault('radius', 1), want_r)
-
-
 def test_densify_and_prune_screen_space_criterion_and_reference_quirk():
     """``densify_and_prune`` (reference avatar/common/nets/module.py:159-240): the reference's screen-space prune reads a
     ``radius_max`` its own ``densify()`` has just zeroed, so it never fires (default, topology as the reference's); with
