@@ -74,6 +74,8 @@ class ExaRasterComposeJob(ctypes.Structure):
         ('out_color', c_void_p), ('out_depth', c_void_p), ('out_alpha', c_void_p),
         ('host_header', c_void_p), ('header_tag', ctypes.c_uint32),
         ('a_color', c_void_p), ('a_depth', c_void_p), ('a_alpha', c_void_p), ('a_bg', c_void_p),
+        ('radii_a', c_void_p), ('radii_b', c_void_p), ('radii_out', c_void_p),
+        ('is_vis_a', c_void_p), ('is_vis_b', c_void_p), ('is_vis_out', c_void_p),
     ]
 
 
@@ -169,7 +171,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError here = ABI mismatch, fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.exa_raster_version() < 136:
+    if lib.exa_raster_version() < 137:
         raise RuntimeError('exavatar_release_amd: libexa_raster.so is too old')
     _lib = lib
     return lib

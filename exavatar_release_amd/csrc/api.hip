@@ -493,6 +493,8 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
         const int n_src = (j.a_color != nullptr) + (j.a_depth != nullptr) + (j.a_alpha != nullptr) + (j.a_bg != nullptr);
         if (n_src != 0 && n_src != 4) return fail(EXA_RASTER_E_INVALID, "composite: pass all of a_color / a_depth / a_alpha / a_bg or none");
         if (j.a_color == j.out_color && j.a_color) return fail(EXA_RASTER_E_ALIAS, "composite: a_color aliases out_color");
+        if ((j.radii_out && (!j.radii_a || !j.radii_b)) || (j.is_vis_out && (!j.is_vis_a || !j.is_vis_b)))
+            return fail(EXA_RASTER_E_NULLPTR, "composite: radii_out / is_vis_out need the sources' arrays");
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int k0 = 0; k0 < K; k0 += MAX_BATCH) {
@@ -513,6 +515,9 @@ int exa_raster_forward_compose_batch(const ExaRasterComposeJob* jobs, int32_t K,
             c.capacity = j.capacity; c.capacity_b = j.capacity_b;
             c.host_hdr = static_cast<uint32_t*>(j.host_header); c.hdr_tag = j.header_tag;
             c.src_color = j.a_color; c.src_bg = j.a_bg; c.bg = j.settings->bg;
+            c.P_a = j.P_a; c.P_b = j.P_b;
+            c.radii_a = j.radii_a; c.radii_b = j.radii_b; c.radii_out = j.radii_out;
+            c.vis_a = j.is_vis_a; c.vis_b = j.is_vis_b; c.vis_out = j.is_vis_out;
             RenderFwdArgs& r = ra[k];
             r.grid = g; r.splats = static_cast<const Splat*>(j.geom_a); r.splats2 = static_cast<const Splat*>(j.geom_b);
             r.tw = c.tw; r.bw = c.bw; r.capacity = j.capacity;

@@ -355,6 +355,9 @@ struct ComposeArgs {
     TileWs tw; BinWs bw; uint64_t capacity, capacity_b;   // the composite's own: bw.touched holds capacity_b bytes
     uint32_t* host_hdr; uint32_t hdr_tag;
     const float* src_color; const float* src_bg; const float* bg;    // see RenderFwdArgs.src_color
+    int P_a, P_b;                                                     // optional outputs radii / is_vis of cat(A, B)
+    const int32_t* radii_a; const int32_t* radii_b; int32_t* radii_out;
+    const uint8_t* vis_a; const uint8_t* vis_b; uint8_t* vis_out;
 };
 hipError_t launch_compose(const ComposeArgs* a, int K, hipStream_t s, int parts = 3);
 // bin workspace of a composite: merged ids [cap] | zero-filled: owner [cap / 64 + 1], blended mask [cap / 64 + 1], touched

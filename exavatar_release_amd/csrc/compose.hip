@@ -44,6 +44,12 @@ __global__ __launch_bounds__(CBLOCK) void compose_kernel(Batch<ComposeArgs> batc
         uint4* p = a.bw.owner;
         const size_t first = (size_t)((int)blockIdx.x - 1) * CBLOCK + tid, stride = (size_t)C_ZERO_WGS * CBLOCK;
         for (size_t i = first; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+        // the composite's radii / is_vis = the sources' one behind the other (ExaRasterComposeJob.radii_out)
+        const size_t n_ab = (size_t)a.P_a + (size_t)a.P_b;
+        if (a.radii_out)
+            for (size_t i = first; i < n_ab; i += stride) a.radii_out[i] = i < (size_t)a.P_a ? a.radii_a[i] : a.radii_b[i - a.P_a];
+        if (a.vis_out)
+            for (size_t i = first; i < n_ab; i += stride) a.vis_out[i] = i < (size_t)a.P_a ? a.vis_a[i] : a.vis_b[i - a.P_a];
         return;                                                  // (the launch order of the blend: merge_kernel writes it)
     }
     const uint2* __restrict__ ra = a.tw_a.ranges;

@@ -764,7 +764,7 @@ class _Rasterize(torch.autograd.Function):
 
 class _CJob:
     """Host-side record of one composite render."""
-    __slots__ = ('a', 'b', 'rs', 'settings', 'keep', 'planes', 'radii', 'ws', 'tile_ptr', 'bin_ptr', 'capacity', 'tb',
+    __slots__ = ('a', 'b', 'rs', 'settings', 'keep', 'planes', 'radii', 'is_vis', 'ws', 'tile_ptr', 'bin_ptr', 'capacity', 'tb',
                  'report', 'key')
 
 
@@ -803,6 +803,9 @@ def _compose_launch(cjobs, store_ctx, device, capturing, sorted_event=None):
         if config.compose_reuse_source and ja.settings.bg:
             pa = ja.planes.data_ptr()
             a.a_color, a.a_depth, a.a_alpha, a.a_bg = pa, pa + 12 * H * W, pa + 16 * H * W, ja.settings.bg
+        if c.radii is not None:
+            a.radii_a, a.radii_b, a.radii_out = ja.radii.data_ptr(), jb.radii.data_ptr(), c.radii.data_ptr()
+            a.is_vis_a, a.is_vis_b, a.is_vis_out = ja.is_vis.data_ptr(), jb.is_vis.data_ptr(), c.is_vis.data_ptr()
         c.report = None
         a.host_header, a.header_tag = None, 0
         if pool is not None:
@@ -871,12 +874,15 @@ class _Compose(torch.autograd.Function):
                 if c.settings.viewmatrix != ja.settings.viewmatrix:
                     raise ValueError('composite render: its camera differs from the sources\'')
                 c.planes = torch.empty((5, ja.H, ja.W), dtype=_F32, device=device)
-                c.radii = torch.cat((ja.radii, jb.radii)) if want_radii else None
+                # radii / is_vis of cat(A, B): written by the composite's own ranges launch (ExaRasterComposeJob.radii_out)
+                c.radii = torch.empty(ja.P + jb.P, dtype=torch.int32, device=device) if want_radii else None
+                c.is_vis = torch.empty(ja.P + jb.P, dtype=torch.bool, device=device) if want_radii else None
                 c.key = ('compose', device.index, ja.P, jb.P, ja.H, ja.W)
                 cjobs.append(c)
             _compose_launch(cjobs, need_ctx, device, capturing,
                             _overlap.pop(device.index, None) if capturing and config.overlap_composites else None)
         ctx.need_ctx = need_ctx
+        _tls.is_vis = [c.is_vis for c in cjobs]
         outs = []
         for c in cjobs:
             col, d, al = torch.split_with_sizes(c.planes, _PLANES)
@@ -1004,7 +1010,8 @@ def rasterize_composites(sources, jobs, token=None, radii=True):
     render got; they receive this render's gradients), a fresh ``means2D`` probe of B's length and ``raster_settings`` (the
     composite's background).  The composite reuses the sources' splat records and MERGES their sorted per-sub-tile lists:
     no preprocess, binning or sort of its own, bit-identical to rendering ``cat(A, B)``.  Returns K ``(color, radii, depth,
-    alpha)`` tuples; ``radii`` = ``cat(radii_a, radii_b)``.  ``token``: the ``.token`` of the handles list when every source B
+    alpha)`` tuples; ``radii`` = ``cat(radii_a, radii_b)`` (and ``take_is_vis()`` the matching ``is_vis``), copied by the
+    composite's own first launch.  ``token``: the ``.token`` of the handles list when every source B
     belongs to that one batched call (see :class:`_Compose`); None is always correct.  ``radii=False``: the radii slot of
     the returned tuples is None (no concatenation kernel; the caller builds it from the sources' radii if anybody asks)."""
     jobs = list(jobs)

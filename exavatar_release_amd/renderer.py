@@ -340,18 +340,16 @@ def render_iteration(renderer, scene_asset, human_asset, human_asset_refined, im
         # ... and the two composites as MERGES of their sorted lists (white background, as the reference renders them)
         comp = [_raster_job(human_asset, img_shape, cam_param, None, mean_2d=pr[2], **kw),
                 _raster_job(human_asset_refined, img_shape, cam_param, None, mean_2d=pr[4], **kw)]
-        couts = rasterize_composites([(handles[0], handles[1]), (handles[0], handles[2])], comp, token=handles.token,
-                                     radii=False)
+        couts = rasterize_composites([(handles[0], handles[1]), (handles[0], handles[2])], comp, token=handles.token)
+        cvis = take_is_vis()
         res = [_output_dict(plain[k], outs[k], vis[k]) for k in range(3)]
 
-        def composite(k, b):
-            # radius / is_vis cover cat(scene, human), as the reference's concatenated render returns them (two small
-            # concatenations per composite; inside a captured iteration they are nodes of the forward graph)
-            img, _none, depth, mask = couts[k]
-            radius = torch.cat((outs[0][1], outs[b][1]))
-            is_vis = torch.cat((vis[0], vis[b])) if vis[0] is not None and vis[b] is not None else radius > 0
-            return {'img': img, 'depthmap': depth, 'mask': mask, 'mean_2d': comp[k]['means2D'], 'is_vis': is_vis, 'radius': radius}
-        return dict(zip(ITERATION_RENDERS, [res[0], res[1], composite(0, 1), res[2], composite(1, 2)]))
+        def composite(k):
+            # radius / is_vis cover cat(scene, human), as the reference's concatenated render returns them: written by the
+            # composite's own ranges launch (ExaRasterComposeJob.radii_out / is_vis_out), no concatenation kernels
+            img, radius, depth, mask = couts[k]
+            return {'img': img, 'depthmap': depth, 'mask': mask, 'mean_2d': comp[k]['means2D'], 'is_vis': cvis[k], 'radius': radius}
+        return dict(zip(ITERATION_RENDERS, [res[0], res[1], composite(0), res[2], composite(1)]))
     rj = [_raster_job(scene_asset, img_shape, cam_param, None, scene_densify_stats, mean_2d=pr[0], **kw),
           _raster_job(human_asset, img_shape, cam_param, bg, mean_2d=pr[1], **kw),
           _raster_job(human_asset, img_shape, cam_param, None, None, scene_asset, mean_2d=pr[2], **kw),

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 136          /* 0.1.3.6: exa_raster_select_row; 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 137          /* 0.1.3.7: ExaRasterComposeJob.radii_out / is_vis_out; 0.1.3.6: exa_raster_select_row; 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 
@@ -290,6 +290,11 @@ typedef struct ExaRasterComposeJob {
      * being blended again.  In ExAvatar's scene + human composites (avatar/main/model.py:129,146: both on the default white
      * background) that is every sub-tile outside the person: ~3/4 of the image.  Bit-identical either way. */
     const float* a_color; const float* a_depth; const float* a_alpha; const float* a_bg;
+    /* Optional (radii_out / is_vis_out NULL = off): the composite's radii [P_a + P_b] and is_vis [P_a + P_b] = the sources'
+     * arrays one behind the other -- what a render of cat(A, B) returns (reference module.py:641-647) -- copied by the
+     * workgroups of the ranges launch that zero-fill the workspace anyway: no launch of their own. */
+    const int32_t* radii_a; const int32_t* radii_b; int32_t* radii_out;
+    const uint8_t* is_vis_a; const uint8_t* is_vis_b; uint8_t* is_vis_out;
 } ExaRasterComposeJob;
 /* tile_bytes / bin_bytes of a composite's workspaces, grad_bytes of its backward scratch (geom_bytes = 0) */
 int exa_raster_compose_sizes(int32_t W, int32_t H, uint64_t capacity, uint64_t capacity_b, ExaRasterWorkspaceSizes* out);
