@@ -35,7 +35,13 @@ with open(os.path.join(out, prefix + '_bench.json'), 'w') as f:
 
 # ---- kernel stats ----------------------------------------------------------------------------------------
 stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
-with open(os.path.join(out, prefix + '_kernel_stats.md'), 'w') as f:
+_ks = os.path.join(out, prefix + '_kernel_stats.md')
+_tail = ''            # hand-written sections ("## ...") of an existing summary survive a regeneration
+if os.path.exists(_ks):
+    _old = open(_ks).read()
+    if '\n## ' in _old:
+        _tail = _old[_old.index('\n## '):]
+with open(_ks, 'w') as f:
     f.write('# %s: rocprofv3 kernel statistics of the bench command\n\n' % prefix)
     f.write('Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 '
             '--no-cpu-baseline --no-concurrent` (C3, 1 x MI355X, hipGraph replay; includes the untimed calibration / warm-up '
@@ -49,6 +55,7 @@ with open(os.path.join(out, prefix + '_kernel_stats.md'), 'w') as f:
             for r in csv.DictReader(g):
                 f.write('| %s | %s | %.1f | %.1f | %.1f | %s |\n' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3,
                                                                   float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage']))
+    f.write(_tail)
 
 # machine-readable copy (bench.py quotes the dominant kernel's rocprof average next to its own HIP-event bracket)
 if stats:
