@@ -204,7 +204,7 @@ class GraphedIteration:
         The object can be used again afterwards (it captures anew).  Call it when a training run ends; ``with
         GraphedIteration(...) as it:`` does."""
         self._release()
-        self._keeper = None
+        self._pool, self._keeper = None, None          # (the pool dies with its last graph; the next capture starts a new one)
 
     def __enter__(self):
         return self
@@ -360,8 +360,8 @@ class GraphedIteration:
                     rz._capture_report = rz._capture_report_c = None
                 cap.outs = res
                 cap.out_list = [res[k][n] for k in ITERATION_RENDERS for n in ('img', 'depthmap', 'mask')]
-                # radius / is_vis of the five renders: static tensors the replay rewrites (the composites' are concatenations
-                # recorded in the forward graph)
+                # radius / is_vis of the five renders: static tensors the replay rewrites (the composites' are written by their
+                # own ranges launch, ExaRasterComposeJob.radii_out)
                 cap.radii = {k: (res[k]['radius'], res[k]['is_vis']) for k in ITERATION_RENDERS}
                 cap.bwd = {}
                 self.captures += 1
