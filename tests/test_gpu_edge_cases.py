@@ -45,7 +45,8 @@ def _to(d, dev, grad=True):
     return {k: v.to(dev).requires_grad_(grad) for k, v in d.items()}
 
 
-@pytest.mark.parametrize('trial', range(16))
+# EXA_FUZZ_TRIALS=n widens the seeded fuzz (round 5 ran it once with 300 seeds: profiles/r05_fuzz_300.log)
+@pytest.mark.parametrize('trial', range(int(os.environ.get('EXA_FUZZ_TRIALS', '16'))))
 def test_edge_case_fuzz_through_the_hip_path(dev, trial):
     """The 16 seeded trials of tests/test_c_oracle.py::test_edge_case_fuzz_* through GaussianRenderer: opacity 0 / 1 / at
     the 1/255 bar, scales x1e-4 .. x300, centres at / around / behind the near plane and ON the camera plane, unnormalised
