@@ -133,8 +133,47 @@ __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const ui
     }
 }
 
+// cov2D = T Sigma T^T, its determinant and the gradient of the conic: in DOUBLE since round 5 (everything else float).
+// A needle-like projected covariance (eigenvalues 894 and 1.0 px^2 in the seeds that showed it: x300 scales, unnormalised
+// quaternions) makes (da, db, dc) differences of terms 200^2 x their size, so the float rounding of a, b, c
+// themselves (1e-7 relative, accumulated over the two 3 x 3 products) came back as up to 3 % of that Gaussian's
+// dL/dscale: 1.5e-3 of the tensor's max-norm, 2 of 300 fuzz seeds over the 1e-3 bar (EXA_FUZZ_TRIALS=300).  Which
+// stage has to be double was settled on the C oracle with one precision per stage (mean projection, Sigma, J / T,
+// T Sigma T^T, conic gradient, everything behind): T Sigma T^T + the conic gradient alone bring the worst of the 300 seeds
+// to 3.4e-5, the same as all-double; any other single stage leaves it at 1.2-2.2e-3.  (All-double was built first:
+// 134 -> 168 VGPRs here, 248 -> 283 in the SUM kernels = one wave per SIMD there, K = 8 batches 9 250 -> 8 370 it/s.)
+struct Cov2DGrad { float ST0[3], ST1[3], dpx, dpy, da, db, dc; };
+__device__ __forceinline__ Cov2DGrad cov2d_conic_grad(float S00, float S01, float S02, float S11, float S12, float S22,
+                                                      const float (&T0)[3], const float (&T1)[3],
+                                                      float mx, float my, float mxx, float mxy, float myy) {
+#pragma clang fp contract(off)
+    const double t0x = T0[0], t0y = T0[1], t0z = T0[2], t1x = T1[0], t1y = T1[1], t1z = T1[2];
+    const double ST0[3] = {S00 * t0x + S01 * t0y + S02 * t0z, S01 * t0x + S11 * t0y + S12 * t0z, S02 * t0x + S12 * t0y + S22 * t0z};
+    const double ST1[3] = {S00 * t1x + S01 * t1y + S02 * t1z, S01 * t1x + S11 * t1y + S12 * t1z, S02 * t1x + S12 * t1y + S22 * t1z};
+    const double a = (t0x * ST0[0] + t0y * ST0[1] + t0z * ST0[2]) + LOWPASS;
+    const double b = t0x * ST1[0] + t0y * ST1[1] + t0z * ST1[2];
+    const double c = (t1x * ST1[0] + t1y * ST1[1] + t1z * ST1[2]) + LOWPASS;
+    const double det = a * c - b * b;
+    // upstream computeCov2DCUDA (backward): "denom2inv" = 1 / (det^2 + 1e-7), not the exact 1 / det^2
+    const double idet = 1.0 / det, idet2 = 1.0 / (det * det + 1e-7);
+    // moments of s = dL/dG * G  ->  d/d(pixel centre) and d/d(conic) with the raw conic (A, B, C) = (c, -b, a) / det
+    const double cA = c * idet, cB = -b * idet, cC = a * idet;
+    const double dA = -0.5 * mxx, dB = -(double)mxy, dC = -0.5 * myy;
+    Cov2DGrad r;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { r.ST0[j] = (float)ST0[j]; r.ST1[j] = (float)ST1[j]; }
+    r.dpx = (float)(-cA * mx - cB * my);
+    r.dpy = (float)(-cC * my - cB * mx);
+    // conic -> cov2D (a, b, c)
+    r.da = (float)(idet2 * (-c * c * dA + b * c * dB - b * b * dC));
+    r.dc = (float)(idet2 * (-b * b * dA + b * a * dB - a * a * dC));
+    r.db = (float)(idet2 * (2.0 * b * c * dA - (det + 2.0 * b * b) * dB + 2.0 * a * b * dC));
+    return r;
+}
+
+// (two waves per SIMD at least: the SUM kernels sit at the 256-register line, and one wave per SIMD costs the K = 8 batches 5-10 %)
 template <bool SUM, int VW, bool SH, bool PREFIX>
-__global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K, int dens_shared) {
+__global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K, int dens_shared) {
     static_assert(VW == 1 || (SUM && VW == BLOCK / 64), "views are split over the waves of a workgroup in SUM mode only");
     __shared__ float s_red[VW > 1 ? 23 * BLOCK : 1];
     __shared__ GatherLds s_gather[BLOCK / 64];
@@ -233,6 +272,10 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         float vq[4] = {0.f, 0.f, 0.f, 0.f}, vcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float vop = 0.f, vcol[3] = {0.f, 0.f, 0.f};
         if (vis) {
+            // Contraction off for the whole chain rule: it is compiled into six instantiations of this kernel, the compiler
+            // contracts each on its own, and a view's gradients have to come out of the batched (SUM) instantiations as they
+            // come out of the single-view ones (dL/dmean2D bit for bit: tests/test_gpu_parity.py, batched views)
+#pragma clang fp contract(off)
             float mx = own[0], my = own[1], mxx = own[2], mxy = own[3], myy = own[4], dz_view = own[9];
             vop = own[5]; vcol[0] = own[6]; vcol[1] = own[7]; vcol[2] = own[8];
 
@@ -241,42 +284,29 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             vop += co[5]; vcol[0] += co[6]; vcol[1] += co[7]; vcol[2] += co[8]; dz_view += co[9];
 
         // ---- recompute the forward quantities ---------------------------------------------------
-        // In DOUBLE since round 5.  A needle-like projected covariance (eigenvalues 894 and 1.0 px^2 in the seeds that showed it:
-        // large anisotropic splats with unnormalised quaternions) makes det = a c - b^2 a difference of two numbers 200 x its
-        // size, and the gradient of the conic divides by det^2: in float the chain rule of such a Gaussian was off by up to 3 %
-        // (1.5e-3 of the tensor's max-norm: 2 of 300 fuzz seeds over the 1e-3 bar, EXA_FUZZ_TRIALS=300), in double all 300 pass.
-        // The kernel is latency-bound (VALU 15 % active): 134 -> 168 VGPRs, still three waves per SIMD, no measurable time
-        // (19.0-19.1 against 19.0-19.7 us by events).  Decisions the forward took in float (the +-1.3 tan(fov) clamp) are
-        // taken on the same float expressions here.
-        typedef double real;
-        const real xd = x, yd = y, zd = z;
-        const real pvx = ((v[0] * xd + v[4] * yd) + v[8] * zd) + v[12];
-        const real pvy = ((v[1] * xd + v[5] * yd) + v[9] * zd) + v[13];
-        const real pvz = ((v[2] * xd + v[6] * yd) + v[10] * zd) + v[14];
-        const real hx = ((p[0] * xd + p[4] * yd) + p[8] * zd) + p[12];
-        const real hy = ((p[1] * xd + p[5] * yd) + p[9] * zd) + p[13];
-        const real hw = ((p[3] * xd + p[7] * yd) + p[11] * zd) + p[15];
-        const real pw = 1.0 / (hw + 1e-7);
-        // (the forward's own float expressions, preprocess_fwd.hip: what its clamp saw)
-        const float pvx_f = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
-        const float pvy_f = ((v[1] * x + v[5] * y) + v[9] * z) + v[13];
-        const float pvz_f = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
+        const float pvx = ((v[0] * x + v[4] * y) + v[8] * z) + v[12];
+        const float pvy = ((v[1] * x + v[5] * y) + v[9] * z) + v[13];
+        const float pvz = ((v[2] * x + v[6] * y) + v[10] * z) + v[14];
+        const float hx = ((p[0] * x + p[4] * y) + p[8] * z) + p[12];
+        const float hy = ((p[1] * x + p[5] * y) + p[9] * z) + p[13];
+        const float hw = ((p[3] * x + p[7] * y) + p[11] * z) + p[15];
+        const float pw = 1.0f / (hw + 1e-7f);
 
-        real S00, S01, S02, S11, S12, S22;
-        real R[9], sc[3];
-        real qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        float S00, S01, S02, S11, S12, S22;
+        float R[9], sc[3];
+        float qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
         if (a.cov3D_precomp) {
             S00 = in_cov[0]; S01 = in_cov[1]; S02 = in_cov[2]; S11 = in_cov[3]; S12 = in_cov[4]; S22 = in_cov[5];
         } else {
-            sc[0] = (real)a.scale_modifier * in_s[0];
-            sc[1] = (real)a.scale_modifier * in_s[1];
-            sc[2] = (real)a.scale_modifier * in_s[2];
+            sc[0] = a.scale_modifier * in_s[0];
+            sc[1] = a.scale_modifier * in_s[1];
+            sc[2] = a.scale_modifier * in_s[2];
             const float4 q = in_q;
             qr = q.x; qx = q.y; qy = q.z; qz = q.w;
             R[0] = 1.0f - 2.0f * (qy * qy + qz * qz); R[1] = 2.0f * (qx * qy - qr * qz); R[2] = 2.0f * (qx * qz + qr * qy);
             R[3] = 2.0f * (qx * qy + qr * qz); R[4] = 1.0f - 2.0f * (qx * qx + qz * qz); R[5] = 2.0f * (qy * qz - qr * qx);
             R[6] = 2.0f * (qx * qz - qr * qy); R[7] = 2.0f * (qy * qz + qr * qx); R[8] = 1.0f - 2.0f * (qx * qx + qy * qy);
-            real M[9];
+            float M[9];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -288,48 +318,32 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             S12 = M[3] * M[6] + M[4] * M[7] + M[5] * M[8];
             S22 = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
         }
-        const float limx_f = 1.3f * a.tanfovx, limy_f = 1.3f * a.tanfovy;
-        const float txtz_f = pvx_f / pvz_f, tytz_f = pvy_f / pvz_f;
-        const bool clamp_x = txtz_f < -limx_f || txtz_f > limx_f;
-        const bool clamp_y = tytz_f < -limy_f || tytz_f > limy_f;
-        const real limx = limx_f, limy = limy_f;
-        const real tz = pvz;
-        const real tx = (clamp_x ? (txtz_f < 0.f ? -limx : limx) : pvx / tz) * tz;
-        const real ty = (clamp_y ? (tytz_f < 0.f ? -limy : limy) : pvy / tz) * tz;
-        const real itz = 1.0 / tz, itz2 = itz * itz;
-        const real J00 = a.focal_x * itz, J02 = -(a.focal_x * tx) * itz2;
-        const real J11 = a.focal_y * itz, J12 = -(a.focal_y * ty) * itz2;
+        const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+        const float tz = pvz;
+        const float txtz = pvx / tz, tytz = pvy / tz;
+        const bool clamp_x = txtz < -limx || txtz > limx;
+        const bool clamp_y = tytz < -limy || tytz > limy;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * tz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * tz;
+        const float itz = 1.0f / tz, itz2 = itz * itz;
+        const float J00 = a.focal_x * itz, J02 = -(a.focal_x * tx) * itz2;
+        const float J11 = a.focal_y * itz, J12 = -(a.focal_y * ty) * itz2;
         // Rv[i][j] = v[j*4+i]
-        const real T0[3] = {J00 * v[0] + J02 * v[2], J00 * v[4] + J02 * v[6], J00 * v[8] + J02 * v[10]};
-        const real T1[3] = {J11 * v[1] + J12 * v[2], J11 * v[5] + J12 * v[6], J11 * v[9] + J12 * v[10]};
-        const real ST0[3] = {S00 * T0[0] + S01 * T0[1] + S02 * T0[2], S01 * T0[0] + S11 * T0[1] + S12 * T0[2],
-                              S02 * T0[0] + S12 * T0[1] + S22 * T0[2]};
-        const real ST1[3] = {S00 * T1[0] + S01 * T1[1] + S02 * T1[2], S01 * T1[0] + S11 * T1[1] + S12 * T1[2],
-                              S02 * T1[0] + S12 * T1[1] + S22 * T1[2]};
-        const real ca2 = (T0[0] * ST0[0] + T0[1] * ST0[1] + T0[2] * ST0[2]) + LOWPASS;
-        const real cb2 = T0[0] * ST1[0] + T0[1] * ST1[1] + T0[2] * ST1[2];
-        const real cc2 = (T1[0] * ST1[0] + T1[1] * ST1[1] + T1[2] * ST1[2]) + LOWPASS;
-        const real det = ca2 * cc2 - cb2 * cb2;
-        // upstream computeCov2DCUDA (backward): "denom2inv" = 1 / (det^2 + 1e-7), not the exact 1 / det^2
-        const real idet = 1.0 / det, idet2 = 1.0 / (det * det + 1e-7);
-        // moments of s = dL/dG * G  ->  d/d(pixel centre) and d/d(conic) with the raw conic (A, B, C)
-        const real cA = cc2 * idet, cB = -cb2 * idet, cC = ca2 * idet;
-        const real dpx = -cA * mx - cB * my, dpy = -cC * my - cB * mx;
-        const real dA = -0.5f * mxx, dB = -mxy, dC = -0.5f * myy;
-
-        // ---- conic (A, B, C) = (c, -b, a) / det  ->  cov2D (a, b, c) -----------------------------
-        const real da = idet2 * (-cc2 * cc2 * dA + cb2 * cc2 * dB - cb2 * cb2 * dC);
-        const real dc = idet2 * (-cb2 * cb2 * dA + cb2 * ca2 * dB - ca2 * ca2 * dC);
-        const real db = idet2 * (2.0f * cb2 * cc2 * dA - (det + 2.0f * cb2 * cb2) * dB + 2.0f * ca2 * cb2 * dC);
+        const float T0[3] = {J00 * v[0] + J02 * v[2], J00 * v[4] + J02 * v[6], J00 * v[8] + J02 * v[10]};
+        const float T1[3] = {J11 * v[1] + J12 * v[2], J11 * v[5] + J12 * v[6], J11 * v[9] + J12 * v[10]};
+        const Cov2DGrad cg = cov2d_conic_grad(S00, S01, S02, S11, S12, S22, T0, T1, mx, my, mxx, mxy, myy);
+        const float* ST0 = cg.ST0;
+        const float* ST1 = cg.ST1;
+        const float dpx = cg.dpx, dpy = cg.dpy, da = cg.da, db = cg.db, dc = cg.dc;
 
         // ---- cov2D -> Sigma3 (full, unsymmetrised gradient G) and -> T ----------------------------
         // G_jk = da T0j T0k + db T0j T1k + dc T1j T1k
-        real G[9];
+        float G[9];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
             for (int k = 0; k < 3; ++k) G[j * 3 + k] = da * T0[j] * T0[k] + db * T0[j] * T1[k] + dc * T1[j] * T1[k];
-        real dT0[3], dT1[3];
+        float dT0[3], dT1[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             dT0[j] = 2.0f * da * ST0[j] + db * ST1[j];
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             vcov[3] = G[4]; vcov[4] = G[5] + G[7]; vcov[5] = G[8];
         } else {
             // Sigma = M M^T, M = R diag(s):  dL/dM = (G + G^T) M
-            real M[9], dM[9];
+            float M[9], dM[9];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -349,12 +363,12 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    real acc = 0.f;
+                    float acc = 0.f;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) acc += (G[i * 3 + k] + G[k * 3 + i]) * M[k * 3 + j];
                     dM[i * 3 + j] = acc;
                 }
-            real dR[9];
+            float dR[9];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 vscale[j] = a.scale_modifier * (dM[0 * 3 + j] * R[0 * 3 + j] + dM[1 * 3 + j] * R[1 * 3 + j] + dM[2 * 3 + j] * R[2 * 3 + j]);
@@ -368,14 +382,14 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         }
 
         // ---- T = J Rv -> J -> view-space t ---------------------------------------------------------
-        const real dJ00 = dT0[0] * v[0] + dT0[1] * v[4] + dT0[2] * v[8];
-        const real dJ02 = dT0[0] * v[2] + dT0[1] * v[6] + dT0[2] * v[10];
-        const real dJ11 = dT1[0] * v[1] + dT1[1] * v[5] + dT1[2] * v[9];
-        const real dJ12 = dT1[0] * v[2] + dT1[1] * v[6] + dT1[2] * v[10];
-        const real itz3 = itz2 * itz;
-        const real dtx = clamp_x ? 0.f : -a.focal_x * itz2 * dJ02;
-        const real dty = clamp_y ? 0.f : -a.focal_y * itz2 * dJ12;
-        const real dtz = -a.focal_x * itz2 * dJ00 - a.focal_y * itz2 * dJ11 +
+        const float dJ00 = dT0[0] * v[0] + dT0[1] * v[4] + dT0[2] * v[8];
+        const float dJ02 = dT0[0] * v[2] + dT0[1] * v[6] + dT0[2] * v[10];
+        const float dJ11 = dT1[0] * v[1] + dT1[1] * v[5] + dT1[2] * v[9];
+        const float dJ12 = dT1[0] * v[2] + dT1[1] * v[6] + dT1[2] * v[10];
+        const float itz3 = itz2 * itz;
+        const float dtx = clamp_x ? 0.f : -a.focal_x * itz2 * dJ02;
+        const float dty = clamp_y ? 0.f : -a.focal_y * itz2 * dJ12;
+        const float dtz = -a.focal_x * itz2 * dJ00 - a.focal_y * itz2 * dJ11 +
                           2.0f * a.focal_x * tx * itz3 * dJ02 + 2.0f * a.focal_y * ty * itz3 * dJ12 + dz_view;
         // t = [mu, 1] @ viewmatrix[:, :3]
         vmean[0] = dtx * v[0] + dty * v[1] + dtz * v[2];
@@ -385,8 +399,8 @@ __global__ __launch_bounds__(BLOCK) void preprocess_bwd_kernel(Batch<PreprocessB
         // ---- pixel centre -> NDC -> clip -> mean ---------------------------------------------------
         vm2[0] = dpx * 0.5f * a.grid.W;
         vm2[1] = dpy * 0.5f * a.grid.H;
-        const real dhx = vm2[0] * pw, dhy = vm2[1] * pw;
-        const real dhw = -(vm2[0] * hx + vm2[1] * hy) * pw * pw;
+        const float dhx = vm2[0] * pw, dhy = vm2[1] * pw;
+        const float dhw = -(vm2[0] * hx + vm2[1] * hy) * pw * pw;
         vmean[0] += dhx * p[0] + dhy * p[1] + dhw * p[3];
         vmean[1] += dhx * p[4] + dhy * p[5] + dhw * p[7];
         vmean[2] += dhx * p[8] + dhy * p[9] + dhw * p[11];
