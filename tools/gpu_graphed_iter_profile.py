@@ -56,7 +56,7 @@ for sync in (False, True):
     run('GraphedIteration check=False', graphed_nc, sync_between=sync)
 # bare replays of the two graphs (no input copies, no autograd)
 cap = it._cap
-g_b = cap.bwd[tuple([True, False, False] * 5)][0]
+g_b = next(iter(cap.bwd.values()))[0]          # the backward graph of the gradient pattern the loop above used
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(50):
     cap.fwd.replay(); g_b.replay()
