@@ -67,17 +67,39 @@ static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 //   row 0 = (sum s dx, sum s dy, sum s dx^2, sum s dx dy)        s = dL/dG * G
 //   row 1 = (sum s dy^2, sum G dL/dalpha, sum w dL/dC_r, sum w dL/dC_g)    w = alpha T
 //   row 2 = (sum w dL/dC_b, sum w dL/dDepth, -, -)
-// PARTIAL_BYTES = 48: three rows packed (one or two cache lines; three separate arrays dirtied twice as many 32-byte
-// sectors, profiles/r02_hbm_traffic.md).  Round 5 measured the alternative -- one record = ONE 64-byte line, written whole
-// (row 3 = zeros: no straddled sector, no half-written line; EXA_PARTIAL_BYTES=64) -- three interleaved runs each on one box:
-// C3 6 597 / 6 623 / 6 609 it/s against 6 646 / 6 637 / 6 650 with 48 bytes (preprocess_bwd 19.6-20.0 vs 19.0 us by events,
-// render_bwd the same): the extra 16 bytes per record cost more than the alignment gives.  48 stays.
+// PARTIAL_BYTES = 40: the ten floats packed (records on 8-byte boundaries, written as 16 + 16 + 8 bytes), since late round 5.
+// Before: 48 (three whole rows; three separate arrays had dirtied twice as many 32-byte sectors, profiles/r02_hbm_traffic.md).
+// Measured alternatives, interleaved runs on one box each (EXA_PARTIAL_BYTES keeps all three buildable):
+//   64 (one record = one 64-byte line, written whole): C3 6 597 / 6 623 / 6 609 it/s against 6 646 / 6 637 / 6 650 with 48
+//      (preprocess_bwd 19.6-20.0 vs 19.0 us by events): the extra 16 bytes per record cost more than the alignment gives;
+//   40: 6 619 / 6 617 / 6 610 against 6 620 / 6 567 / 6 559 with 48 on one box (preprocess_bwd 19.4-19.6 vs 19.7-20.1 us,
+//      render_bwd 43.9-44.5 vs 44.0-44.5), 6 603 / 6 600 / 6 588 / 6 605 against 6 603 / 6 606 / 6 603 / 6 610 on a second:
+//      a wash in time (the two kernels are bound by instruction issue and latency, not by these bytes), gradients
+//      bit-identical, a sixth less workspace and 3.3 MB less written and re-read per C3 step.  Kept for the bytes.
 #ifndef EXA_PARTIAL_BYTES
-#define EXA_PARTIAL_BYTES 48
+#define EXA_PARTIAL_BYTES 40
 #endif
-constexpr int PARTIAL_BYTES = EXA_PARTIAL_BYTES, PARTIAL_ROWS = PARTIAL_BYTES / 16;
-static_assert(PARTIAL_BYTES == 48 || PARTIAL_BYTES == 64, "partial records: three rows packed, or one 64-byte line");
+constexpr int PARTIAL_BYTES = EXA_PARTIAL_BYTES;
+static_assert(PARTIAL_BYTES == 40 || PARTIAL_BYTES == 48 || PARTIAL_BYTES == 64, "partial records: ten floats packed, three rows, or one 64-byte line");
 struct PartialWs { float4* rec; };
+// rows of the record in slot `ps` (40-byte records sit on 8-byte boundaries: the accesses stay 16 bytes wide, which the
+// hardware serves at dword alignment)
+typedef float partial_v4 __attribute__((ext_vector_type(4), aligned(8)));
+typedef float partial_v2 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ char* partial_at(float4* rec, size_t ps) { return reinterpret_cast<char*>(rec) + ps * PARTIAL_BYTES; }
+__device__ __forceinline__ const char* partial_at(const float4* rec, size_t ps) { return reinterpret_cast<const char*>(rec) + ps * PARTIAL_BYTES; }
+__device__ __forceinline__ void partial_load(const float4* rec, size_t ps, float4& q0, float4& q1, float4& q2) {
+    const char* p = partial_at(rec, ps);
+    const partial_v4 a = *reinterpret_cast<const partial_v4*>(p), b = *reinterpret_cast<const partial_v4*>(p + 16);
+    q0 = make_float4(a.x, a.y, a.z, a.w); q1 = make_float4(b.x, b.y, b.z, b.w);
+    if (PARTIAL_BYTES == 40) {
+        const partial_v2 c = *reinterpret_cast<const partial_v2*>(p + 32);
+        q2 = make_float4(c.x, c.y, 0.f, 0.f);
+    } else {
+        const partial_v4 c = *reinterpret_cast<const partial_v4*>(p + 32);
+        q2 = make_float4(c.x, c.y, c.z, c.w);
+    }
+}
 
 struct Grid {
     int W, H;

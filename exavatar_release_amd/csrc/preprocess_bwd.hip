@@ -10,7 +10,7 @@
 // (pixel gradient * (W/2, H/2), z = 0), which is what the reference's densification reads
 // (avatar/main/train.py:51).
 //
-// HBM traffic per Gaussian: reads 1 B per instance + 48 B per BLENDED instance + 32 B of the splat record + 44 B
+// HBM traffic per Gaussian: reads 1 B per instance + 40 B per BLENDED instance + 32 B of the splat record + 44 B
 // inputs, writes 68 B of gradients (SH: + 12 * M B).
 #include "common.h"
 
@@ -33,7 +33,7 @@ namespace exa {
 // ---- wave-cooperative gather of the partial records ---------------------------------------------------------------
 // The 64 Gaussians of a wave own CONSECUTIVE ranges of the Gaussian-major instance numbering (a typical avatar splat ~6
 // instances, some lane of most waves 25-40).  Until round 4 every lane walked its own range -- `touched` bytes, then the
-// flagged 48-byte records, eight instances per trip -- and the wave left that loop with its slowest lane: five trips of two
+// flagged records, eight instances per trip -- and the wave left that loop with its slowest lane: five trips of two
 // dependent, fully divergent gathers = 9-12 us of the kernel's 17.6 on C3 (tools/gpu_pbwd_phases.py).  Now the wave
 // streams the concatenation of its lanes' ranges through LDS: stream position q -> (lane, instance) by a binary search
 // over the wave's prefix of instance counts, GCH positions per chunk with ALL their `touched` bytes requested at once and
@@ -44,7 +44,7 @@ namespace exa {
 #ifndef EXA_PBWD_GCH
 #define EXA_PBWD_GCH 256
 #endif
-constexpr int GCH = EXA_PBWD_GCH;             // staged slots per chunk and wave (48 B each)
+constexpr int GCH = EXA_PBWD_GCH;             // staged slots per chunk and wave (48 B of LDS each)
 struct GatherLds {
     uint32_t pre[64], off[64];
     float4 rec[GCH * 3];
@@ -104,15 +104,17 @@ __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const ui
                 const uint32_t bo = ((fl >> u) & 1u) ? slot[u] * (uint32_t)PARTIAL_BYTES : BUF_OOB;
                 q0[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo, 0, 0));
                 q1[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 16u, 0, 0));
-                q2[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 32u, 0, 0));
+                if (PARTIAL_BYTES == 40) {
+                    const float2 t = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, bo + 32u, 0, 0));
+                    q2[u] = make_float4(t.x, t.y, 0.f, 0.f);
+                } else {
+                    q2[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, bo + 32u, 0, 0));
+                }
             }
         } else {
 #pragma unroll
             for (int u = 0; u < GCH / 64; ++u) {
-                if ((fl >> u) & 1u) {
-                    const float4* src = prec + (size_t)slot[u] * PARTIAL_ROWS;
-                    q0[u] = src[0]; q1[u] = src[1]; q2[u] = src[2];
-                }
+                if ((fl >> u) & 1u) partial_load(prec, slot[u], q0[u], q1[u], q2[u]);
             }
         }
 #pragma unroll
@@ -247,8 +249,8 @@ __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<Preproce
                     float acc[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     for (uint32_t j = (uint32_t)lane; j < nn; j += 64) {
                         if (touched[off + j]) {
-                            const float4* src = prec + (size_t)(off + j) * PARTIAL_ROWS;
-                            const float4 q0 = src[0], q1 = src[1], q2 = src[2];
+                            float4 q0, q1, q2;
+                            partial_load(prec, off + j, q0, q1, q2);
                             acc[0] += q0.x; acc[1] += q0.y; acc[2] += q0.z; acc[3] += q0.w;
                             acc[4] += q1.x; acc[5] += q1.y; acc[6] += q1.z; acc[7] += q1.w;
                             acc[8] += q2.x; acc[9] += q2.y;

@@ -35,7 +35,7 @@
 //  All staged float4 reads stay 16 bytes wide (keep_b128): narrowed to ds_read_b96 they cost 3.6 M bank-conflict cycles
 //  per dispatch in round 3.
 //
-// Only blended instances get their 48-byte Gaussian-major partial record written (exactly once: no memset, NO atomic
+// Only blended instances get their 40-byte Gaussian-major partial record written (exactly once: no memset, NO atomic
 // in the whole backward pass -- device-scope fp32 atomics run at ~12 G/s on MI355X -- bit-deterministic) and their
 // `touched` byte set; preprocess_bwd.hip reads the bytes and fetches only those records.
 //
@@ -56,7 +56,7 @@
 // (~1e-7 relative), not bit for bit.
 //
 // Algorithmic HBM bytes: reads 4 B/instance (sorted ids), 64 B per gathered (blended) splat, 12 (+8) B/pixel of
-// incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 49 B per blended instance.
+// incoming gradient per batch, 2 x 20 B/pixel of checkpoints per batch; writes 41 B per blended instance.
 #include <stdlib.h>
 #include "blend.h"
 
@@ -420,11 +420,12 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
                 const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
                 const uint32_t ps = s_pslot[kk];
                 if (!PREFIX || ps != NO_SLOT) {
-                    float4* dst = prec + (size_t)ps * PARTIAL_ROWS;
-                    dst[0] = make_float4(o * mx, o * my, o * mxx, o * mxy);
-                    dst[1] = make_float4(o * myy, dop, dr, dg);
-                    dst[2] = make_float4(db, dz, 0.f, 0.f);
-                    if (PARTIAL_ROWS == 4) dst[3] = make_float4(0.f, 0.f, 0.f, 0.f);      // (the whole line: no partial sector)
+                    char* dst = partial_at(prec, ps);
+                    *reinterpret_cast<partial_v4*>(dst) = partial_v4{o * mx, o * my, o * mxx, o * mxy};
+                    *reinterpret_cast<partial_v4*>(dst + 16) = partial_v4{o * myy, dop, dr, dg};
+                    if (PARTIAL_BYTES == 40) *reinterpret_cast<partial_v2*>(dst + 32) = partial_v2{db, dz};
+                    else *reinterpret_cast<partial_v4*>(dst + 32) = partial_v4{db, dz, 0.f, 0.f};
+                    if (PARTIAL_BYTES == 64) *reinterpret_cast<partial_v4*>(dst + 48) = partial_v4{0.f, 0.f, 0.f, 0.f};      // (the whole line: no partial sector)
                     touched[ps] = (uint8_t)1;
                 }
             }

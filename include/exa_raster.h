@@ -76,7 +76,7 @@ typedef struct ExaRasterWorkspaceSizes {
     uint64_t geom_bytes;   /* per-Gaussian splat records, 64 B * P                         */
     uint64_t tile_bytes;   /* header, (chunk, cell) count matrix, prefixes, per-sub-tile ranges   */
     uint64_t bin_bytes;    /* keys, sorted ids, cell buckets, batch owners / masks, checkpoints: ~50 B * capacity */
-    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 48 B * capacity  */
+    uint64_t grad_bytes;   /* backward scratch: per-instance partial sums, 40 B * capacity  */
 } ExaRasterWorkspaceSizes;
 
 /* Device-side header at the start of the tile workspace (readable with a 28-byte D2H copy). */
@@ -229,7 +229,7 @@ typedef struct ExaRasterBackwardJob {
     int32_t grad_first;
     /* Composite render (exa_raster_forward_compose_batch): compose_geom_a != NULL makes this the backward of a composite.
      * Then P, the input tensors, radii and every gradient array describe source B (the trainable Gaussians), geom_ws is B's
-     * splat workspace, tile_ws / bin_ws / capacity are the COMPOSITE's workspaces, grad_ws holds exa_raster_compose_sizes().grad_bytes (48 B x compose_capacity_b),
+     * splat workspace, tile_ws / bin_ws / capacity are the COMPOSITE's workspaces, grad_ws holds exa_raster_compose_sizes().grad_bytes (40 B x compose_capacity_b),
      * compose_geom_a / compose_P_a name source A's records (constants: no gradient) and grad_first must be 0. */
     const void* compose_geom_a; int32_t compose_P_a; uint64_t compose_capacity_b;
     /* Optional (NULL = off): DEVICE address of one pointer that the kernels load at EXECUTION time and read dL/dcolor from,
