@@ -75,7 +75,9 @@ static_assert(sizeof(Splat) == 64, "Splat must be one 64-byte line");
 //   40: 6 619 / 6 617 / 6 610 against 6 620 / 6 567 / 6 559 with 48 on one box (preprocess_bwd 19.4-19.6 vs 19.7-20.1 us,
 //      render_bwd 43.9-44.5 vs 44.0-44.5), 6 603 / 6 600 / 6 588 / 6 605 against 6 603 / 6 606 / 6 603 / 6 610 on a second:
 //      a wash in time (the two kernels are bound by instruction issue and latency, not by these bytes), gradients
-//      bit-identical, a sixth less workspace and 3.3 MB less written and re-read per C3 step.  Kept for the bytes.
+//      bit-identical, a sixth less workspace.  By the counters (profiles/r05_hbm_traffic.md) render_bwd writes the SAME
+//      38.8 MB -- a 40-byte record dirties two 32-byte sectors just as a 48-byte one does -- and preprocess_bwd fetches
+//      21.7 instead of 23.6 MB.  Kept for the workspace.
 #ifndef EXA_PARTIAL_BYTES
 #define EXA_PARTIAL_BYTES 40
 #endif
