@@ -47,7 +47,11 @@ def parse():
     ap.add_argument('--config', default='c3', choices=['c3', 'c2', 'c1', 'c5'])
     ap.add_argument('--mode', default=None, choices=['train', 'forward'],
                     help='train = forward + backward (default; c5 defaults to forward)')
-    ap.add_argument('--launch', default='graph', choices=['graph', 'eager'])
+    ap.add_argument('--launch', default='abi', choices=['abi', 'graph', 'eager'],
+                    help="how a step is issued: 'abi' (default) plain launches straight through the C ABI from pre-marshalled "
+                         "jobs and static buffers (exavatar_release_amd.StaticRender), 'graph' the autograd surface replayed "
+                         "from a hipGraph (the headline of rounds 2-5; reported next to the headline as extra_graph_replay), "
+                         "'eager' the autograd surface call by call (host-bound)")
     ap.add_argument('--streams', type=int, default=1,
                     help='independent views in flight per GPU (each on its own HIP stream + hipGraph); 1 = one '
                          'view at a time, the headline configuration')
@@ -278,13 +282,42 @@ def main():
     exa.config.mode = 'capacity'
     exa.config.fixed_capacity = int(D_max) + 64      # every view of the shard was probed: D_max is exact (overflow is checked)
 
-    # ---- optional hipGraph capture of the raster step --------------------------------------------------
+    # ---- 'abi': the step straight through the C ABI (exavatar_release_amd/static.py) ----------------------------
+    # One StaticRender: static inputs, workspaces, images, gradient arrays; the forward / backward jobs of every view of the
+    # shard marshalled once, their settings pointing INTO the resident camera table (no per-step camera copy); a step = two
+    # ctypes calls = seven kernel launches on the current stream.  N > 1: the gradient arrays ARE the two flat buffers of the
+    # all-reducer (no pack kernels).
     launch = args.launch
+    use_abi = launch == 'abi' and KV == 1 and S == 1
+    if launch == 'abi' and not use_abi:
+        launch = 'graph'                     # the batched / multi-stream variants are built on the captured contexts
+    sr = None
+    if use_abi:
+        m3, sc, rot, op, col = [t.detach() for t in params]
+        sr = exa.StaticRender(m3, op, sc, rot, colors_precomp=None if use_sh else col, shs=col if use_sh else None,
+                              image_size=(H, W), capacity=int(D_max) + 64, train=train)
+        for j, v in enumerate(vs):
+            st_j = GaussianRasterizationSettings(
+                image_height=H, image_width=W, tanfovx=v['tanfovx'], tanfovy=v['tanfovy'], bg=bg, scale_modifier=1.0,
+                viewmatrix=cam_tab[j, 0:16].view(4, 4), projmatrix=cam_tab[j, 16:32].view(4, 4), sh_degree=sh_degree,
+                campos=cam_tab[j, 32:35], prefiltered=False, debug=False)
+            sr.add_view(st_j, dL_dcolor=dL_dimg if train else None)
+        if train:
+            for b in range(2 if reducer is not None else 1):
+                if reducer is not None:
+                    bv = reducer.buffer_views(b)       # order of `params`: means3D, scales, rotations, opacities, colour | SH
+                    sr.add_grad_outputs(means3D=bv[0], scales=bv[1], rotations=bv[2], opacities=bv[3],
+                                        **({'shs': bv[4]} if use_sh else {'colors_precomp': bv[4]}))
+                else:
+                    sr.add_grad_outputs()
+
+    # ---- hipGraph capture of the raster step (the 'graph' protocol; under 'abi' only for the extras built on it) -------
+    want_graph = launch == 'graph' or (use_abi and world == 1 and not args.no_concurrent)
     set_view(0, c0)
     for _ in range(3):
         raster_step(c0, 0)
     torch.cuda.synchronize()
-    if launch == 'graph':
+    if want_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -308,9 +341,22 @@ def main():
             print('bench.py: hipGraph capture failed (%s); using eager launches' % e, file=sys.stderr)
             for c in ctxs:
                 c['graph'] = None
-            launch = 'eager'
+            if launch == 'graph':
+                launch = 'eager'
 
-    def step(i):
+    n_my = len(my_views)
+
+    def step_abi(i):
+        k = i & 1
+        if reducer is not None:
+            reducer.wait(k)                 # the all-reduce that last read this gradient buffer (two steps ago)
+        sr.forward(i % n_my)
+        if train:
+            sr.backward(k if reducer is not None else 0)
+        if reducer is not None:
+            reducer.reduce(k)
+
+    def step_ctx(i):
         k = i % n_ctx
         c = ctxs[k]
         if c['stream'] is not None:
@@ -330,6 +376,8 @@ def main():
             raster_step(c, k)
         if reducer is not None:
             reducer.reduce(k)
+
+    step = step_abi if use_abi else step_ctx
 
     def finish():
         if reducer is not None:
@@ -364,6 +412,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    if use_abi:
+        sr.check()                           # every render's header report: raises if any overflowed the instance buffer
+    graph_replay = None
+    if use_abi and rank == 0 and world == 1 and ctxs and ctxs[0].get('graph') is not None:
+        # the protocol of rounds 2-5 on the same box, same settle / warm-up / steps: the autograd surface replayed from a hipGraph
+        seek_view(0)
+        for i in range(settle):
+            step_ctx(i)
+        torch.cuda.synchronize()
+        seek_view(0)
+        for i in range(args.warmup):
+            step_ctx(i)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for i in range(args.steps):
+            step_ctx(args.warmup + i)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg
+        graph_replay = {'value': args.steps / tg, 'unit': 'iters/s', 'ms_per_step': tg / args.steps * 1e3,
+                        'what': 'the same step issued as rounds 2-5 issued it: the autograd surface (GaussianRasterizer + '
+                                'autograd.grad) captured once and replayed from a hipGraph whose first node copies the next '
+                                'view\'s camera block out of the resident table (exa_raster_select_row); ~4 us between two '
+                                'launches of the graph + 4.6 us for that node are what the plain launches of the headline do not pay'}
+
     # every rank reports what ITS communicator says (world size, its device): the driver's SCALE line can be checked against it
     rank_info = {'rank': rank, 'world_size': dist.get_world_size() if world > 1 else 1, 'device': torch.cuda.current_device(),
                  'device_name': torch.cuda.get_device_name(device), 'views': len(my_views)}
@@ -393,7 +465,16 @@ def main():
                                      '2e-2; grads 1e-3 rel, 1e-1 * mean floor for Gaussians under an ambiguous pixel (tests/helpers.py)',
                        'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
                        'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle,
-                       'view_switch': 'per step, inside the timed region: the next view\'s camera block (48 floats) copied from the '
+                       'launch_what': {'abi': 'plain kernel launches straight through the C ABI: exa_raster_forward_batch + '
+                                              'exa_raster_backward_batch on pre-marshalled jobs and static buffers '
+                                              '(exavatar_release_amd.StaticRender), two ctypes calls = seven launches per step, the '
+                                              'host ~30 us per step ahead of a ~145 us device step; every render\'s overflow report '
+                                              'checked after the timed region',
+                                       'graph': 'the autograd surface captured once and replayed from a hipGraph',
+                                       'eager': 'the autograd surface call by call (host-bound)'}[launch],
+                       'view_switch': 'per step, inside the timed region: every view\'s pre-marshalled job reads its camera block (48 floats) '
+                                      'IN PLACE from the resident table of ring views (no copy)' if use_abi else
+                                      'per step, inside the timed region: the next view\'s camera block (48 floats) copied from the '
                                       'resident table of ring views into the graph\'s static tensor by ' +
                                       ('the first node of the replayed graph (exa_raster_select_row + a device-side counter; '
                                        'EXA_BENCH_CAM_COPY=kernel: an eager elementwise kernel in front of every replay, the '
@@ -410,9 +491,12 @@ def main():
                      'ranks': ranks},
         }
 
+    if rank == 0 and graph_replay is not None:
+        result['extra_graph_replay'] = graph_replay
     single = S == 1 and KV == 1 and world == 1
     # ---- extras (not the headline): K views per batched launch; independent views on separate streams -------
-    if rank == 0 and single and launch == 'graph' and not args.no_concurrent and args.config != 'c1':
+    if rank == 0 and single and launch in ('graph', 'abi') and ctxs[0].get('graph') is not None and not args.no_concurrent \
+            and args.config != 'c1':
         for name, fn in (('extra_batched_views', lambda: batched_throughput(8, 1, args, make_ctx, set_view, raster_step)),
                          ('extra_batched_views_x2', lambda: batched_throughput(8, 2, args, make_ctx, set_view, raster_step)),
                          ('extra_views_in_flight', lambda: concurrent_throughput(4, args, make_ctx, set_view, raster_step))):
@@ -696,7 +780,7 @@ def other_config(cfg, args):
         else:
             nbytes = 128 * P + 252 * V + 44 * D + 56 * WH
         gbs = nbytes / (d['ms_per_step'] * 1e-3) / 1e9
-        res['roofline'] = {'bound': 'hbm', 'level': 'whole step (graph replay)', 'algorithmic_bytes': nbytes, 'achieved': gbs,
+        res['roofline'] = {'bound': 'hbm', 'level': 'whole step (launch: %s)' % c.get('launch', '?'), 'algorithmic_bytes': nbytes, 'achieved': gbs,
                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS}
         return res
     except Exception as e:  # noqa: BLE001

@@ -11,8 +11,9 @@ from .densify import track_densify_stats
 from .losses import SSIM, PhotometricLoss, RGBLoss
 from .renderer import ITERATION_RENDERS, GaussianRenderer, GraphedRenderer, render_iteration, render_many, render_views
 from .graphed import GraphedIteration
+from .static import StaticRender, required_capacity
 
 __all__ = ['GaussianRasterizationSettings', 'GaussianRasterizer', 'GaussianRenderer', 'rasterize_gaussians',
            'rasterize_gaussians_batch', 'config', 'track_densify_stats', 'render_many', 'render_views',
-           'render_iteration', 'ITERATION_RENDERS', 'GraphedRenderer', 'GraphedIteration',
+           'render_iteration', 'ITERATION_RENDERS', 'GraphedRenderer', 'GraphedIteration', 'StaticRender', 'required_capacity',
            'SSIM', 'RGBLoss', 'PhotometricLoss']

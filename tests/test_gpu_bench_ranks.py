@@ -51,5 +51,5 @@ def test_bench_eight_ranks_on_one_gpu_as_the_driver_types_it():
     assert res['n_gpus'] == 8 and res['steps'] == 10 and res['value'] > 0 and res['scaling'] == 'weak'
     assert res['rccl']['world_size'] == 8 and res['rccl']['backend'] == 'gloo'
     assert [r['rank'] for r in res['rccl']['ranks']] == list(range(8)) and all(r['world_size'] == 8 and r['views'] == 25 for r in res['rccl']['ranks'])
-    assert res['config']['views_per_rank'] == 25 and res['config']['launch'] == 'graph'
+    assert res['config']['views_per_rank'] == 25 and res['config']['launch'] == 'abi'
     assert 'dp8' in res['config']['parallelism']
