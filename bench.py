@@ -192,7 +192,7 @@ def main():
         if S > 1:
             c['stream'] = torch.cuda.Stream()
 
-    # How the graph-replayed single-view step gets its camera: 'graph' (default) -- the first node of the captured graph is
+    # How the GRAPH-REPLAYED single-view step (--launch graph, and the extras built on captured contexts) gets its camera: 'graph' (default) -- the first node of the captured graph is
     # exa_raster_select_row: row (counter mod views) of the resident camera table -> the graph's camera block, counter + 1
     # (the ring of views is resident in HBM, as the contract of this line says; no launch outside the graph per step);
     # 'kernel' -- one eager elementwise kernel in front of every replay (round 4 until this change: ~4.5 us of GPU time per step,
@@ -412,8 +412,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    host_us = None
     if use_abi:
         sr.check()                           # every render's header report: raises if any overflowed the instance buffer
+        # what the host spends per step (queueing only: 32 steps issued back to back onto an idle device, clock stopped before
+        # the device is waited for) -- the protocol holds as long as this stays under the device's step
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for i in range(32):
+            step(i)
+        host_us = (time.perf_counter() - th) / 32 * 1e6
+        finish()
+        torch.cuda.synchronize()
+        sr.check()
     graph_replay = None
     if use_abi and rank == 0 and world == 1 and ctxs and ctxs[0].get('graph') is not None:
         # the protocol of rounds 2-5 on the same box, same settle / warm-up / steps: the autograd surface replayed from a hipGraph
@@ -464,7 +475,7 @@ def main():
                        'parity_bar': 'image 1e-4 L-inf off the <= 0.04 % threshold-adjacent (ambiguous) pixels, which may be off by '
                                      '2e-2; grads 1e-3 rel, 1e-1 * mean floor for Gaussians under an ambiguous pixel (tests/helpers.py)',
                        'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
-                       'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle,
+                       'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle, 'host_us_per_step': host_us,
                        'launch_what': {'abi': 'plain kernel launches straight through the C ABI: exa_raster_forward_batch + '
                                               'exa_raster_backward_batch on pre-marshalled jobs and static buffers '
                                               '(exavatar_release_amd.StaticRender), two ctypes calls = seven launches per step, the '
@@ -564,7 +575,7 @@ def main():
             set_view(i, c1)
             # two steps back to back, the second one is read: its launches are queued behind running work, so the
             # event brackets hold the kernels and not the ~5 us a launch needs to reach an idle GPU (agrees with the
-            # rocprofv3 --kernel-trace durations of the graph-replayed step, profiles/)
+            # rocprofv3 --kernel-trace durations of the bench command's step, profiles/)
             raster_step(c1, 0)
             raster_step(c1, 0)
             torch.cuda.synchronize()
@@ -600,7 +611,7 @@ def main():
             'frac': achieved / HBM_PEAK_GBS,
             'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
             'clock': 'HIP events around eager launches of the kernel, this run (2nd of two back-to-back steps, stratified views); '
-                     'the rocprofv3 --kernel-trace average of the graph-replayed step is in profiles/ (1-3 us lower)',
+                     'the rocprofv3 --kernel-trace average of the same kernel inside the bench command\'s step is in profiles/ (1-3 us lower)',
             'byte_model': 'SURVEY.md 8(d) with the run\'s own P, V and D = 16x16 tile instances (header.num_tile_instances)',
             'kernel_avg_us': avg_us,
             'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),

@@ -78,7 +78,7 @@ with open(os.path.join(out, prefix + '_c5_kernel_stats.md'), 'w') as f:
     f.write('# %s: C5 (BASELINE configs[4]) per kernel -- 300 k Gaussians, SH degree 3 in-kernel, 2048 x 2048, forward only, hipGraph\n\n' % prefix)
     f.write('Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --config c5 --steps 100 --warmup 10 --no-cpu-baseline\n'
             '--no-concurrent --no-other-configs` (1 x MI355X; includes the untimed calibration / settle launches of bench.py).\n\n')
-    f.write('Bench line of that run: **%.1f frames/s, %.4f ms/frame** (graph replay, `torch.no_grad()`, no backward context stored).\n'
+    f.write('Bench line of that run: **%.1f frames/s, %.4f ms/frame** (launch protocol: `config.launch` of that line, no backward context stored).\n'
             % (c5['value'], c5['ms_per_step']))
     if rf:
         st = rf.get('step', {})

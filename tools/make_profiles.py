@@ -44,7 +44,7 @@ if os.path.exists(_ks):
 with open(_ks, 'w') as f:
     f.write('# %s: rocprofv3 kernel statistics of the bench command\n\n' % prefix)
     f.write('Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 '
-            '--no-cpu-baseline --no-concurrent` (C3, 1 x MI355X, hipGraph replay; includes the untimed calibration / warm-up '
+            '--no-cpu-baseline --no-concurrent` (C3, 1 x MI355X, launch protocol of that bench line (`config.launch`); includes the untimed calibration / warm-up '
             'launches of bench.py, hence more calls than steps).\n\n')
     f.write('Bench line of the same build (default `python bench.py`): %.1f it/s, %.4f ms/step; roofline kernel %s '
             'avg %.1f us (HIP events) .\n\n' % (bench['value'], bench['ms_per_step'], bench['roofline']['kernel'],
@@ -67,7 +67,7 @@ if stats:
                 kern[k] = {'avg_us': float(r['AverageNs']) / 1e3, 'calls': int(r['Calls'])}
     with open(os.path.join(out, prefix + '_kernel_stats.json'), 'w') as f:
         json.dump({'what': 'rocprofv3 --kernel-trace --stats of `python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-concurrent` '
-                           '(C3, graph replay, ring average)', 'kernels': kern}, f, indent=1)
+                           '(C3, the launch protocol of that bench line, ring average)', 'kernels': kern}, f, indent=1)
 
 # ---- HBM traffic -----------------------------------------------------------------------------------------
 fe, wr = counters('pmc_fetch'), counters('pmc_write')
