@@ -5,16 +5,22 @@ rasterize at 1024x1024 with ~150 k avatar-like Gaussians (config C3), view-shard
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one `GaussianRasterizer` forward + its backward for one training view with a dense
+One "step" = one rasterizer forward + its backward for one training view with a dense
 dL/dimage (inputs already resident in HBM), followed for N > 1 by the RCCL all-reduce of the
-Gaussian gradients (14 floats x P = 8.4 MB) through the product's `dist.FlatGradAllReducer`.  Views: the 200
+Gaussian gradients (14 floats x P = 8.4 MB) through the product's `dist.FlatGradAllReducer`.
+How the step is issued (`--launch`): `abi` (default since late round 5) -- plain kernel launches straight through the C ABI
+(`exa_raster_forward_batch` + `exa_raster_backward_batch`) from the product's `StaticRender`: static buffers, the jobs of every
+view marshalled once and reading their camera in place from the resident table, two ctypes calls per step, gradients written
+directly into the all-reducer's flat buffers; `graph` -- the drop-in autograd surface (`GaussianRasterizer` + `autograd.grad`)
+captured once and replayed from a hipGraph (the headline of rounds 2-5; the default line carries it as `extra_graph_replay`);
+`eager` -- the autograd surface call by call (host-bound: ~310 us of host per step against ~142 us of device).  Views: the 200
 ring cameras of config C4 dealt by the product's `dist.shard_views` in a fixed stratified order (step i -> view
 (i * 123) mod 200: a short run covers the ring like a long one); every rank cycles through its shard, so
 per-GPU work is fixed as N grows (weak scaling) and `value` = views rasterized fwd+bwd per second over all ranks.
 
 Other workloads: `--config c2|c1` (same step), `--config c5` = BASELINE configs[4]: 300 k Gaussians
-(200 k avatar + 100 k scene), in-kernel SH degree 3, 2048x2048, FORWARD ONLY under `torch.no_grad()` (no backward
-context stored), hipGraph-captured -- the animation / inference use case of avatar/main/animate.py:64-66.
+(200 k avatar + 100 k scene), in-kernel SH degree 3, 2048x2048, FORWARD ONLY (no backward context stored), same launch
+protocols -- the animation / inference use case of avatar/main/animate.py:64-66.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: `roofline` (dominant kernel,
 HIP-event timed inside this script), `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
