@@ -94,7 +94,9 @@ class StaticRender:
         self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         self._stream_ptr = ctypes.c_void_p(self.stream.cuda_stream)
         sz = _lib.workspace_sizes(self.P, self.W, self.H, self.capacity)
-        with torch.cuda.device(self.device):
+        # (allocated ON the stream the calls are queued on: the caching allocator then hands a freed buffer to nobody before that
+        #  stream is past the kernels that used it)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.stream):
             self._geom = torch.empty(int(sz.geom_bytes), dtype=torch.uint8, device=self.device)
             self._tile = torch.empty(int(sz.tile_bytes), dtype=torch.uint8, device=self.device)
             self._bin = torch.empty(int(sz.bin_bytes), dtype=torch.uint8, device=self.device)
@@ -186,7 +188,8 @@ class StaticRender:
         for name, shape in shapes.items():
             t = arrays.pop(name, None)
             if t is None:
-                t = torch.zeros(shape, dtype=_F32, device=self.device)
+                with torch.cuda.stream(self.stream):
+                    t = torch.zeros(shape, dtype=_F32, device=self.device)
             elif not (t.dtype is _F32 and t.is_contiguous() and t.device == self.device and t.numel() == math.prod(shape)):
                 raise ValueError('StaticRender.add_grad_outputs: %s must be a contiguous float32 tensor of shape %s' % (name, shape))
             out[name] = t
