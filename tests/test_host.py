@@ -294,3 +294,16 @@ def test_densify_and_prune_screen_space_criterion_and_reference_quirk():
     assert torch.equal(new['mean'][:P - 4], params['mean'][keep])
     st = opt.state[new['mean']]
     assert st['exp_avg'].shape[0] == P + 1 and bool((st['exp_avg'][P - 4:] == 0).all())   # new rows: zero optimizer state
+
+
+def test_static_render_rejects_what_it_cannot_drive():
+    """StaticRender (exavatar_release_amd/static.py) validates before it touches the library: CPU tensors, both colour inputs."""
+    P = 8
+    z = lambda *s: torch.zeros(*s)     # noqa: E731
+    with pytest.raises(ValueError, match='exactly one'):
+        exa.StaticRender(z(P, 3), z(P, 1), z(P, 3), z(P, 4), image_size=(16, 16), capacity=64)
+    with pytest.raises(ValueError, match='exactly one'):
+        exa.StaticRender(z(P, 3), z(P, 1), z(P, 3), z(P, 4), colors_precomp=z(P, 3), shs=z(P, 1, 3), image_size=(16, 16), capacity=64)
+    with pytest.raises(ValueError, match='on a GPU'):
+        exa.StaticRender(z(P, 3), z(P, 1), z(P, 3), z(P, 4), colors_precomp=z(P, 3), image_size=(16, 16), capacity=64)
+    assert 'StaticRender' in exa.__all__ and 'required_capacity' in exa.__all__
