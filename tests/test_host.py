@@ -307,3 +307,33 @@ def test_static_render_rejects_what_it_cannot_drive():
     with pytest.raises(ValueError, match='on a GPU'):
         exa.StaticRender(z(P, 3), z(P, 1), z(P, 3), z(P, 4), colors_precomp=z(P, 3), image_size=(16, 16), capacity=64)
     assert 'StaticRender' in exa.__all__ and 'required_capacity' in exa.__all__
+
+
+def test_header_compiles_as_plain_c_and_cxx_and_links_against_the_library(tmp_path):
+    """include/exa_raster.h is the drop-in boundary for NATIVE hosts: it has to compile as C99 and as C++11
+    without torch, HIP or any other header of ours, and a C program that takes the address of every function it declares
+    has to link against libexa_raster.so (no compute call: there is no GPU here)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, 'include', 'exa_raster.h')).read()
+    names = sorted(set(re.findall(r'\b(exa_(?:raster|l1|photo|ssim)_\w+)\s*\(', hdr)))
+    assert set(names) == set(_lib.SIGNATURES), 'binding and header disagree on the exported functions'
+    src = tmp_path / 'host.c'
+    src.write_text('#include "exa_raster.h"\n#include <stdio.h>\nint main(void) {\n  void* f[] = {%s};\n'
+                   '  ExaRasterForwardJob fj; ExaRasterBackwardJob bj; ExaRasterComposeJob cj; (void)fj; (void)bj; (void)cj;\n'
+                   '  printf("%%d %%d\\n", (int)(sizeof f / sizeof f[0]), exa_raster_version());\n  return 0;\n}\n'
+                   % ', '.join('(void*)' + n for n in names))
+    inc = ['-I', os.path.join(root, 'include')]
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-Werror', '-Wno-pedantic', '-fsyntax-only'] + inc + [str(src)], check=True)
+    if shutil.which('g++'):
+        subprocess.run(['g++', '-std=c++11', '-Wall', '-Wextra', '-Werror', '-fsyntax-only', '-x', 'c++'] + inc + [str(src)], check=True)
+    lib = os.path.join(root, 'exavatar_release_amd', 'libexa_raster.so')
+    exe = tmp_path / 'host'
+    subprocess.run(['gcc', '-std=c99'] + inc + [str(src), lib, '-Wl,-rpath,' + os.path.dirname(lib), '-Wl,--allow-shlib-undefined',
+                                                 '-o', str(exe)], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH='/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env).stdout.split()
+    assert int(out[0]) == len(names) and int(out[1]) == _lib.load().exa_raster_version()
