@@ -30,7 +30,10 @@ constexpr int HEADER_BYTES = 512;      // ExaRasterHeader at 0, length-class cur
 // of K, and their workgroups fill the chip together (a single 1024x1024 view leaves most of the 256 CUs idle in
 // every stage but the blend).  The job records live in the kernarg segment: indexing them with blockIdx.y compiles
 // to scalar loads with a register offset (no scratch copy).
-constexpr int MAX_BATCH = 8;
+#ifndef EXA_MAX_BATCH
+#define EXA_MAX_BATCH 8
+#endif
+constexpr int MAX_BATCH = EXA_MAX_BATCH;
 template <typename T> struct Batch { T v[MAX_BATCH]; };
 template <typename T>
 inline Batch<T> make_batch(const T* a, int K) {          // unused slots repeat job 0 (never indexed: gridDim.y = K)
