@@ -16,7 +16,12 @@ LIB = os.path.join(HERE, 'libexa_raster.so')
 BUILD = os.path.join(HERE, '_build')
 
 ARCH = 'gfx950'
-COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics',
+# -fno-slp-vectorize: left to itself the compiler packs pairs of independent scalar float operations of the blends into
+# v_pk_*_f32 -- which take two passes of the VALU like the two scalar ones, i.e. save nothing where the kernel is bound by
+# VALU throughput -- and pays for it with v_mov shuffles into and out of register pairs (render_fwd: 64 moves and 66 packed
+# operations against 54 and 52).  The packed operations written out in blend.h (ext_vector_type) stay.  Same arithmetic, same
+# bits; render_bwd 44.1 -> 42.1 us by events, the C3 step 142.1 -> 139.6 us (7 023 / 7 052 -> 7 167 / 7 164 it/s interleaved).
+COMMON = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-fno-slp-vectorize',
           '-Wall', '-Wno-unused-function'] + (['-DEXA_PROBE_SORT'] if os.environ.get('EXA_PROBE_SORT') else []) + \
     (['-DEXA_PROBE_FWD'] if os.environ.get('EXA_PROBE_FWD') else [])
 # per-file extra flags: the forward per-Gaussian stage is the bit-exact-with-oracle part

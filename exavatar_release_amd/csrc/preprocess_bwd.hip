@@ -135,6 +135,11 @@ __device__ __forceinline__ void stream_gather(uint32_t off, uint32_t n, const ui
     }
 }
 
+// ||dL/dmean2D|| of the densification statistics: ONE spelling (an explicit fma) for the kernel that accumulates it inside the
+// backward pass and the stand-alone one, which have to agree bit for bit (tests/test_gpu_parity.py, fused densify statistics) --
+// left to the compiler, x * x + y * y is contracted in one kernel and not in the other depending on the code around it.
+__device__ __forceinline__ float grad_norm2(float x, float y) { return sqrtf(fmaf(x, x, y * y)); }
+
 // cov2D = T Sigma T^T, its determinant and the gradient of the conic: in DOUBLE since round 5 (everything else float).
 // A needle-like projected covariance (eigenvalues 894 and 1.0 px^2 in the seeds that showed it: x300 scales, unnormalised
 // quaternions) makes (da, db, dc) differences of terms 200^2 x their size, so the float rounding of a, b, c
@@ -482,11 +487,11 @@ __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<Preproce
         // screen-space gradient is in registers here, no separate pass over the Gaussians
         if (vis) {
             if (SUM && dens_shared) {
-                dn_acc += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
+                dn_acc += grad_norm2(vm2[0], vm2[1]);
                 dn_cnt += 1.0f;
                 dn_rmax = fmaxf(dn_rmax, (float)a.radii[idc]);
             } else {
-                if (a.dens_accum) a.dens_accum[row] += sqrtf(vm2[0] * vm2[0] + vm2[1] * vm2[1]);
+                if (a.dens_accum) a.dens_accum[row] += grad_norm2(vm2[0], vm2[1]);
                 if (a.dens_cnt) a.dens_cnt[row] += 1.0f;
                 if (a.dens_rmax) a.dens_rmax[row] = fmaxf(a.dens_rmax[row], (float)a.radii[idc]);
             }
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) void densify_stats_kernel(int P, const float
     if (r <= 0) return;
     if (accum) {
         const float gx = g2d[3 * i], gy = g2d[3 * i + 1];
-        accum[i] += sqrtf(gx * gx + gy * gy);
+        accum[i] += grad_norm2(gx, gy);
     }
     if (cnt) cnt[i] += 1.0f;
     if (rmax) rmax[i] = fmaxf(rmax[i], (float)r);

@@ -17,7 +17,7 @@ OBJS=""
 for src in preprocess_fwd binning render_fwd render_bwd compose preprocess_bwd ssim api; do
   [ -f $T/exavatar_release_amd/csrc/$src.hip ] || continue
   X=""; [ $src = preprocess_fwd ] && X="-ffp-contract=off"
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -w $X "$@" -c $T/exavatar_release_amd/csrc/$src.hip -o $T/$src.o
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize -w $X "$@" -c $T/exavatar_release_amd/csrc/$src.hip -o $T/$src.o
   OBJS="$OBJS $T/$src.o"
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/exavatar_release_amd/_variants/$NAME.so $OBJS
