@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library variants (EXA_RASTER_LIB): C3 (fwd + bwd) and C5 (forward) headline steps, graph-replayed, plus the
+# A/B of library variants (EXA_RASTER_LIB): C3 (fwd + bwd) and C5 (forward) headline steps (default launch protocol of bench.py), plus the
 # HIP-event kernel times.  Usage: bash tools/gpu_ab.sh [-n repeats] lib1.so lib2.so ...   (interleaved: lib1 lib2 lib1 lib2 ...)
 cd $GRAFT_REPO_ROOT
 N=2; if [ "$1" = -n ]; then N=$2; shift 2; fi
