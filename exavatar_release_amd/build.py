@@ -44,9 +44,15 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
+BINDING_SRC = 'torch_binding.cpp'        # the compiled autograd node (host code over the C ABI): its own artefact and stamp
+BINDING = os.path.join(HERE, '_exa_torch.so')
+
+
 def _digest():
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)):
+        if name == BINDING_SRC:
+            continue
         with open(os.path.join(CSRC, name), 'rb') as f:
             h.update(name.encode())
             h.update(f.read())
@@ -81,5 +87,49 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def _binding_digest():
+    import torch
+    h = hashlib.sha256()
+    for path in (os.path.join(CSRC, BINDING_SRC), os.path.join(HERE, '..', 'include', 'exa_raster.h')):
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    h.update(repr((torch.__version__, BINDING_FLAGS)).encode())
+    return h.hexdigest()
+
+
+BINDING_FLAGS = ['-O2', '-std=c++17', '-fPIC', '-shared', '-w', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+                 '-DTORCH_EXTENSION_NAME=_exa_torch', '-DTORCH_API_INCLUDE_EXTENSION_H', '-D_GLIBCXX_USE_CXX11_ABI=1']
+
+
+def build_binding(force=False, verbose=False):
+    """Compile ``csrc/torch_binding.cpp`` -- the compiled autograd node of the drop-in surface: host C++ against torch's
+    headers and ``include/exa_raster.h``, no device code -- into the in-tree Python extension ``_exa_torch.so`` (g++, ~40 s
+    once; it opens ``libexa_raster.so`` itself at ``init``).  Returns its path."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    os.makedirs(BUILD, exist_ok=True)
+    stamp = os.path.join(BUILD, 'stamp_binding')
+    dig = _binding_digest()
+    if not force and os.path.exists(BINDING) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return BINDING
+    cxx = os.environ.get('CXX') or shutil.which('g++') or shutil.which('c++')
+    if not cxx:
+        raise RuntimeError('g++ not found')
+    tlib = os.path.join(os.path.dirname(torch.__file__), 'lib')
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    cmd = [cxx] + BINDING_FLAGS + ['-I' + p for p in ce.include_paths()] + \
+        ['-I' + sysconfig.get_paths()['include'], '-I' + os.path.join(rocm, 'include'), os.path.join(CSRC, BINDING_SRC),
+         '-o', BINDING, '-L' + tlib, '-ltorch', '-ltorch_cpu', '-ltorch_python', '-lc10', '-lc10_hip', '-lamdhip64', '-ldl',
+         '-Wl,-rpath,' + tlib]
+    if verbose:
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    return BINDING
+
+
 if __name__ == '__main__':
     print(build(force='--force' in sys.argv, verbose=True))
+    print(build_binding(force='--force' in sys.argv, verbose=True))

@@ -47,6 +47,7 @@ polled: the report goes to a reserved slot the owner of the graph reads after ea
 import ctypes
 import threading
 import time
+import warnings
 import weakref
 from typing import NamedTuple
 
@@ -90,6 +91,10 @@ class _Config:
     #                               by scale_modifier); identical for the reference, which passes 1.0 (module.py:615)
     poison = False                # debug: fill every workspace with 0xFF before the kernels see it (the library promises to write
     #                               every section before it reads it; tests run under it with EXA_TEST_POISON=1)
+    compiled_node = 'auto'        # single renders through the compiled autograd node (csrc/torch_binding.cpp -> _exa_torch.so: the
+    #                               same C-ABI calls, arena layouts and overflow protocol as _Rasterize below at a quarter of the
+    #                               host time): 'auto' = when it is built and the call is one it covers, 'off' = always the Python
+    #                               node, 'require' = raise if the extension is missing
 
 
 config = _Config()
@@ -233,9 +238,12 @@ class _HdrPool:
     replay for as long as it lives, so it must never be dealt to anybody else."""
     N = 2048
     RESERVED = 1024
+    COMPILED = 8       # behind the reserved slots: the compiled autograd node's own small ring (a report is consumed inside its call)
 
     def __init__(self):
         total = self.N + self.RESERVED
+        self.compiled_first = total
+        total += self.COMPILED
         self.buf = torch.zeros((total, 4), dtype=torch.int32, pin_memory=True)
         dp = ctypes.c_void_p()
         _lib.check(_lib.load().exa_raster_host_device_pointer(ctypes.c_void_p(self.buf.data_ptr()), ctypes.byref(dp)))
@@ -243,7 +251,7 @@ class _HdrPool:
         self.words = (ctypes.c_uint32 * (4 * total)).from_address(self.buf.data_ptr())
         self.next = 0
         self.tag = 1
-        self.free_reserved = list(range(total - 1, self.N - 1, -1))
+        self.free_reserved = list(range(self.compiled_first - 1, self.N - 1, -1))
 
     def _next_tag(self):
         tag = self.tag
@@ -1062,11 +1070,76 @@ def _check_densify_aliasing(dens, shared):
         seen.update(a for a in p if a is not None)
 
 
+_compiled = None      # the compiled autograd node (csrc/torch_binding.cpp): module, or False when it cannot be used
+compiled_calls = 0    # renders the compiled node has taken (tests / logs)
+
+
+def _compiled_node():
+    """``_exa_torch`` initialised against the loaded library and its header-report slots; False if unavailable."""
+    global _compiled
+    if _compiled is None:
+        _compiled = False
+        try:
+            from . import _exa_torch
+            pool = _pool()
+            if pool is None:
+                raise RuntimeError('pinned host memory cannot be mapped for the device')
+            _lib.load()
+            _exa_torch.init(_lib.LIB_PATH, pool.buf.data_ptr() + 16 * pool.compiled_first, pool.dev_base + 16 * pool.compiled_first,
+                            pool.COMPILED)
+            _compiled = _exa_torch
+        except Exception as e:  # noqa: BLE001
+            if config.compiled_node == 'require':
+                _compiled = None
+                raise
+            warnings.warn('exavatar_release_amd: the compiled autograd node is not available (%s): single renders go through '
+                          'the Python node, ~0.2 ms of host time slower per fwd + bwd (python -m exavatar_release_amd.build)' % e,
+                          RuntimeWarning)
+    return _compiled
+
+
+def _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, dens):
+    """One render through the compiled node, or None when this call is not one it covers (the Python node takes it)."""
+    cfg = config
+    if cfg.mode == 'exact' or cfg.on_overflow != 'retry' or cfg.keep_debug or cfg.upstream_scale_grad:
+        return None
+    node = _compiled if _compiled is not None else _compiled_node()
+    if not node:
+        return None
+    key = (means3D.device.index, means3D.shape[0], rs[0], rs[1])
+    cap = cfg.fixed_capacity
+    if cap is None:
+        seen = _seen_D.get(key)
+        if seen is None:
+            return None           # first call of this shape: the Python node measures D once in exact mode, like upstream does
+        cap = max(int(seen * cfg.capacity_growth), cfg.min_capacity)
+    elif isinstance(cap, (list, tuple)):
+        cap = cap[0]
+    res = node.rasterize(rs, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, int(cap),
+                         cfg.mode == 'auto', cfg.poison, dens)
+    if res is None:
+        return None
+    global compiled_calls
+    compiled_calls += 1
+    color, radii, depth, alpha, is_vis, need, overflowed = res
+    if need > _seen_D.get(key, 0):
+        _seen_D[key] = need
+    if overflowed:
+        _record_overflow(key, need, overflowed, 'retried')
+    _tls.is_vis = [is_vis]
+    return color, radii, depth, alpha
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, densify_stats=None):
     """``densify_stats``: optional ``(xyz_grad_accum, track_cnt, radius_max)`` float32 tensors of P elements that THIS
     render's backward updates in place (fused densification statistics, see ``densify.track_densify_stats``)."""
     dens = None if densify_stats is None else [_check_densify(densify_stats, int(means3D.shape[0]), means3D.device)]
+    if config.compiled_node != 'off' and isinstance(raster_settings, tuple) and _capture_report is None:
+        out = _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                  raster_settings, dens[0] if dens else None)
+        if out is not None:
+            return out
     return _Rasterize.apply(1, (raster_settings,), torch.is_grad_enabled(), False, dens, None, None, means3D, means2D, sh,
                             colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
 
