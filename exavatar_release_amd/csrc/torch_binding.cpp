@@ -64,6 +64,7 @@ struct State : torch::CustomClassHolder {
     bool poison = false;
     Tensor ws, radii, is_vis;                 // splat records | tile workspace | bin workspace (one arena)
     uint64_t gb = 0, tb = 0;
+    int edge[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};      // argument position -> edge of the node (tensor arguments present only)
 };
 
 struct Outputs { Tensor color, depth, alpha; };
@@ -128,7 +129,7 @@ Outputs run_forward(State& st, const Tensor& m3, const c10::optional<Tensor>& sh
     return o;
 }
 
-// argument positions of RasterizeFn::forward (needs_input_grad indices)
+// argument positions of RasterizeFn::forward = positions of the gradients backward returns
 enum { A_STATE, A_M3, A_M2, A_SH, A_COL, A_OP, A_SC, A_ROT, A_COV, A_COUNT };
 
 struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
@@ -136,6 +137,10 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                                  const c10::optional<Tensor>& sh, const c10::optional<Tensor>& col, const Tensor& op,
                                  const c10::optional<Tensor>& sc, const c10::optional<Tensor>& rot,
                                  const c10::optional<Tensor>& cov) {
+        // AutogradContext::needs_input_grad counts the node's EDGES: the tensor arguments that are present, in argument order
+        const bool present[A_COUNT] = {false, true, true, sh.has_value(), col.has_value(), true, sc.has_value(), rot.has_value(),
+                                       cov.has_value()};
+        for (int i = 0, e = 0; i < A_COUNT; ++i) st->edge[i] = present[i] ? e++ : -1;
         auto stream = c10::hip::getCurrentHIPStream(m3.device().index());
         Outputs o = run_forward(*st, m3, sh, col, op, sc, rot, cov, true, stream);
         ctx->saved_data["st"] = c10::IValue::make_capsule(st);
@@ -161,6 +166,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         const Tensor &g_color_in = grads[0], &g_depth_in = grads[2], &g_alpha_in = grads[3];
         if (!g_color_in.defined() && !g_depth_in.defined() && !g_alpha_in.defined()) return ret;    // nothing reached the images
         auto st = c10::static_intrusive_pointer_cast<State>(ctx->saved_data["st"].toCapsule());
+        auto needs = [&](int arg) { return st->edge[arg] >= 0 && ctx->needs_input_grad((size_t)st->edge[arg]); };
         auto saved = ctx->get_saved_variables();          // (checks the version counters of the inputs)
         const Tensor &m3 = saved[0], &sh = saved[1], &col = saved[2], &op = saved[3], &sc = saved[4], &rot = saved[5],
                      &cov = saved[6];
@@ -174,10 +180,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         Tensor g_depth = grad_in(g_depth_in, 1, H, W), g_alpha = grad_in(g_alpha_in, 1, H, W);
         const bool has_dens = st->dens[0].defined() || st->dens[1].defined() || st->dens[2].defined();
         // ONE arena for the small per-Gaussian gradients (layout of rasterizer._Rasterize.backward); dL/dsh stays its own tensor
-        const bool want[7] = {ctx->needs_input_grad(A_M3), ctx->needs_input_grad(A_M2) || has_dens,
-                              col.defined() && ctx->needs_input_grad(A_COL), ctx->needs_input_grad(A_OP),
-                              sc.defined() && ctx->needs_input_grad(A_SC), rot.defined() && ctx->needs_input_grad(A_ROT),
-                              cov.defined() && ctx->needs_input_grad(A_COV)};
+        const bool want[7] = {needs(A_M3), needs(A_M2) || has_dens, needs(A_COL), needs(A_OP), needs(A_SC), needs(A_ROT), needs(A_COV)};
         static const int64_t width[7] = {3, 3, 3, 1, 3, 4, 6};
         int64_t total = 0;
         for (int i = 0; i < 7; ++i) total += want[i] ? width[i] : 0;
@@ -192,7 +195,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
                 }
         }
         Tensor d_sh;
-        if (sh.defined() && ctx->needs_input_grad(A_SH)) d_sh = at::empty({P, (int64_t)st->sh_M, 3}, f32);
+        if (needs(A_SH)) d_sh = at::empty({P, (int64_t)st->sh_M, 3}, f32);
         ExaRasterWorkspaceSizes sz{};
         check_rc(g.workspace_sizes((int32_t)P, (int32_t)W, (int32_t)H, st->capacity, &sz), "workspace_sizes");
         Tensor grad_ws = at::empty({(int64_t)sz.grad_bytes}, at::TensorOptions().dtype(at::kByte).device(dev));
@@ -214,7 +217,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         b.used_slots = st->need ? (uint32_t)((st->need + 63) / 64) : 0;     // one wave per batch slot IN USE
         check_rc(g.backward_batch(&b, 1, 0, stream.stream()), "exa_raster_backward_batch");
         ret[A_M3] = std::move(d[0]);
-        if (ctx->needs_input_grad(A_M2)) ret[A_M2] = std::move(d[1]);
+        if (needs(A_M2)) ret[A_M2] = std::move(d[1]);
         ret[A_SH] = std::move(d_sh);
         ret[A_COL] = std::move(d[2]);
         ret[A_OP] = std::move(d[3]);
