@@ -7,8 +7,8 @@
 // ~140 us of DEVICE time for both on the C3 workload -- the surface ExAvatar calls was host-bound by 2.6x.  This node keeps
 // the same semantics (capacity-mode render, zero-copy header report polled before the outputs leave forward, overflow
 // repaired in place, same arena layouts => bit-identical results) at a fraction of the host time.
-// Everything it does not cover (K > 1, constant prefixes, composites, stream capture, exact mode, non-contiguous or
-// non-float32 inputs, on_overflow='raise', debug probes) returns None and the caller takes the Python node.
+// Everything it does not cover (K > 1, constant prefixes, composites, stream capture, non-contiguous or non-float32 inputs,
+// on_overflow='raise', debug probes) returns None and the caller takes the Python node.
 #include <torch/extension.h>
 #include <torch/csrc/autograd/custom_function.h>
 #include <c10/hip/HIPStream.h>
@@ -28,6 +28,9 @@ using torch::autograd::variable_list;
 
 struct Abi {
     int (*forward_batch)(const ExaRasterForwardJob*, int32_t, int32_t, void*) = nullptr;
+    int (*forward_bin_batch)(const ExaRasterForwardJob*, int32_t, void*) = nullptr;
+    int (*forward_render_batch)(const ExaRasterForwardJob*, int32_t, int32_t, void*) = nullptr;
+    int (*read_header_async)(const void*, void*, void*) = nullptr;
     int (*backward_batch)(const ExaRasterBackwardJob*, int32_t, int32_t, void*) = nullptr;
     int (*workspace_sizes)(int32_t, int32_t, int32_t, uint64_t, ExaRasterWorkspaceSizes*) = nullptr;
     const char* (*last_error)(void) = nullptr;
@@ -39,6 +42,12 @@ struct Abi {
     std::atomic<uint32_t> next{0};
     std::atomic<uint32_t> tag{1};
 } g;
+
+const char* g_declined = "";        // why the most recent call was not taken (diagnostics: _exa_torch.last_decline())
+inline py::object decline(const char* why) {
+    g_declined = why;
+    return py::none();
+}
 
 void check_rc(int rc, const char* where) {
     if (rc == 0) return;
@@ -62,7 +71,8 @@ struct State : torch::CustomClassHolder {
     uint64_t capacity = 0;
     int64_t need = 0, retried_from = 0;
     bool poison = false;
-    Tensor ws, radii, is_vis;                 // splat records | tile workspace | bin workspace (one arena)
+    Tensor ws, bins, radii, is_vis;           // ws: splat records | tile workspace | bin workspace (one arena); exact mode: the bin
+                                              // workspace is allocated after the host has read the instance count -> `bins`
     uint64_t gb = 0, tb = 0;
     int edge[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};      // argument position -> edge of the node (tensor arguments present only)
 };
@@ -89,6 +99,36 @@ Outputs run_forward(State& st, const Tensor& m3, const c10::optional<Tensor>& sh
     float* base = planes.data_ptr<float>();
     j.out_color = base; j.out_depth = base + 3 * (size_t)H * W; j.out_alpha = base + 4 * (size_t)H * W;
     j.keep_sorted_keys = 0;
+    auto take_slot = [&](uint32_t& tag) {
+        const uint32_t slot = g.next.fetch_add(1) % (uint32_t)g.n_slots;
+        tag = g.tag.fetch_add(1);
+        if (tag == 0) tag = g.tag.fetch_add(1);
+        return slot;
+    };
+    if (st.capacity == 0) {
+        // 'exact' (what upstream does): stage 1, read the instance count back (16-byte D2H copy + one stream synchronisation),
+        // allocate exactly, stage 2
+        ExaRasterWorkspaceSizes sz{};
+        check_rc(g.workspace_sizes(st.P, W, H, 0, &sz), "workspace_sizes");
+        st.gb = sz.geom_bytes; st.tb = sz.tile_bytes;
+        st.ws = at::empty({(int64_t)(sz.geom_bytes + sz.tile_bytes)}, u8);
+        if (st.poison) st.ws.fill_(255);
+        uint8_t* w = st.ws.data_ptr<uint8_t>();
+        j.geom_ws = w; j.tile_ws = w + sz.geom_bytes; j.bin_ws = nullptr; j.capacity = 0;
+        j.host_header = nullptr; j.header_tag = 0;
+        check_rc(g.forward_bin_batch(&j, 1, stream.stream()), "exa_raster_forward_bin_batch");
+        uint32_t tag;
+        volatile uint32_t* rep = g.slots_host + 4 * take_slot(tag);
+        check_rc(g.read_header_async(j.tile_ws, const_cast<uint32_t*>(rep), stream.stream()), "exa_raster_read_header_async");
+        stream.synchronize();
+        st.need = rep[0];
+        st.capacity = std::max<uint64_t>(rep[0], 64);          // (the header reports whole 64-instance batch slots)
+        check_rc(g.workspace_sizes(st.P, W, H, st.capacity, &sz), "workspace_sizes");
+        st.bins = at::empty({(int64_t)sz.bin_bytes}, u8);
+        if (st.poison) st.bins.fill_(255);
+        j.bin_ws = st.bins.data_ptr<uint8_t>(); j.capacity = st.capacity;
+        check_rc(g.forward_render_batch(&j, 1, store_ctx ? 1 : 0, stream.stream()), "exa_raster_forward_render_batch");
+    } else
     for (int attempt = 0; attempt < 2; ++attempt) {
         ExaRasterWorkspaceSizes sz{};
         check_rc(g.workspace_sizes(st.P, W, H, st.capacity, &sz), "workspace_sizes");
@@ -98,9 +138,8 @@ Outputs run_forward(State& st, const Tensor& m3, const c10::optional<Tensor>& sh
         uint8_t* w = st.ws.data_ptr<uint8_t>();
         j.geom_ws = w; j.tile_ws = w + sz.geom_bytes; j.bin_ws = w + sz.geom_bytes + sz.tile_bytes;
         j.capacity = st.capacity;
-        const uint32_t slot = g.next.fetch_add(1) % (uint32_t)g.n_slots;
-        uint32_t tag = g.tag.fetch_add(1);
-        if (tag == 0) tag = g.tag.fetch_add(1);
+        uint32_t tag;
+        const uint32_t slot = take_slot(tag);
         volatile uint32_t* rep = g.slots_host + 4 * slot;
         j.host_header = reinterpret_cast<void*>(g.slots_dev + 16ull * slot);
         j.header_tag = tag;
@@ -207,7 +246,8 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         b.scales = fptr_w(sc); b.rotations = fptr_w(rot); b.cov3D_precomp = fptr_w(cov);
         b.radii = st->radii.data_ptr<int32_t>();
         uint8_t* w = st->ws.data_ptr<uint8_t>();
-        b.geom_ws = w; b.tile_ws = w + st->gb; b.bin_ws = w + st->gb + st->tb; b.capacity = st->capacity;
+        b.geom_ws = w; b.tile_ws = w + st->gb; b.capacity = st->capacity;
+        b.bin_ws = st->bins.defined() ? st->bins.data_ptr<uint8_t>() : w + st->gb + st->tb;
         b.dL_dcolor = g_color.data_ptr<float>(); b.dL_ddepth = fptr_w(g_depth); b.dL_dalpha = fptr_w(g_alpha);
         b.grad_ws = grad_ws.data_ptr<uint8_t>();
         b.dL_dmeans3D = fptr_w(d[0]); b.dL_dmeans2D = fptr_w(d[1]); b.dL_dcolors = fptr_w(d[2]); b.dL_dopacity = fptr_w(d[3]);
@@ -229,38 +269,42 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
 };
 
 // rasterize(settings tuple (the 12 fields of GaussianRasterizationSettings), means3D, means2D, shs, colors_precomp, opacities,
-//           scales, rotations, cov3D_precomp, capacity, auto_mode, poison, densify_stats | None)
+//           scales, rotations, cov3D_precomp, capacity (0 = 'exact': two stages with a host round trip, as upstream), auto_mode,
+//           poison, densify_stats | None)
 // -> None (not a call this node covers: take the Python node) or
 //    (color, radii, depth, alpha, is_vis, needed instances, capacity that overflowed | 0)
 py::object rasterize(const py::tuple& rs, const Tensor& m3, const Tensor& m2, const c10::optional<Tensor>& sh,
                      const c10::optional<Tensor>& col, const Tensor& op, const c10::optional<Tensor>& sc,
                      const c10::optional<Tensor>& rot, const c10::optional<Tensor>& cov, int64_t capacity, bool auto_mode,
                      bool poison, const py::object& densify) {
-    if (!g.forward_batch || rs.size() != 12) return py::none();
+    if (!g.forward_batch || rs.size() != 12) return decline("not initialised, or the settings are not a 12-tuple");
     const auto dev = m3.device();
-    if (!dev.is_cuda() || m3.dim() != 2 || m3.size(0) == 0 || capacity <= 0) return py::none();
+    if (!dev.is_cuda() || m3.dim() != 2 || m3.size(0) == 0 || capacity < 0) return decline("means3D is not a non-empty [P, 3] device tensor");
     if (!(f32c(m3, dev) && f32c(op, dev) && f32c_opt(sh, dev) && f32c_opt(col, dev) && f32c_opt(sc, dev) && f32c_opt(rot, dev) &&
           f32c_opt(cov, dev)))
-        return py::none();
-    if (!m2.defined() || m2.device() != dev) return py::none();
-    if (sh.has_value() == col.has_value()) return py::none();                     // (the Python path raises upstream's messages)
-    if ((sc.has_value() && rot.has_value()) == cov.has_value() || sc.has_value() != rot.has_value()) return py::none();
+        return decline("an input is not a contiguous float32 tensor on the device of means3D");
+    if (!m2.defined() || m2.device() != dev) return decline("means2D is on another device");
+    if (sh.has_value() == col.has_value()) return decline("shs / colors_precomp: not exactly one");                     // (the Python path raises upstream's messages)
+    if ((sc.has_value() && rot.has_value()) == cov.has_value() || sc.has_value() != rot.has_value())
+        return decline("scales + rotations / cov3D_precomp: not exactly one");
     const bool grad_on = at::GradMode::is_enabled();
     const bool need_ctx = grad_on && (m3.requires_grad() || m2.requires_grad() || op.requires_grad() ||
                                       (sh.has_value() && sh->requires_grad()) || (col.has_value() && col->requires_grad()) ||
                                       (sc.has_value() && sc->requires_grad()) || (rot.has_value() && rot->requires_grad()) ||
                                       (cov.has_value() && cov->requires_grad()));
-    if (auto_mode && !need_ctx) return py::none();          // config.mode 'auto': a render nobody differentiates is sized exactly
+    if (auto_mode && !need_ctx) capacity = 0;               // config.mode 'auto': a render nobody differentiates is sized exactly
     auto st = c10::make_intrusive<State>();
     // the settings tuple, field by field (module.py:609-622); the four tensors must already live on the device as float32
     for (int i : {4, 6, 7, 9})
-        if (!THPVariable_Check(rs[i].ptr())) return py::none();
+        if (!THPVariable_Check(rs[i].ptr())) return decline("a camera field of the settings is not a tensor");
     st->bg = THPVariable_Unpack(rs[4].ptr());
     st->view = THPVariable_Unpack(rs[6].ptr());
     st->proj = THPVariable_Unpack(rs[7].ptr());
     st->campos = THPVariable_Unpack(rs[9].ptr());
-    if (!(f32c(st->bg, dev) && f32c(st->view, dev) && f32c(st->proj, dev) && f32c(st->campos, dev))) return py::none();
-    if (st->bg.numel() < 3 || st->view.numel() < 16 || st->proj.numel() < 16 || st->campos.numel() < 3) return py::none();
+    if (!(f32c(st->bg, dev) && f32c(st->view, dev) && f32c(st->proj, dev) && f32c(st->campos, dev)))
+        return decline("a camera tensor of the settings is not contiguous float32 on the device");
+    if (st->bg.numel() < 3 || st->view.numel() < 16 || st->proj.numel() < 16 || st->campos.numel() < 3)
+        return decline("a camera tensor of the settings is too small");
     ExaRasterSettings& s = st->s;
     try {
         s.image_height = rs[0].cast<int32_t>(); s.image_width = rs[1].cast<int32_t>();
@@ -269,7 +313,7 @@ py::object rasterize(const py::tuple& rs, const Tensor& m3, const Tensor& m2, co
         s.sh_degree = rs[8].cast<int32_t>();
         s.prefiltered = rs[10].cast<bool>() ? 1 : 0; s.debug = rs[11].cast<bool>() ? 1 : 0;
     } catch (const py::cast_error&) {
-        return py::none();                                   // (scalars given as something else: the Python node converts them)
+        return decline("a scalar field of the settings has an unexpected type");      // (the Python node converts it)
     }
     s.bg = st->bg.data_ptr<float>();
     s.viewmatrix = st->view.data_ptr<float>(); s.projmatrix = st->proj.data_ptr<float>();
@@ -280,14 +324,16 @@ py::object rasterize(const py::tuple& rs, const Tensor& m3, const Tensor& m2, co
     st->poison = poison;
     if (!densify.is_none()) {
         py::tuple dt = densify.cast<py::tuple>();
-        if (dt.size() != 3) return py::none();
+        if (dt.size() != 3) return decline("densify_stats is not a 3-tuple");
         for (int i = 0; i < 3; ++i)
             if (!dt[i].is_none()) st->dens[i] = THPVariable_Unpack(dt[i].ptr());
     }
     c10::DeviceGuard guard(dev);
     auto stream = c10::hip::getCurrentHIPStream(dev.index());
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream.stream(), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return py::none();
+    if (hipStreamIsCapturing(stream.stream(), &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+        return decline("the stream is being captured");
+    g_declined = "";
     Tensor color, depth, alpha;
     if (need_ctx) {
         variable_list o = RasterizeFn::apply(st, m3, m2, sh, col, op, sc, rot, cov);
@@ -297,6 +343,7 @@ py::object rasterize(const py::tuple& rs, const Tensor& m3, const Tensor& m2, co
         Outputs o = run_forward(*st, m3, sh, col, op, sc, rot, cov, false, stream);
         color = o.color; depth = o.depth; alpha = o.alpha;
         st->ws = Tensor();
+        st->bins = Tensor();
     }
     return py::make_tuple(color, st->radii, depth, alpha, st->is_vis, st->need, st->retried_from);
 }
@@ -315,6 +362,9 @@ void init(const std::string& lib_path, uint64_t slots_host, uint64_t slots_dev, 
     g.workspace_sizes = reinterpret_cast<decltype(g.workspace_sizes)>(sym("exa_raster_workspace_sizes"));
     g.last_error = reinterpret_cast<decltype(g.last_error)>(sym("exa_raster_last_error"));
     g.backward_batch = reinterpret_cast<decltype(g.backward_batch)>(sym("exa_raster_backward_batch"));
+    g.forward_bin_batch = reinterpret_cast<decltype(g.forward_bin_batch)>(sym("exa_raster_forward_bin_batch"));
+    g.forward_render_batch = reinterpret_cast<decltype(g.forward_render_batch)>(sym("exa_raster_forward_render_batch"));
+    g.read_header_async = reinterpret_cast<decltype(g.read_header_async)>(sym("exa_raster_read_header_async"));
     g.slots_host = reinterpret_cast<volatile uint32_t*>(slots_host);
     g.slots_dev = slots_dev;
     g.n_slots = n_slots;
@@ -328,5 +378,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled autograd node of exavatar_release_amd.GaussianRasterizer over the C ABI of libexa_raster.so";
     m.def("init", &init);
     m.def("rasterize", &rasterize);
+    m.def("last_decline", []() { return std::string(g_declined); });
     m.attr("abi_version") = EXA_RASTER_VERSION;
 }

@@ -1101,22 +1101,24 @@ def _compiled_node():
 def _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, dens):
     """One render through the compiled node, or None when this call is not one it covers (the Python node takes it)."""
     cfg = config
-    if cfg.mode == 'exact' or cfg.on_overflow != 'retry' or cfg.keep_debug or cfg.upstream_scale_grad:
+    mode = cfg.mode
+    if cfg.on_overflow != 'retry' or cfg.keep_debug or cfg.upstream_scale_grad or mode not in ('auto', 'exact', 'capacity') \
+            or not means3D.is_cuda:
         return None
     node = _compiled if _compiled is not None else _compiled_node()
     if not node:
         return None
     key = (means3D.device.index, means3D.shape[0], rs[0], rs[1])
-    cap = cfg.fixed_capacity
-    if cap is None:
-        seen = _seen_D.get(key)
-        if seen is None:
-            return None           # first call of this shape: the Python node measures D once in exact mode, like upstream does
-        cap = max(int(seen * cfg.capacity_growth), cfg.min_capacity)
-    elif isinstance(cap, (list, tuple)):
-        cap = cap[0]
+    cap = 0                       # 'exact': two stages with a host round trip in between, as upstream does
+    if mode != 'exact':
+        cap = cfg.fixed_capacity
+        if cap is None:
+            seen = _seen_D.get(key)       # (first call of a shape: measured exactly once)
+            cap = 0 if seen is None else max(int(seen * cfg.capacity_growth), cfg.min_capacity)
+        elif isinstance(cap, (list, tuple)):
+            cap = cap[0]
     res = node.rasterize(rs, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, int(cap),
-                         cfg.mode == 'auto', cfg.poison, dens)
+                         mode == 'auto', cfg.poison, dens)
     if res is None:
         return None
     global compiled_calls

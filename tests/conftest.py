@@ -47,3 +47,13 @@ def _gpu_test_isolation(request):
             setattr(cfg, k, v)
         if os.environ.get('EXA_TEST_POISON'):
             cfg.poison = True
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU runs: how many renders the compiled autograd node took (gpurun_out/compiled_node_calls.txt, when that directory exists)."""
+    import sys as _sys
+    rz = _sys.modules.get('exavatar_release_amd.rasterizer')
+    out = os.path.join(ROOT, 'gpurun_out')
+    if rz is not None and getattr(rz, 'compiled_calls', 0) and os.path.isdir(out):
+        with open(os.path.join(out, 'compiled_node_calls.txt'), 'w') as f:
+            f.write('%d renders of this pytest session went through the compiled autograd node (_exa_torch)\n' % rz.compiled_calls)

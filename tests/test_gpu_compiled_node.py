@@ -1,8 +1,8 @@
 """The compiled autograd node (``csrc/torch_binding.cpp`` -> ``_exa_torch.so``) against the Python node it stands in for
 (``rasterizer._Rasterize``): the same C-ABI calls on the same arena layouts, so every output and every gradient must be equal
 BIT FOR BIT -- precomputed colours and in-kernel SH, depth / alpha gradients, fused densification statistics, non-leaf inputs,
-an overflow repaired inside the call, ``no_grad`` renders in capacity mode -- and the calls it does not cover (first call of a
-shape, exact mode, non-contiguous inputs, a stream capture) must fall through to the Python node unnoticed."""
+an overflow repaired inside the call, ``no_grad`` renders, exact (two-stage) and capacity mode -- and the calls it does not cover
+(non-contiguous inputs, settings that live on the host) must fall through to the Python node unnoticed."""
 import pytest
 import torch
 
@@ -65,7 +65,8 @@ def _same(x, y):
 
 @pytest.mark.parametrize('use_sh', [False, True])
 @pytest.mark.parametrize('image_grads', ['colour', 'all'])
-def test_compiled_node_equals_the_python_node_bit_for_bit(dev, use_sh, image_grads):
+@pytest.mark.parametrize('mode', ['auto', 'exact'])
+def test_compiled_node_equals_the_python_node_bit_for_bit(dev, use_sh, image_grads, mode):
     H, W, f, P = 144, 176, 240.0, 5000 + 7
     a = {k: v.to(dev) for k, v in scenes.dist_b_avatar(P, seed=5).items()}
     sh = scenes.sh_from_rgb(a['rgb'].cpu(), 2, seed=3, rest_sigma=0.3).to(dev).contiguous() if use_sh else None
@@ -74,10 +75,11 @@ def test_compiled_node_equals_the_python_node_bit_for_bit(dev, use_sh, image_gra
     if image_grads == 'colour':
         Gd = Ga = None
     bg = torch.rand(3, generator=g).to(dev)
+    exa.config.mode = mode
     for v in (0, 7, 19):
         st = _settings(scenes.ring_camera(H, W, v, 24, focal=f), H, W, bg, dev, 2 if use_sh else 0)
         exa.config.compiled_node = 'off'
-        ref = _run(a, st, G, Gd, Ga, sh)            # (also measures the capacity of this shape: the first call is exact)
+        ref = _run(a, st, G, Gd, Ga, sh)            # (auto: also measures the capacity of this shape, the first call is exact)
         ref = _run(a, st, G, Gd, Ga, sh)
         assert ref[2] == 0
         exa.config.compiled_node = 'auto'
@@ -116,7 +118,7 @@ def test_compiled_node_repairs_an_overflow_inside_the_call(dev):
     exa.config.compiled_node = 'off'
     exa.config.mode = 'exact'
     ref = _run(a, st, G, None, None)
-    exa.config.mode = 'auto'
+    exa.config.mode = 'capacity'
     key = (dev.index or 0, P, H, W)
     need = rz._seen_D[key]
     exa.config.compiled_node = 'auto'
@@ -139,26 +141,30 @@ def test_calls_the_compiled_node_does_not_cover_fall_through(dev):
     a = {k: v.to(dev) for k, v in scenes.dist_a_random(P, H, W, seed=3, focal=150.0).items()}
     G = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1)).to(dev)
     st = _settings(scenes.neutral_camera(H, W, focal=150.0), H, W, torch.ones(3, device=dev), dev)
-    rz._seen_D.pop((dev.index or 0, P, H, W), None)
+    key = (dev.index or 0, P, H, W)
+    rz._seen_D.pop(key, None)
     first = _run(a, st, G, None, None)
-    assert first[2] == 0                                  # first call of a shape: measured in exact mode by the Python node
+    assert first[2] == 1 and key in rz._seen_D            # first call of a shape: measured in exact mode (two stages), by either node
     second = _run(a, st, G, None, None)
     assert second[2] == 1
     _same(first, second)
-    # a no_grad render: 'auto' sizes it exactly (Python node); 'capacity' mode renders it through the compiled node
+    # a no_grad render: 'auto' sizes it exactly, 'capacity' from the memo; no context is kept either way
     with torch.no_grad():
-        n0 = rz.compiled_calls
-        c0 = exa.GaussianRasterizer(st)(means3D=a['mean_3d'], means2D=torch.zeros_like(a['mean_3d']), opacities=a['opacity'],
-                                        colors_precomp=a['rgb'], scales=a['scale'], rotations=a['rotation'])
-        assert rz.compiled_calls == n0
-        exa.config.mode = 'capacity'
-        c1 = exa.GaussianRasterizer(st)(means3D=a['mean_3d'], means2D=torch.zeros_like(a['mean_3d']), opacities=a['opacity'],
-                                        colors_precomp=a['rgb'], scales=a['scale'], rotations=a['rotation'])
-        assert rz.compiled_calls == n0 + 1
+        outs = {}
+        for how in ('off', 'auto'):
+            exa.config.compiled_node = how
+            for mode in ('auto', 'capacity'):
+                exa.config.mode = mode
+                n0 = rz.compiled_calls
+                outs[how, mode] = exa.GaussianRasterizer(st)(means3D=a['mean_3d'], means2D=torch.zeros_like(a['mean_3d']),
+                                                             opacities=a['opacity'], colors_precomp=a['rgb'], scales=a['scale'],
+                                                             rotations=a['rotation'])
+                assert rz.compiled_calls == n0 + (how == 'auto')
         exa.config.mode = 'auto'
-    for x, y in zip(c0, c1):
-        assert torch.equal(x, y)
-    assert torch.equal(c0[0], first[0][0]) and not c1[0].requires_grad
+    for o in outs.values():
+        for x, y in zip(o, outs['off', 'auto']):
+            assert torch.equal(x, y)
+        assert torch.equal(o[0], first[0][0]) and not o[0].requires_grad
     # non-contiguous input: converted by the Python node
     b = dict(a)
     b['scale'] = a['scale'].t().contiguous().t()

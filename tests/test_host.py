@@ -190,6 +190,21 @@ def test_product_path_has_no_cpu_fallback():
             assert not pat.search(open(os.path.join(pkg, fn)).read()), fn
 
 
+def test_compiled_autograd_node_is_built_against_this_abi_and_declines_what_it_cannot_run():
+    """``_exa_torch`` (csrc/torch_binding.cpp): host C++ over the C ABI.  It must be in the tree (built by
+    ``__graft_entry__.build()``), carry the ABI version of the header it was compiled against, and hand a call it cannot run
+    -- here: before ``init`` (no GPU in this container), CPU tensors -- back to the Python node by returning None."""
+    from exavatar_release_amd import _exa_torch
+    assert _exa_torch.abi_version == _lib.load().exa_raster_version()
+    m = torch.zeros(4, 3)
+    assert _exa_torch.rasterize(_settings(), m, m, None, m, torch.ones(4, 1), torch.ones(4, 3), torch.ones(4, 4), None, 64, True,
+                                False, None) is None
+    assert _exa_torch.last_decline() != ''
+    src = open(os.path.join(ROOT, 'exavatar_release_amd', 'csrc', 'torch_binding.cpp')).read()
+    assert '__global__' not in src and 'hipLaunchKernelGGL' not in src          # host code only: the kernels live behind the C ABI
+    assert 'oracle' not in src
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, '_lib', None)
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
