@@ -66,6 +66,35 @@ def test_poisoned_workspaces_do_not_show_through(dev):
                 assert torch.equal(out[k]['img'].detach(), out3[k]['img'].detach()), k
             for i, name in enumerate(('scene', 'human', 'refined human')):
                 _assert_same_grads(s[i], r3[i], 'iteration, slack %.1f, %s' % (slack, name))
+        # StaticRender (the C ABI with static storage, bench.py's headline path): ONE set of workspaces reused by views with very
+        # different instance counts, allocated through the same poisoned allocator -- stale sections would show here
+        from exavatar_release_amd.renderer import _raster_job
+        cam_b = {k: v.to(dev) for k, v in scenes.ring_camera(H, W, 3, 8, radius=2.0, center=(0.0, 0.0, 4.0), focal=F).items()}
+        exa.config.mode, exa.config.fixed_capacity = 'exact', None
+        exa.config.poison = False
+        ref_b = _leaves(scene, dev)
+        ref_b_out = rend(ref_b, (H, W), cam_b, bg)
+        (ref_b_out['img'] * G).sum().backward()
+        exa.config.poison = True
+        flat = {k: v.detach().to(dev).contiguous() for k, v in scene.items()}
+        sts = [_raster_job(flat, (H, W), c, bg)['raster_settings'] for c in (cam, cam_b)]
+        with exa.StaticRender(flat['mean_3d'], flat['opacity'], flat['scale'], flat['rotation'], colors_precomp=flat['rgb'],
+                              image_size=(H, W), capacity=int(ns * 3.0), slots=2) as sr:
+            vs = [sr.add_view(st, dL_dcolor=G) for st in sts]
+            assert [sr.add_grad_outputs() for _ in range(2)] == [0, 1]
+            for order in ((0, 1), (1, 0), (0, 0), (1, 1)):
+                for slot, v in enumerate(order):
+                    sr.forward(vs[v], slot=slot)
+                    sr.backward(slot, slot=slot)
+                sr.check()
+                for slot, v in enumerate(order):
+                    want_out, want = (ref_out, ref) if v == 0 else (ref_b_out, ref_b)
+                    assert torch.equal(sr.outputs(slot)['color'], want_out['img'].detach()), ('static', order, slot)
+                    g = sr.grad_outputs(slot)
+                    for k, n in (('mean_3d', 'means3D'), ('scale', 'scales'), ('rotation', 'rotations'), ('opacity', 'opacities'),
+                                 ('rgb', 'colors_precomp')):
+                        assert not bool(torch.isnan(g[n]).any()), ('static', k, 'NaN: a poisoned section was read')
+                        assert torch.equal(g[n].view_as(want[k].grad), want[k].grad), ('static', order, slot, k)
         exa.config.mode, exa.config.fixed_capacity = 'exact', None
         with exa.GraphedIteration((H, W), dev) as it:
             for rep in range(2):

@@ -1,6 +1,8 @@
 """``StaticRender`` (exavatar_release_amd/static.py): the C ABI driven with static storage and pre-marshalled jobs must give
 what the autograd surface gives -- same kernels, same bits -- for several cameras in turn, with precomputed colours and with
-in-kernel SH, for training and no_grad renders, into caller-owned gradient arrays; and an overflowed render must raise."""
+in-kernel SH, for training and no_grad renders, into caller-owned gradient arrays, with several renders in flight (slots) and
+their gradients accumulated in a fixed order; an overflowed render is repaired inside the call (or raises, by policy); and the
+object follows a training run whose Gaussian count changes (``rebind``)."""
 import pytest
 import torch
 
@@ -98,7 +100,7 @@ def test_static_no_grad_render_and_overflow_raises(dev):
         with pytest.raises(RuntimeError, match='not a training render'):
             sr.backward()
     with exa.StaticRender(a['mean_3d'], a['opacity'], a['scale'], a['rotation'], colors_precomp=a['rgb'], image_size=(H, W),
-                          capacity=max(64, need // 4), train=False) as sr:
+                          capacity=max(64, need // 4), train=False, on_overflow='raise') as sr:
         v = sr.add_view(st)
         sr.forward(v)
         with pytest.raises(RuntimeError, match='needed %d instances' % need):
@@ -140,3 +142,192 @@ def test_static_render_reads_its_cameras_in_place(dev):
             ref = exa.GaussianRasterizer(str_)(means3D=a['mean_3d'], means2D=torch.zeros_like(a['mean_3d']), opacities=a['opacity'],
                                                colors_precomp=a['rgb'], scales=a['scale'], rotations=a['rotation'])[0]
         assert torch.equal(imgs[r], ref)
+
+
+def _sum_in_order(gs):
+    out = gs[0].clone()
+    for g in gs[1:]:
+        out = out + g
+    return out
+
+
+def test_static_slots_keep_views_in_flight_and_accumulate_in_order(dev):
+    """Three slots: six views dealt round-robin, each into its own gradient set, equal the autograd surface bit for bit; then
+    groups of three views ACCUMULATED into one set through the chained per-Gaussian kernels = the sum in slot order."""
+    H, W, f, P = 144, 176, 240.0, 5000 + 7
+    a = {k: v.to(dev) for k, v in scenes.dist_b_avatar(P, seed=5).items()}
+    g = torch.Generator().manual_seed(6)
+    G, Gd, Ga = (torch.randn(n, H, W, generator=g).to(dev) for n in (3, 1, 1))
+    bg = torch.rand(3, generator=g).to(dev)
+    sts = [_settings(scenes.ring_camera(H, W, v, 24, focal=f), H, W, bg, dev) for v in (0, 4, 7, 12, 19, 22)]
+    exa.config.mode = 'exact'
+    refs = [_reference(a, st, G, Gd, Ga) for st in sts]
+    need = exa.required_capacity(a['mean_3d'], a['opacity'], a['scale'], a['rotation'], colors_precomp=a['rgb'], settings=sts)
+    S = 3
+    with exa.StaticRender(a['mean_3d'], a['opacity'], a['scale'], a['rotation'], colors_precomp=a['rgb'], image_size=(H, W),
+                          capacity=need, slots=S) as sr:
+        assert sr.n_slots == S
+        views = [sr.add_view(st, dL_dcolor=G, dL_ddepth=Gd, dL_dalpha=Ga) for st in sts]
+        sets = [sr.add_grad_outputs() for _ in range(S)]
+        for rounds in range(2):
+            for base in (0, 3):
+                sr.begin()
+                for s in range(S):
+                    sr.forward(views[base + s], slot=s)
+                    sr.backward(sets[s], slot=s)
+                sr.end()
+                sr.check()
+                for s in range(S):
+                    color, depth, alpha, radii, gr = refs[base + s]
+                    o = sr.outputs(s)
+                    assert torch.equal(o['color'], color) and torch.equal(o['depth'], depth) and torch.equal(o['alpha'], alpha)
+                    assert torch.equal(o['radii'], radii) and torch.equal(o['is_vis'], radii > 0)
+                    for k, ref in gr.items():
+                        assert torch.equal(sr.grad_outputs(sets[s])[k].view_as(ref), ref), (k, base, s)
+        total = sr.add_grad_outputs()
+        for base in (0, 3, 0):
+            sr.begin()
+            for s in range(S):
+                sr.forward(views[base + s], slot=s)
+                sr.backward(total, slot=s, accumulate=s > 0, after=s - 1 if s else None)
+            sr.end()
+            sr.check()
+            got = sr.grad_outputs(total)
+            for k in ('means3D', 'opacities', 'scales', 'rotations', 'colors_precomp'):
+                want = _sum_in_order([refs[base + s][4][k] for s in range(S)])
+                assert torch.equal(got[k].view_as(want), want), (k, base)
+            assert torch.equal(got['means2D'], refs[base + S - 1][4]['means2D'])        # per render: the last one's
+
+
+def test_static_render_repairs_an_overflow_inside_the_call(dev):
+    H, W, f, P = 128, 128, 200.0, 4000
+    a = {k: v.to(dev) for k, v in scenes.dist_b_avatar(P, seed=8).items()}
+    g = torch.Generator().manual_seed(3)
+    G, Gd, Ga = (torch.randn(n, H, W, generator=g).to(dev) for n in (3, 1, 1))
+    bg = torch.ones(3, device=dev)
+    sts = [_settings(scenes.ring_camera(H, W, v, 24, focal=f), H, W, bg, dev) for v in (3, 9)]
+    exa.config.mode = 'exact'
+    refs = [_reference(a, st, G, Gd, Ga) for st in sts]
+    needs = [exa.required_capacity(a['mean_3d'], a['opacity'], a['scale'], a['rotation'], colors_precomp=a['rgb'], settings=st)
+             for st in sts]
+    with exa.StaticRender(a['mean_3d'], a['opacity'], a['scale'], a['rotation'], colors_precomp=a['rgb'], image_size=(H, W),
+                          capacity=max(64, min(needs) // 4)) as sr:
+        views = [sr.add_view(st, dL_dcolor=G, dL_ddepth=Gd, dL_dalpha=Ga) for st in sts]
+        for rounds in range(2):
+            for v, (color, depth, alpha, radii, gr) in zip(views, refs):
+                sr.forward(v)
+                sr.backward()
+                sr.check()
+                assert torch.equal(sr.color, color) and torch.equal(sr.depth, depth) and torch.equal(sr.alpha, alpha)
+                assert torch.equal(sr.radii, radii)
+                for k, ref in gr.items():
+                    assert torch.equal(sr.grads[k].view_as(ref), ref), k
+        assert 1 <= sr.repairs <= 2 and sr.capacity >= max(needs)          # the slot kept the larger buffers: no repair in round 2
+        n = sr.repairs
+        sr.forward(views[0])
+        assert sr.repairs == n
+
+
+def test_static_render_follows_a_training_run_with_densification(dev):
+    """A loop shaped like ``avatar/main/train.py:41-57`` on ONE Gaussian set: render, L2 loss against a target, Adam, and every
+    20 steps clone / prune (``avatar/main/model.py:279-292`` changes P every 100) -- through ``StaticRender`` (``rebind`` after
+    every change of P, one forced overflow) and through the autograd surface: the same parameters bit for bit."""
+    H, W, f, P0 = 96, 128, 170.0, 2500
+    a0 = scenes.dist_a_random(P0, H, W, seed=21, focal=f)
+    tgt = {k: (v + 0.03 * torch.randn(v.shape, generator=torch.Generator().manual_seed(5)) if k in ('mean_3d', 'rgb') else v.clone())
+           for k, v in a0.items()}
+    tgt['rgb'].clamp_(0, 1)
+    bg = torch.tensor([0.1, 0.4, 0.3], device=dev)
+    cams = [scenes.ring_camera(H, W, 5 * v, 40, radius=3.2, center=(0.0, 0.0, 3.0), focal=f) for v in range(4)]
+    sts = [_settings(c, H, W, bg, dev) for c in cams]
+    names = ('mean_3d', 'opacity', 'scale', 'rotation', 'rgb')
+    exa.config.mode = 'exact'
+    with torch.no_grad():
+        targets = [exa.GaussianRasterizer(st)(means3D=tgt['mean_3d'].to(dev), means2D=torch.zeros(P0, 3, device=dev),
+                                              opacities=tgt['opacity'].to(dev), colors_precomp=tgt['rgb'].to(dev),
+                                              scales=tgt['scale'].to(dev), rotations=tgt['rotation'].to(dev))[0].clone() for st in sts]
+
+    def densify(params, score, rnd):
+        """clone the 10 % with the largest accumulated screen-space gradient (displaced a little), prune the 5 % most transparent"""
+        P = params['mean_3d'].shape[0]
+        top = torch.topk(score, P // 10).indices.sort().values
+        keep = torch.ones(P, dtype=torch.bool, device=dev)
+        if rnd % 2:
+            keep[torch.topk(-params['opacity'].flatten(), P // 20).indices] = False
+        new = {}
+        for k, v in params.items():
+            extra = v[top].clone()
+            if k == 'mean_3d':
+                extra = extra + 0.01
+            new[k] = torch.cat((v[keep], extra)).contiguous()
+        return new
+
+    def run(static):
+        params = {k: a0[k].to(dev).clone() for k in names}
+        sr, outs, losses, p_hist = None, None, [], []
+        dL = torch.zeros(3, H, W, device=dev)
+        score = torch.zeros(P0, device=dev)
+        make_opt = lambda: torch.optim.Adam([{'params': [params[k]], 'lr': 2e-3 if k != 'mean_3d' else 5e-4} for k in names], eps=1e-15)  # noqa: E731
+        opt = make_opt()
+        if static:
+            need = max(exa.required_capacity(params['mean_3d'], params['opacity'], params['scale'], params['rotation'],
+                                             colors_precomp=params['rgb'], settings=st) for st in sts)
+            sr = exa.StaticRender(params['mean_3d'], params['opacity'], params['scale'], params['rotation'],
+                                  colors_precomp=params['rgb'], image_size=(H, W), capacity=int(need * 1.3))
+            for st in sts:
+                sr.add_view(st, dL_dcolor=dL)
+        for i in range(70):
+            v = (i * 3) % len(sts)
+            if static:
+                sr.forward(v)
+                torch.sub(sr.color, targets[v], out=dL)
+                loss = 0.5 * (dL * dL).sum()
+                sr.backward()
+                g = sr.grads
+                grads = {'mean_3d': g['means3D'], 'opacity': g['opacities'], 'scale': g['scales'], 'rotation': g['rotations'],
+                         'rgb': g['colors_precomp']}
+                m2, radii = g['means2D'], sr.radii
+            else:
+                leaves = {k: params[k].requires_grad_(True) for k in names}
+                probe = torch.zeros(params['mean_3d'].shape[0], 3, device=dev, requires_grad=True)
+                color, radii, _, _ = exa.GaussianRasterizer(sts[v])(
+                    means3D=leaves['mean_3d'], means2D=probe, opacities=leaves['opacity'], colors_precomp=leaves['rgb'],
+                    scales=leaves['scale'], rotations=leaves['rotation'])
+                d = color.detach() - targets[v]
+                loss = 0.5 * (d * d).sum()
+                gl = torch.autograd.grad([color], [leaves[k] for k in names] + [probe], grad_outputs=[d])
+                grads = dict(zip(names, gl[:5]))
+                m2 = gl[5]
+                for k in names:
+                    params[k].requires_grad_(False)
+            score += m2[:, :2].norm(dim=1) * (radii > 0)
+            for k in names:
+                params[k].grad = grads[k].view_as(params[k]).clone()
+            opt.step()
+            with torch.no_grad():
+                params['opacity'].clamp_(0.01, 0.99)
+                params['scale'].clamp_(1e-4, 1.0)
+                params['rgb'].clamp_(0.0, 1.0)
+            losses.append(float(loss))
+            if i % 20 == 19:
+                params = densify(params, score, i // 20)
+                score = torch.zeros(params['mean_3d'].shape[0], device=dev)
+                opt = make_opt()
+                if static:
+                    # P changed: new tensors.  The second rebind also shrinks the instance buffers to a quarter: the next forward
+                    # overflows and is repaired in place
+                    sr.rebind(params['mean_3d'], params['opacity'], params['scale'], params['rotation'], colors_precomp=params['rgb'],
+                              capacity=sr.capacity // 4 if i == 39 else None)
+            p_hist.append(int(params['mean_3d'].shape[0]))
+        res = {'final': [params[k].clone() for k in names], 'losses': losses, 'p_hist': p_hist, 'repairs': sr.repairs if static else 0}
+        if static:
+            sr.close()
+        return res
+    ref = run(False)
+    got = run(True)
+    assert got['p_hist'] == ref['p_hist'] and len(set(ref['p_hist'])) >= 3
+    assert got['losses'] == ref['losses']
+    for x, y in zip(got['final'], ref['final']):
+        assert torch.equal(x, y)
+    assert got['repairs'] >= 1
+    assert sum(ref['losses'][-10:]) < sum(ref['losses'][:10])
