@@ -8,12 +8,14 @@ rasterize at 1024x1024 with ~150 k avatar-like Gaussians (config C3), view-shard
 One "step" = one rasterizer forward + its backward for one training view with a dense
 dL/dimage (inputs already resident in HBM), followed for N > 1 by the RCCL all-reduce of the
 Gaussian gradients (14 floats x P = 8.4 MB) through the product's `dist.FlatGradAllReducer`.
-How the step is issued (`--launch`): `abi` (default since late round 5) -- plain kernel launches straight through the C ABI
+How the step is issued (`--launch`): `abi` (default) -- plain kernel launches straight through the C ABI
 (`exa_raster_forward_batch` + `exa_raster_backward_batch`) from the product's `StaticRender`: static buffers, the jobs of every
-view marshalled once and reading their camera in place from the resident table, two ctypes calls per step, gradients written
-directly into the all-reducer's flat buffers; `graph` -- the drop-in autograd surface (`GaussianRasterizer` + `autograd.grad`)
-captured once and replayed from a hipGraph (the headline of rounds 2-5; the default line carries it as `extra_graph_replay`);
-`eager` -- the autograd surface call by call (host-bound: ~310 us of host per step against ~142 us of device).  Views: the 200
+view marshalled once and reading their camera in place from the resident table, two ctypes calls per step, every forward polling
+its own overflow report (and re-rendering in place if it had to), gradients written directly into the all-reducer's flat buffers;
+`surface` (= `eager`) -- the drop-in autograd surface call by call: `GaussianRasterizer(settings)(...)` + `torch.autograd.grad`
+through the compiled autograd node.  The default line ALWAYS carries the surface next to the ABI headline
+(`extra_plugin_surface_eager`, also for N > 1).  `--views-in-flight S`: S render slots of the `StaticRender` on S HIP streams, a
+step = a group of S views whose gradients are accumulated in slot order (N > 1: one all-reduce per group).  Views: the 200
 ring cameras of config C4 dealt by the product's `dist.shard_views` in a fixed stratified order (step i -> view
 (i * 123) mod 200: a short run covers the ring like a long one); every rank cycles through its shard, so
 per-GPU work is fixed as N grows (weak scaling) and `value` = views rasterized fwd+bwd per second over all ranks.
@@ -23,10 +25,13 @@ Other workloads: `--config c2|c1` (same step), `--config c5` = BASELINE configs[
 protocols -- the animation / inference use case of avatar/main/animate.py:64-66.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects: `roofline` (dominant kernel,
-HIP-event timed inside this script), `cpu_baseline` (the CPU oracle timed on a bounded sample of the same
-workload, rank 0 at N = 1 only), `extra_batched_views` (K views per batched launch, next to -- never instead of --
-the single-view headline), `extra_views_in_flight` (independent views on separate streams) and `extra_exavatar_iteration`
-(the five same-camera renders of one ExAvatar training sample, eager, three ways).
+HIP-event timed inside this script; `traffic` / `secondary` / `rocprof` are quoted from committed profiles ONLY when those were
+measured on the build that is loaded -- digest of the library sources -- and are null with the reason otherwise),
+`cpu_baseline` (the CPU oracle timed on a bounded sample of the same workload, rank 0 at N = 1 only),
+`extra_plugin_surface_eager`, `extra_abi_views_in_flight` (four views in flight through the C ABI), `extra_batched_views`
+(K views per batched launch, next to -- never instead of -- the single-view headline) and `extra_exavatar_iteration`
+(the five same-camera renders of one ExAvatar training sample, eager, three ways); for N > 1 every rank's own step time with
+and without the exchange (`rccl.ranks`).
 """
 import argparse
 import ctypes
@@ -42,7 +47,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_VIEWS = 200
 VIEW_STRIDE = 123      # step i renders ring view (i * VIEW_STRIDE) mod N_VIEWS (coprime: a permutation)
-PROFILE_PREFIXES = ('r05', 'r04', 'r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
+PROFILE_PREFIXES = ('r06', 'r05', 'r04', 'r03', 'r02')   # profiles/<prefix>_hbm_traffic.json feeds roofline.traffic (newest first)
 
 
 def parse():
@@ -53,18 +58,17 @@ def parse():
     ap.add_argument('--config', default='c3', choices=['c3', 'c2', 'c1', 'c5'])
     ap.add_argument('--mode', default=None, choices=['train', 'forward'],
                     help='train = forward + backward (default; c5 defaults to forward)')
-    ap.add_argument('--launch', default='abi', choices=['abi', 'graph', 'eager'],
-                    help="how a step is issued: 'abi' (default) plain launches straight through the C ABI from pre-marshalled "
-                         "jobs and static buffers (exavatar_release_amd.StaticRender), 'graph' the autograd surface replayed "
-                         "from a hipGraph (the headline of rounds 2-5; reported next to the headline as extra_graph_replay), "
-                         "'eager' the autograd surface call by call (host-bound)")
-    ap.add_argument('--streams', type=int, default=1,
-                    help='independent views in flight per GPU (each on its own HIP stream + hipGraph); 1 = one '
-                         'view at a time, the headline configuration')
-    ap.add_argument('--views-per-launch', type=int, default=1,
-                    help='K views of this rank\'s shard per batched launch (exa_raster_*_batch); 1 = the headline')
+    ap.add_argument('--launch', default='abi', choices=['abi', 'surface', 'eager'],
+                    help="how a step is issued: 'abi' (default) plain launches straight through the C ABI from pre-marshalled jobs and "
+                         "static buffers (exavatar_release_amd.StaticRender); 'surface' (= 'eager') the drop-in autograd surface call by "
+                         "call: GaussianRasterizer(settings)(...) + torch.autograd.grad through the compiled autograd node (the default "
+                         "line carries it as extra_plugin_surface_eager)")
+    ap.add_argument('--views-in-flight', type=int, default=1,
+                    help="'abi' only: S render slots of the StaticRender, each on its own HIP stream; a step is then a GROUP of S views "
+                         "of this rank's shard whose gradients are accumulated in slot order into one set of arrays (N > 1: one "
+                         "all-reduce per group); 1 = the headline, one view at a time")
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-concurrent', action='store_true')
+    ap.add_argument('--no-concurrent', action='store_true', help='skip the extras that run next to the headline')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true', help='skip the extra_c5_forward / extra_c2 child runs')
     return ap.parse_args()
@@ -134,7 +138,7 @@ def main():
     import exavatar_release_amd as exa
     from exavatar_release_amd import _lib
     from exavatar_release_amd import dist as exa_dist
-    from exavatar_release_amd.rasterizer import (GaussianRasterizationSettings, rasterize_gaussians,
+    from exavatar_release_amd.rasterizer import (GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians,
                                                  rasterize_gaussians_batch)
 
     mode = args.mode or ('forward' if args.config == 'c5' else 'train')
@@ -144,12 +148,12 @@ def main():
     P = assets['mean_3d'].shape[0]
     use_sh = 'sh' in assets
     sh_degree = 3 if use_sh else 0
-    KV = max(1, args.views_per_launch)
-    S = max(1, args.streams)
-    if world > 1 and (S > 1 or KV > 1):
-        raise SystemExit('bench.py: --streams / --views-per-launch > 1 are only implemented for --gpus 1')
+    launch = 'surface' if args.launch == 'eager' else args.launch
+    S = max(1, args.views_in_flight)
+    if S > 1 and (launch != 'abi' or not train):
+        raise SystemExit("bench.py: --views-in-flight > 1 needs --launch abi and --mode train")
 
-    # ---- parameters: contiguous leaves; for N > 1 their gradients are packed into ONE flat buffer ----
+    # ---- parameters: contiguous leaves; for N > 1 their gradients travel in ONE flat buffer ----
     names = ('mean_3d', 'scale', 'rotation', 'opacity') + (('sh',) if use_sh else ('rgb',))
     params = [assets[k].to(device).contiguous().requires_grad_(train) for k in names]
     n_float = sum(p.numel() for p in params)
@@ -168,7 +172,9 @@ def main():
     view_order = list(range(N_VIEWS)) if ring_order else [(i * VIEW_STRIDE) % N_VIEWS for i in range(N_VIEWS)]
     my_views = exa_dist.shard_views(N_VIEWS, rank, world, order=view_order) if args.config != 'c1' else [0]
     vs = [view_settings(k, shape, args.config) for k in my_views]
-    # one 48-float row per view: viewmatrix (16) | projmatrix (16) | campos (3) | pad -- a view switch is ONE copy
+    n_my = len(my_views)
+    # the views are RESIDENT: one 48-float row per view -- viewmatrix (16) | projmatrix (16) | campos (3) | pad -- and every view's
+    # settings point INTO its row: no camera is copied per step by any protocol of this script
     cam_tab = torch.zeros(len(vs), 48)
     for j, v in enumerate(vs):
         cam_tab[j, 0:16] = v['view'].reshape(-1).cpu()
@@ -176,75 +182,42 @@ def main():
         cam_tab[j, 32:35] = v['campos'].reshape(-1).cpu()
     cam_tab = cam_tab.to(device)
 
+    def settings_of(table, j, v):
+        return GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=v['tanfovx'], tanfovy=v['tanfovy'], bg=bg, scale_modifier=1.0,
+            viewmatrix=table[j, 0:16].view(4, 4), projmatrix=table[j, 16:32].view(4, 4), sh_degree=sh_degree,
+            campos=table[j, 32:35], prefiltered=False, debug=False)
+    view_st = [settings_of(cam_tab, j, v) for j, v in enumerate(vs)]
+
     def make_ctx(kv=1):
-        """One launch context: kv camera slots (static tensors the captured graph reads), settings, mean_2d probes."""
+        """A launch context of the extras that replay K views per batched call from a hipGraph (batched_throughput) and of the
+        per-kernel timing: kv camera slots (static tensors a captured graph reads), settings, mean_2d probes."""
         c = {'cam': cam_tab[:kv].clone()}
-        c['settings'] = [GaussianRasterizationSettings(
-            image_height=H, image_width=W, tanfovx=vs[0]['tanfovx'], tanfovy=vs[0]['tanfovy'], bg=bg,
-            scale_modifier=1.0, viewmatrix=c['cam'][i, 0:16].view(4, 4), projmatrix=c['cam'][i, 16:32].view(4, 4),
-            sh_degree=sh_degree, campos=c['cam'][i, 32:35], prefiltered=False, debug=False) for i in range(kv)]
+        c['settings'] = [settings_of(c['cam'], i, vs[0]) for i in range(kv)]
         c['mean_2d'] = [torch.zeros(P, 3, device=device, requires_grad=train) for _ in range(kv)]
         c['stream'] = None
         c['graph'] = None
         c['kv'] = kv
         return c
 
-    # N > 1: gradients go through the product's double-buffered flat all-reducer: two launch contexts on the SAME
-    # stream, context i packs into buffer i (captured in its graph), the all-reduce of step i overlaps step i + 1
-    n_ctx = S if world == 1 else 2
-    reducer = exa_dist.FlatGradAllReducer(params, average=False, n_buffers=2) if world > 1 else None
-    ctxs = [make_ctx(KV) for _ in range(n_ctx)]
-    for c in ctxs:
-        if S > 1:
-            c['stream'] = torch.cuda.Stream()
-
-    # How the GRAPH-REPLAYED single-view step (--launch graph, and the extras built on captured contexts) gets its camera: 'graph' (default) -- the first node of the captured graph is
-    # exa_raster_select_row: row (counter mod views) of the resident camera table -> the graph's camera block, counter + 1
-    # (the ring of views is resident in HBM, as the contract of this line says; no launch outside the graph per step);
-    # 'kernel' -- one eager elementwise kernel in front of every replay (round 4 until this change: ~4.5 us of GPU time per step,
-    # mostly the system-scope fences of a launch outside the graph); 'memcpy' -- the runtime's blit (rounds 1-3).
-    # (Round 5 tried to take the 4.6 us of that first node off the chain: select_row on a FORKED branch of the step's graph,
-    #  filling the camera block of the NEXT step while this one runs, two blocks / two graphs alternating.  A graph with two
-    #  branches costs this runtime ~30 us per replay: 5 500 against 6 640 it/s, twice each on one box.  Not kept.)
-    cam_mode = os.environ.get('EXA_BENCH_CAM_COPY', 'graph')
-    view_counter = torch.zeros(1, dtype=torch.int32, device=device)
-    in_graph_switch = {'on': False}
-
-    def select_view_in_graph(c):
-        _lib.check(_lib.load().exa_raster_select_row(
-            ctypes.c_void_p(cam_tab.data_ptr()), len(my_views), 48, ctypes.c_void_p(view_counter.data_ptr()),
-            ctypes.c_void_p(c['cam'].data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
-
-    def seek_view(i):
-        """(outside the timed region) the next replay renders this rank's view i mod views"""
-        if in_graph_switch['on']:
-            view_counter.fill_(i % len(my_views))
-
     def set_view(i, c):
         """Point context c at views i .. i + kv - 1 of this rank's shard (ONE gather-copy kernel)."""
         if c['kv'] == 1:
-            if in_graph_switch['on'] and c.get('graph') is not None and c.get('switch_in_graph'):
-                return                                                          # the replay itself takes the next row
-            if cam_mode == 'memcpy':
-                c['cam'].copy_(cam_tab[i % len(my_views)].view(1, 48))          # the runtime's blit: 3.6 us of GPU time per step
-            else:
-                j = i % len(my_views)
-                torch.mul(cam_tab[j:j + 1], 1.0, out=c['cam'])                  # one elementwise kernel
+            j = i % n_my
+            torch.mul(cam_tab[j:j + 1], 1.0, out=c['cam'])                  # one elementwise kernel
         else:
-            idx = torch.arange(i * c['kv'], (i + 1) * c['kv'], device=device) % len(my_views)
+            idx = torch.arange(i * c['kv'], (i + 1) * c['kv'], device=device) % n_my
             torch.index_select(cam_tab, 0, idx, out=c['cam'])
 
-    def raster_step(c, buf=None):
-        """forward (+ backward) of the rasterizer for the kv views of context c; N > 1: gradients packed into `buf`."""
+    def raster_step(c):
+        """forward (+ backward) of the rasterizer for the kv views of context c through the autograd surface."""
         m3, sc, rot, op, col = params
         kw = dict(shs=col, colors_precomp=None) if use_sh else dict(shs=None, colors_precomp=col)
         if c['kv'] == 1:
             if train:
                 color, radii, depth, alpha = rasterize_gaussians(m3, c['mean_2d'][0], kw['shs'], kw['colors_precomp'], op, sc,
                                                                  rot, None, c['settings'][0])
-                grads = torch.autograd.grad([color], params + c['mean_2d'], grad_outputs=[dL_dimg])
-                if reducer is not None:
-                    reducer.pack(grads[:5], buf)          # elementwise kernels: capturable in the hipGraph
+                torch.autograd.grad([color], params + c['mean_2d'], grad_outputs=[dL_dimg])
             else:
                 with torch.no_grad():
                     rasterize_gaussians(m3, c['mean_2d'][0], kw['shs'], kw['colors_precomp'], op, sc, rot, None,
@@ -260,7 +233,6 @@ def main():
                 rasterize_gaussians_batch(jobs)
 
     # ---- calibrate the instance-buffer capacity over this rank's views (stage 1 through the C ABI, untimed) -------
-    import ctypes
     lib = _lib.load()
     from exavatar_release_amd.rasterizer import _make_settings, _ptr, _stream_ptr, read_header
     sz = _lib.workspace_sizes(P, W, H, 0)
@@ -268,11 +240,9 @@ def main():
     tile = torch.empty(int(sz.tile_bytes), dtype=torch.uint8, device=device)
     radii = torch.empty(P, dtype=torch.int32, device=device)
     D_list, V_list, I_list, T_list = [], [], [], []
-    c0 = ctxs[0]
-    for i in range(len(my_views)):        # every view of the shard: the capacity below provably covers them
-        c0['cam'][0].copy_(cam_tab[i])
+    for i in range(n_my):        # every view of the shard: the capacity below provably covers them
         keep = []
-        st = _make_settings(c0['settings'][0], device, keep)
+        st = _make_settings(view_st[i], device, keep)
         m3, sc, rot, op, col = [t.detach() for t in params]
         _lib.check(lib.exa_raster_forward_bin(ctypes.byref(st), P, 16 if use_sh else 0, _ptr(m3), _ptr(col) if use_sh else None,
                                               None if use_sh else _ptr(col), _ptr(op), _ptr(sc), _ptr(rot), None, _ptr(radii),
@@ -286,27 +256,30 @@ def main():
     D_max, I_mean, V_mean = max(D_list), sum(I_list) / len(I_list), sum(V_list) / len(V_list)
     D_mean = sum(T_list) / len(T_list)
     exa.config.mode = 'capacity'
-    exa.config.fixed_capacity = int(D_max) + 64      # every view of the shard was probed: D_max is exact (overflow is checked)
+    exa.config.fixed_capacity = int(D_max) + 64      # every view of the shard was probed: D_max is exact (and every render checks itself)
+
+    # N > 1: gradients go through the product's double-buffered flat all-reducer: the all-reduce of step i overlaps the
+    # rasterize of step i + 1 (buffer i & 1); 'abi' writes its gradients straight into the reducer's buffers
+    reducer = exa_dist.FlatGradAllReducer(params, average=False, n_buffers=2) if world > 1 else None
+    wait_host = [0.0]
+
+    def reducer_wait(k):
+        if reducer is not None:
+            t_w = time.perf_counter()
+            reducer.wait(k)                 # the all-reduce that last read this gradient buffer (two steps ago)
+            wait_host[0] += time.perf_counter() - t_w
 
     # ---- 'abi': the step straight through the C ABI (exavatar_release_amd/static.py) ----------------------------
     # One StaticRender: static inputs, workspaces, images, gradient arrays; the forward / backward jobs of every view of the
-    # shard marshalled once, their settings pointing INTO the resident camera table (no per-step camera copy); a step = two
-    # ctypes calls = seven kernel launches on the current stream.  N > 1: the gradient arrays ARE the two flat buffers of the
-    # all-reducer (no pack kernels).
-    launch = args.launch
-    use_abi = launch == 'abi' and KV == 1 and S == 1
-    if launch == 'abi' and not use_abi:
-        launch = 'graph'                     # the batched / multi-stream variants are built on the captured contexts
+    # shard marshalled once, their settings pointing INTO the resident camera table; a step = two ctypes calls = seven kernel
+    # launches.  Every forward polls its own zero-copy header report and would repair an overflow in place (on_overflow='repair').
     sr = None
-    if use_abi:
+    if launch == 'abi':
         m3, sc, rot, op, col = [t.detach() for t in params]
         sr = exa.StaticRender(m3, op, sc, rot, colors_precomp=None if use_sh else col, shs=col if use_sh else None,
-                              image_size=(H, W), capacity=int(D_max) + 64, train=train)
-        for j, v in enumerate(vs):
-            st_j = GaussianRasterizationSettings(
-                image_height=H, image_width=W, tanfovx=v['tanfovx'], tanfovy=v['tanfovy'], bg=bg, scale_modifier=1.0,
-                viewmatrix=cam_tab[j, 0:16].view(4, 4), projmatrix=cam_tab[j, 16:32].view(4, 4), sh_degree=sh_degree,
-                campos=cam_tab[j, 32:35], prefiltered=False, debug=False)
+                              image_size=(H, W), capacity=int(D_max) + 64, train=train, slots=S,
+                              on_overflow=os.environ.get('EXA_BENCH_OVERFLOW', 'repair'))
+        for st_j in view_st:
             sr.add_view(st_j, dL_dcolor=dL_dimg if train else None)
         if train:
             for b in range(2 if reducer is not None else 1):
@@ -317,148 +290,120 @@ def main():
                 else:
                     sr.add_grad_outputs()
 
-    # ---- hipGraph capture of the raster step (the 'graph' protocol; under 'abi' only for the extras built on it) -------
-    want_graph = launch == 'graph' or (use_abi and world == 1 and not args.no_concurrent)
-    set_view(0, c0)
-    for _ in range(3):
-        raster_step(c0, 0)
-    torch.cuda.synchronize()
-    if want_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    raster_step(c0, 0)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            use_switch = cam_mode == 'graph' and KV == 1
-            for b, c in enumerate(ctxs):
-                c['graph'] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(c['graph']):
-                    if use_switch:
-                        select_view_in_graph(c)
-                    raster_step(c, b)
-                c['switch_in_graph'] = use_switch
-                c['graph'].replay()
-                torch.cuda.synchronize()
-            in_graph_switch['on'] = use_switch
-        except Exception as e:  # noqa: BLE001 -- fall back to eager launches, say so in the result
-            print('bench.py: hipGraph capture failed (%s); using eager launches' % e, file=sys.stderr)
-            for c in ctxs:
-                c['graph'] = None
-            if launch == 'graph':
-                launch = 'eager'
-
-    n_my = len(my_views)
-
-    def step_abi(i):
+    def step_abi(i, reduce=True):
         k = i & 1
-        if reducer is not None:
-            reducer.wait(k)                 # the all-reduce that last read this gradient buffer (two steps ago)
+        if reduce:
+            reducer_wait(k)
         sr.forward(i % n_my)
         if train:
             sr.backward(k if reducer is not None else 0)
-        if reducer is not None:
+        if reduce and reducer is not None:
             reducer.reduce(k)
 
-    def step_ctx(i):
-        k = i % n_ctx
-        c = ctxs[k]
-        if c['stream'] is not None:
-            with torch.cuda.stream(c['stream']):
-                set_view(i, c)
-                if c['graph'] is not None:
-                    c['graph'].replay()
-                else:
-                    raster_step(c)
-            return
-        if reducer is not None:
-            reducer.wait(k)                 # the all-reduce that last read this context's buffer (two steps ago)
-        set_view(i, c)
-        if c['graph'] is not None:
-            c['graph'].replay()
+    def step_abi_group(i, reduce=True):
+        """S views of the shard in flight; their gradients accumulated in slot order into ONE set (N > 1: one all-reduce)."""
+        k = i & 1
+        if reduce:
+            reducer_wait(k)
+        out = k if reducer is not None else 0
+        sr.begin()
+        for s in range(S):
+            sr.forward((i * S + s) % n_my, slot=s)
+            sr.backward(out, slot=s, accumulate=s > 0, after=s - 1 if s else None)
+        sr.end()
+        if reduce and reducer is not None:
+            reducer.reduce(k)
+
+    # ---- 'surface': the drop-in autograd surface call by call ----------------------------------------------------
+    # One GaussianRasterizer module per view (the reference builds one per render, module.py:623: ~10 us of nn.Module
+    # construction that this loop does not pay), its settings reading the camera in place; torch.autograd.grad as the backward.
+    rasts = [GaussianRasterizer(st_j) for st_j in view_st]
+    probe = torch.zeros(P, 3, device=device, requires_grad=train)
+    surf_in = params + [probe]
+    kw_col = dict(shs=params[4]) if use_sh else dict(colors_precomp=params[4])
+
+    def step_surface(i, reduce=True):
+        k = i & 1
+        if reduce:
+            reducer_wait(k)
+        if train:
+            color = rasts[i % n_my](means3D=params[0], means2D=probe, opacities=params[3], scales=params[1], rotations=params[2],
+                                    **kw_col)[0]
+            grads = torch.autograd.grad([color], surf_in, grad_outputs=[dL_dimg])
+            if reduce and reducer is not None:
+                reducer.pack(grads[:5], k)
+                reducer.reduce(k)
         else:
-            raster_step(c, k)
-        if reducer is not None:
-            reducer.reduce(k)
+            with torch.no_grad():
+                rasts[i % n_my](means3D=params[0], means2D=probe, opacities=params[3], scales=params[1], rotations=params[2], **kw_col)
 
-    step = step_abi if use_abi else step_ctx
+    step = step_surface if launch == 'surface' else step_abi_group if S > 1 else step_abi
+    units = S if (launch == 'abi' and S > 1) else 1          # views per step
 
     def finish():
         if reducer is not None:
             reducer.finish()
 
+    def timed(fn, n, w, settle_n=0):
+        """settle_n + w untimed steps, then n steps between synchronisations; seconds."""
+        for i in range(settle_n):
+            fn(i)
+        finish()
+        torch.cuda.synchronize()
+        for i in range(w):
+            fn(i)
+        finish()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t_0 = time.perf_counter()
+        for i in range(n):
+            fn(w + i)
+        finish()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t_0
+
     # Settle phase (setup, untimed, reported as config.settle_steps): the calibration above is a stop-and-go of 200 tiny
     # launches with a host read-back each, which leaves the GPU in a low power state; the first ~50 steps after it run
     # 4-7 % slower than the steady state that any training run is in.  The W warm-up steps asked for follow it.
     settle = int(os.environ.get('EXA_BENCH_SETTLE_STEPS', '300'))
-    seek_view(0)
-    for i in range(settle):
-        step(i)
-    finish()
-    torch.cuda.synchronize()
-    seek_view(0)
-    for i in range(args.warmup):
-        step(i)
-    finish()
+    wait_host[0] = 0.0
+    elapsed_local = timed(step, args.steps, args.warmup, settle)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    finish()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    # (the clock of the contract: barrier + synchronize on both sides of exactly K steps -- `timed` synchronises before it
+    #  starts its clock behind a barrier and stops it after finish() + synchronize; the closing barrier above is outside it,
+    #  the MAX over ranks below covers a rank that finished late)
+    t = torch.tensor([elapsed_local], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    wait_us = wait_host[0] / max(args.steps + args.warmup + settle, 1) * 1e6
+    if sr is not None:
+        sr.check()
 
+    # what the host spends per step (queueing only: steps issued back to back onto an idle device, clock stopped before the
+    # device is waited for; 'repair' polls every forward's report, i.e. includes waiting for the scatter stage of each render)
     host_us = None
-    if use_abi:
-        sr.check()                           # every render's header report: raises if any overflowed the instance buffer
-        # what the host spends per step (queueing only: 32 steps issued back to back onto an idle device, clock stopped before
-        # the device is waited for) -- the protocol holds as long as this stays under the device's step
+    if world == 1:
         torch.cuda.synchronize()
         th = time.perf_counter()
         for i in range(32):
             step(i)
         host_us = (time.perf_counter() - th) / 32 * 1e6
-        finish()
         torch.cuda.synchronize()
-        sr.check()
-    graph_replay = None
-    if use_abi and rank == 0 and world == 1 and ctxs and ctxs[0].get('graph') is not None:
-        try:
-            # the protocol of rounds 2-5 on the same box, same settle / warm-up / steps: the autograd surface replayed from a hipGraph
-            seek_view(0)
-            for i in range(settle):
-                step_ctx(i)
-            torch.cuda.synchronize()
-            seek_view(0)
-            for i in range(args.warmup):
-                step_ctx(i)
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for i in range(args.steps):
-                step_ctx(args.warmup + i)
-            torch.cuda.synchronize()
-            tg = time.perf_counter() - tg
-            graph_replay = {'value': args.steps / tg, 'unit': 'iters/s', 'ms_per_step': tg / args.steps * 1e3,
-                            'what': 'the same step issued as rounds 2-5 issued it: the autograd surface (GaussianRasterizer + '
-                                    'autograd.grad) captured once and replayed from a hipGraph whose first node copies the next '
-                                    'view\'s camera block out of the resident table (exa_raster_select_row); ~4 us between two '
-                                    'launches of the graph + 4.6 us for that node are what the plain launches of the headline do not pay'}
-        except Exception as e:  # noqa: BLE001 -- an extra must never take the headline down
-            graph_replay = {'error': str(e)[:200]}
 
-    # every rank reports what ITS communicator says (world size, its device): the driver's SCALE line can be checked against it
+    # N > 1: the same steps WITHOUT the exchange, per rank -- what the all-reduce costs this rank's step when it is not hidden
+    local_ms = None
+    if world > 1 and train:
+        local_ms = timed(lambda i: step(i, reduce=False), max(args.steps // 2, 4), 2) / max(args.steps // 2, 4) * 1e3
+        dist.barrier()
+
+    # every rank reports what ITS communicator says and what ITS steps took: a SCALE line that disappoints can be read against it
     rank_info = {'rank': rank, 'world_size': dist.get_world_size() if world > 1 else 1, 'device': torch.cuda.current_device(),
-                 'device_name': torch.cuda.get_device_name(device), 'views': len(my_views)}
+                 'device_name': torch.cuda.get_device_name(device), 'views': n_my,
+                 'step_ms': elapsed_local / args.steps * 1e3, 'step_ms_without_allreduce': local_ms,
+                 'allreduce_wait_host_us_per_step': wait_us if world > 1 else None}
     ranks = [rank_info]
     if world > 1:
         ranks = [None] * world
@@ -466,7 +411,7 @@ def main():
     result = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps * KV / elapsed
+        value = world * args.steps * units / elapsed
         if not train:
             metric = 'forward renders/sec at %dx%d / %dk Gaussians%s' % (W, H, P // 1000, ', SH deg 3 (BASELINE configs[4])' if use_sh else '')
         elif args.config == 'c3':
@@ -484,75 +429,48 @@ def main():
                        'parity_bar': 'image 1e-4 L-inf off the <= 0.04 % threshold-adjacent (ambiguous) pixels, which may be off by '
                                      '2e-2; grads 1e-3 rel, 1e-1 * mean floor for Gaussians under an ambiguous pixel (tests/helpers.py)',
                        'P': P, 'W': W, 'H': H, 'mode': 'fwd+bwd' if train else 'forward only (no_grad)',
-                       'views_per_rank': len(my_views), 'launch': launch, 'settle_steps': settle, 'host_us_per_step': host_us,
+                       'views_per_rank': n_my, 'launch': launch, 'settle_steps': settle, 'host_us_per_step': host_us,
                        'launch_what': {'abi': 'plain kernel launches straight through the C ABI: exa_raster_forward_batch + '
                                               'exa_raster_backward_batch on pre-marshalled jobs and static buffers '
-                                              '(exavatar_release_amd.StaticRender), two ctypes calls = seven launches per step, the '
-                                              'host ~30 us per step ahead of a ~145 us device step; every render\'s overflow report '
-                                              'checked after the timed region',
-                                       'graph': 'the autograd surface captured once and replayed from a hipGraph',
-                                       'eager': 'the autograd surface call by call (host-bound)'}[launch],
-                       'view_switch': 'per step, inside the timed region: every view\'s pre-marshalled job reads its camera block (48 floats) '
-                                      'IN PLACE from the resident table of ring views (no copy)' if use_abi else
-                                      'per step, inside the timed region: the next view\'s camera block (48 floats) copied from the '
-                                      'resident table of ring views into the graph\'s static tensor by ' +
-                                      ('the first node of the replayed graph (exa_raster_select_row + a device-side counter; '
-                                       'EXA_BENCH_CAM_COPY=kernel: an eager elementwise kernel in front of every replay, the '
-                                       'protocol until late round 4, 0.5 % slower; =memcpy: the runtime\'s blit, rounds 1-3)'
-                                       if in_graph_switch['on'] else
-                                       'the runtime\'s blit (EXA_BENCH_CAM_COPY=memcpy)' if cam_mode == 'memcpy' else
-                                       'one eager elementwise kernel in front of every replay (EXA_BENCH_CAM_COPY=kernel)'),
-                       'views_in_flight_per_gpu': S, 'views_per_launch': KV,
-                       'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads (dist.FlatGradAllReducer)'
-                                      % (world, n_float * 4),
+                                              '(exavatar_release_amd.StaticRender), two ctypes calls = eight kernels per step '
+                                              '(forward: preprocess_fwd, cell_scatter, subtile_count, subtile_bin, sort_subtiles, '
+                                              'render_fwd; backward: render_bwd, preprocess_bwd); every forward polls its own '
+                                              'overflow report inside the timed region and would re-render in place (on_overflow=%s; '
+                                              'repairs during this run: %d)' % (sr.on_overflow if sr else '-', sr.repairs if sr else 0),
+                                       'surface': 'the drop-in autograd surface call by call: GaussianRasterizer(settings)(...) + '
+                                                  'torch.autograd.grad through the compiled autograd node (csrc/torch_binding.cpp); one '
+                                                  'module per view, built once'}[launch],
+                       'view_switch': 'per step, inside the timed region: every view\'s settings read its camera block (48 floats) IN PLACE '
+                                      'from the resident table of ring views (no copy)',
+                       'views_in_flight_per_gpu': S, 'views_per_step': units,
+                       'parallelism': 'view-sharded dp%d, RCCL all-reduce of %d B grads (dist.FlatGradAllReducer)%s'
+                                      % (world, n_float * 4, ', one per group of %d views accumulated in slot order' % S if S > 1 else ''),
                        'mean_instances_D': D_mean, 'mean_subtile_instances': I_mean, 'mean_visible_V': V_mean},
             'rccl': {'world_size': dist.get_world_size() if world > 1 else 1,
                      'backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if world > 1 else None,
                      'ranks': ranks},
         }
 
-    if rank == 0 and graph_replay is not None:
-        result['extra_graph_replay'] = graph_replay
-    single = S == 1 and KV == 1 and world == 1
-    # ---- extras (not the headline): K views per batched launch; independent views on separate streams -------
-    if rank == 0 and single and launch in ('graph', 'abi') and ctxs[0].get('graph') is not None and not args.no_concurrent \
-            and args.config != 'c1':
+    single = S == 1 and world == 1
+    # ---- the drop-in autograd surface next to the headline: ALWAYS (rank 0, its own shard, no exchange) -----------------
+    if rank == 0 and train and launch == 'abi':
+        try:
+            result['extra_plugin_surface_eager'] = surface_throughput(step_surface, args, exa)
+        except Exception as e:  # noqa: BLE001 -- an extra must never take the headline down
+            result['extra_plugin_surface_eager'] = {'error': str(e)[:200]}
+
+    # ---- extras (not the headline): views in flight through the C ABI; K views per batched launch -------
+    if rank == 0 and single and launch == 'abi' and train and not args.no_concurrent and args.config != 'c1':
+        try:
+            result['extra_abi_views_in_flight'] = abi_views_in_flight(4, args, exa, params, use_sh, shape, D_max, view_st, dL_dimg)
+        except Exception as e:  # noqa: BLE001
+            result['extra_abi_views_in_flight'] = {'error': str(e)[:200]}
         for name, fn in (('extra_batched_views', lambda: batched_throughput(8, 1, args, make_ctx, set_view, raster_step)),
-                         ('extra_batched_views_x2', lambda: batched_throughput(8, 2, args, make_ctx, set_view, raster_step)),
-                         ('extra_views_in_flight', lambda: concurrent_throughput(4, args, make_ctx, set_view, raster_step))):
+                         ('extra_batched_views_x2', lambda: batched_throughput(8, 2, args, make_ctx, set_view, raster_step))):
             try:
                 result[name] = fn()
             except Exception as e:  # noqa: BLE001
                 result[name] = {'error': str(e)[:200]}
-        # what the gap BETWEEN two graph launches costs the headline (rocprofv3 kernel trace: ~8 us from the last kernel of one
-        # replay to the first of the next, of a 151 us step): the same step, four to a recorded graph
-        if in_graph_switch['on'] and train:
-            try:
-                U = 4
-                c4 = make_ctx(1)
-                g4 = torch.cuda.CUDAGraph()
-                set_view(0, c4)
-                raster_step(c4, 0)
-                torch.cuda.synchronize()
-                with torch.cuda.graph(g4):
-                    for _ in range(U):
-                        select_view_in_graph(c4)
-                        raster_step(c4, 0)
-                n_rep = max(args.steps // U, 8)
-                for _ in range(8):
-                    g4.replay()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n_rep):
-                    g4.replay()
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                result['extra_steps_per_replay'] = {
-                    'steps_per_replay': U, 'value': n_rep * U / dt, 'unit': 'iters/s', 'ms_per_step': dt / (n_rep * U) * 1e3,
-                    'what': 'the headline step, %d of them (consecutive views) recorded into ONE hipGraph: what is left when the '
-                            'gap between two graph launches is paid once per %d steps; NOT the headline protocol' % (U, U)}
-            except Exception as e:  # noqa: BLE001
-                result['extra_steps_per_replay'] = {'error': str(e)[:200]}
 
     # ---- extra: one ExAvatar training sample = five same-camera renders fwd + bwd (model.py:119-167), eager ----
     if rank == 0 and single and not args.no_concurrent and args.config == 'c3' and train:
@@ -579,14 +497,14 @@ def main():
         from exavatar_release_amd import rasterizer as rz_, stats as exa_stats
         work = []
         exa.config.keep_debug = train and not use_sh
-        n_t = min(len(my_views), 20)
+        n_t = min(n_my, 20)
         for i in range(n_t + 2):
             set_view(i, c1)
             # two steps back to back, the second one is read: its launches are queued behind running work, so the
             # event brackets hold the kernels and not the ~5 us a launch needs to reach an idle GPU (agrees with the
             # rocprofv3 --kernel-trace durations of the bench command's step, profiles/)
-            raster_step(c1, 0)
-            raster_step(c1, 0)
+            raster_step(c1)
+            raster_step(c1)
             torch.cuda.synchronize()
             tm = _lib.timing_read()
             if i >= 2:
@@ -608,34 +526,43 @@ def main():
             'subtile_bin': 16 * V + 8 * D,
             'sort_subtiles': 12 * D,
             'render_fwd': 4 * D + 40 * V + 28 * WH,
-            'render_bwd': 4 * D + 80 * V + 28 * WH,
+            # B1 of SURVEY.md 8(d) prices 28 B/px of image reads; 8 of them are dL/ddepth + dL/dalpha, which THIS workload (the
+            # ExAvatar training case: both null) never reads -- they are left out, the line says so in `byte_model`
+            'render_bwd': 4 * D + 80 * V + 20 * WH,
             'preprocess_bwd': 40 * V + 44 * V + 68 * P,
         }
         dom = max((k for k in avg_us if k in alg and alg[k] > 0), key=lambda k: avg_us[k])
         achieved = alg[dom] / (avg_us[dom] * 1e-6) / 1e9
         fwd_bytes = 60 * P + 88 * V + 40 * D + 28 * WH + sh_bytes
-        total_bytes = (128 * P + 252 * V + 44 * D + 56 * WH) if train else fwd_bytes
+        total_bytes = (128 * P + 252 * V + 44 * D + 48 * WH) if train else fwd_bytes
         result['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS,
+            'frac_with_survey_B1_bytes': ((alg[dom] + (8 * WH if dom == 'render_bwd' else 0)) / (avg_us[dom] * 1e-6) / 1e9 / HBM_PEAK_GBS),
             'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_us': avg_us[dom],
             'clock': 'HIP events around eager launches of the kernel, this run (2nd of two back-to-back steps, stratified views); '
                      'the rocprofv3 --kernel-trace average of the same kernel inside the bench command\'s step is in profiles/ (1-3 us lower)',
-            'byte_model': 'SURVEY.md 8(d) with the run\'s own P, V and D = 16x16 tile instances (header.num_tile_instances)',
+            'byte_model': 'SURVEY.md 8(d) with the run\'s own P, V and D = 16x16 tile instances (header.num_tile_instances); the '
+                          'backward blend is priced WITHOUT the 8 B/px of dL/ddepth + dL/dalpha reads of B1 (null in this workload, as '
+                          'in ExAvatar training: the kernel instantiation that runs never reads them), i.e. 20 instead of 28 B/px',
             'kernel_avg_us': avg_us,
             'step': {'algorithmic_bytes': total_bytes, 'gpu_us_sum_of_kernels': sum(avg_us.values()),
-                     'achieved_GBs_at_measured_step': total_bytes * KV / (ms_per_step * 1e-3) / 1e9,
-                     'frac_at_measured_step': total_bytes * KV / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     'achieved_GBs_at_measured_step': total_bytes * units / (ms_per_step * 1e-3) / 1e9,
+                     'frac_at_measured_step': total_bytes * units / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        tr, src = pmc_traffic(dom) if args.config == 'c3' and train else (None, None)
+        digest = lib_digest()
+        tr, src = pmc_traffic(dom, digest) if args.config == 'c3' and train else (None, None)
         result['roofline']['traffic'] = tr
         result['roofline']['traffic_source'] = src
-        rp = rocprof_time(dom) if args.config == 'c3' and train else None
-        if rp is not None:      # the committed rocprofv3 average of the same kernel (kernel begin -> end, no launch gap in the bracket)
+        result['roofline']['library_digest'] = digest
+        rp = rocprof_time(dom, digest) if args.config == 'c3' and train else None
+        if rp is not None and rp[0] is not None:      # the committed rocprofv3 average of the same kernel (kernel begin -> end, no launch gap in the bracket)
             result['roofline']['rocprof'] = {'avg_launch_us': rp[0], 'frac': alg[dom] / (rp[0] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                              'source': rp[1]}
+        elif rp is not None:
+            result['roofline']['rocprof'] = {'avg_launch_us': None, 'source': rp[1]}
         if work:
-            result['roofline']['secondary'] = valu_roofline(work, avg_us)
+            result['roofline']['secondary'] = valu_roofline(work, avg_us, digest)
             n_w = len(work)
             result['config']['list_length_histogram'] = {
                 'what': 'non-empty 8x8-pixel sub-tile lists by length, mean over the %d measured views; bins start at' % n_w,
@@ -650,12 +577,11 @@ def main():
                                           'ms_per_launch': eb['ms_per_launch'], 'achieved_GBs': gbs,
                                           'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm'}
 
-    # ---- other BASELINE configs as driver-visible lines: C5 (configs[4], forward only, hipGraph) and C2 ----------
+    # ---- other BASELINE configs as driver-visible lines: C5 (configs[4], forward only) and C2 ----------
     if rank == 0 and single and not args.no_concurrent and args.config == 'c3' and train and not args.no_other_configs:
-        # free this process's graphs / workspaces first: the child runs on the same GPU
-        for c in ctxs:
-            c['graph'] = None
-        ctxs.clear()
+        # free this process's workspaces first: the child runs on the same GPU
+        if sr is not None:
+            sr.close()
         torch.cuda.empty_cache()
         result['extra_c5_forward'] = other_config('c5', args)
         result['extra_c2'] = other_config('c2', args)
@@ -678,6 +604,97 @@ def main():
         dist.destroy_process_group()
 
 
+def surface_throughput(step_surface, args, exa):
+    """The drop-in autograd surface -- GaussianRasterizer(settings)(...) + torch.autograd.grad, what the reference calls at
+    avatar/common/nets/module.py:632-640 and differentiates from avatar/main/train.py:46 -- on the headline's workload and views,
+    call by call, three ways: through the compiled autograd node (the default), the same with PyTorch's autograd engine told
+    to run the backward on the calling thread (torch.autograd.set_multithreading_enabled(False): no hand-over to the device
+    thread and back, ~40 us of host time per step), and through the Python node it replaces."""
+    n, w = args.steps, max(args.warmup, 10)
+
+    from exavatar_release_amd import rasterizer as rz_
+
+    def run(label):
+        for i in range(w + 50):
+            step_surface(i, reduce=False)
+        torch.cuda.synchronize()
+        c_0 = rz_.compiled_calls
+        t_0 = time.perf_counter()
+        for i in range(n):
+            step_surface(w + i, reduce=False)
+        t_host = time.perf_counter() - t_0           # the Python thread is done queueing; the GPU may still be busy
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t_0) / n
+        return {'value': 1.0 / dt, 'unit': 'iters/s', 'ms_per_step': dt * 1e3, 'host_ms_per_step': t_host / n * 1e3,
+                'renders_through_the_compiled_node': rz_.compiled_calls - c_0, 'what': label}
+    saved = exa.config.compiled_node
+    try:
+        res = run('GaussianRasterizer + torch.autograd.grad per step, eager, compiled autograd node (exavatar_release_amd/_exa_torch)')
+        with torch.autograd.set_multithreading_enabled(False):
+            res['autograd_multithreading_off'] = run('the same with torch.autograd.set_multithreading_enabled(False): backward on the calling thread')
+        exa.config.compiled_node = 'off'
+        res['python_node'] = run('the same through the Python autograd node (config.compiled_node = "off"): the surface of rounds 1-5')
+    finally:
+        exa.config.compiled_node = saved
+    res['compiled_node_in_use'] = bool(rz_._compiled)
+    return res
+
+
+def abi_views_in_flight(S, args, exa, params, use_sh, shape, D_max, view_st, dL_dimg):
+    """S views of the shard in flight through the C ABI: a StaticRender with S render slots (own workspaces, images and HIP
+    stream each, shared inputs, plain launches), views dealt round-robin, every view's gradients into its slot's own arrays --
+    the independent-steps form (what the headline counts, S at a time) -- and, second, the grouped form a trainer with a
+    batch of S views uses: the S gradients ACCUMULATED in slot order into one set (chained per-Gaussian kernels)."""
+    H, W = shape
+    m3, sc, rot, op, col = [t.detach() for t in params]
+    n_v = len(view_st)
+    with exa.StaticRender(m3, op, sc, rot, colors_precomp=None if use_sh else col, shs=col if use_sh else None, image_size=(H, W),
+                          capacity=int(D_max) + 64, slots=S) as sr:
+        for st_j in view_st:
+            sr.add_view(st_j, dL_dcolor=dL_dimg)
+        sets = [sr.add_grad_outputs() for _ in range(S)]
+
+        def independent(i):
+            s = i % S
+            sr.forward(i % n_v, slot=s)
+            sr.backward(sets[s], slot=s)
+
+        def grouped(i):
+            sr.begin()
+            for s in range(S):
+                sr.forward((i * S + s) % n_v, slot=s)
+                sr.backward(sets[0], slot=s, accumulate=s > 0, after=s - 1 if s else None)
+            sr.end()
+        out = {'views_in_flight': S}
+        for name, fn, per in (('independent', independent, 1), ('grouped', grouped, S)):
+            n = max(args.steps // per, 8) if per > 1 else max(args.steps, 8 * S)
+            for i in range(40 * S // per):
+                fn(i)
+            sr.check()
+            t_0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            sr.check()
+            dt = time.perf_counter() - t_0
+            out[name] = {'value': n * per / dt, 'unit': 'iters/s', 'ms_per_view': dt / (n * per) * 1e3}
+        out['value'], out['unit'] = out['independent']['value'], 'iters/s'
+        out['repairs'] = sr.repairs
+        out['what'] = ('exa.StaticRender(slots=%d): plain launches through the C ABI on %d HIP streams; independent = every view fwd + bwd '
+                       'into its slot\'s own gradient arrays; grouped = groups of %d views whose gradients are accumulated in slot order '
+                       'into one set (backward(accumulate=True, after=previous slot))' % (S, S, S))
+        return out
+
+
+def lib_digest():
+    """Digest of the sources the loaded library was built from (exavatar_release_amd.build._digest: csrc + header + flags) --
+    committed profile summaries carry the digest of the build they measured."""
+    try:
+        from exavatar_release_amd import build as b
+        return b._digest()[:16]
+    except Exception:  # noqa: BLE001
+        return None
+
+
 # Issue cost of one wave64 instruction on one SIMD, MEASURED on MI355X with tools/probe/valu_probe.hip at 8 waves per SIMD
 # (profiles/r05_valu_probe.txt): v_fma_f32 1.07 ns, v_exp_f32 3.51 ns (v_rcp_f32: the same pipe); a packed v_pk_fma_f32 costs
 # 2.17 ns = two plain ones (two results per lane: no extra throughput), a v_cmp + v_cndmask pair ~3.6 ns.
@@ -687,7 +704,7 @@ N_SIMD = 1024
 VALU_NS, TRANS_NS = 1.07, 3.51
 
 
-def valu_roofline(work, avg_us):
+def valu_roofline(work, avg_us, digest=None):
     """SURVEY.md 8(d) secondary bound: "fp32 vector + v_exp_f32 throughput for the pixel-Gaussian evaluations per pass" --
     the one that binds the two blends (profiles/*_pmc.md: VALU-issue bound, a sixth of the HBM roofline).  Per kernel: the
     pixel-Gaussian pairs it evaluated in the measured views (from the workspaces), the VALU and transcendental
@@ -697,7 +714,7 @@ def valu_roofline(work, avg_us):
     n = len(work)
     pairs = {'render_fwd': sum(w['fwd_pairs'] for w in work) / n, 'render_bwd': sum(w['bwd_pairs'] for w in work) / n}
     trans_per_pair = {'render_fwd': 1, 'render_bwd': 2}
-    pmc, src = pmc_counters()
+    pmc, src = pmc_counters(digest)
     out = {'bound': 'valu', 'unit': 'G wave-instructions/s',
            'peak': N_SIMD / VALU_NS,
            'peak_what': '%d SIMDs / %.2f ns per wave64 fp32 instruction (v_exp_f32 / v_rcp_f32: %.2f ns), measured: '
@@ -731,51 +748,64 @@ def valu_roofline(work, avg_us):
     return out
 
 
-def pmc_counters():
-    """(per-kernel SQ counters of the committed PMC pass of the newest round that has one, source) -- builder-side
-    rocprofv3 --pmc passes of the same C3 workload, NOT collected in this run; ({}, None) if unavailable."""
+def _profile(suffix, digest):
+    """(parsed profiles/<newest round>_<suffix>.json, its file name) if it was measured on THIS build -- the summary carries
+    the digest of the library sources it was taken with (tools/make_profiles.py) and it must equal the loaded library's --
+    else (None, why not).  A number measured on another build is not evidence for this one: the line then carries null."""
     here = os.path.dirname(os.path.abspath(__file__))
     for prefix in PROFILE_PREFIXES:
+        name = prefix + '_' + suffix + '.json'
+        path = os.path.join(here, 'profiles', name)
+        if not os.path.exists(path):
+            continue
         try:
-            name = prefix + '_pmc.json'
-            with open(os.path.join(here, 'profiles', name)) as f:
+            with open(path) as f:
                 d = json.load(f)
-            return d['kernels'], 'profiles/%s (%s; not collected in this run)' % (name, d.get('what', ''))
-        except Exception:  # noqa: BLE001
-            pass
-    return {}, None
+        except Exception as e:  # noqa: BLE001
+            return None, 'profiles/%s is unreadable (%s)' % (name, e)
+        have = d.get('library_digest')
+        if digest is None or have != digest:
+            return None, ('profiles/%s was measured on library build %s, the loaded library is %s: not quoted'
+                          % (name, have or '(unstamped)', digest))
+        return d, name
+    return None, 'no profiles/*_%s.json' % suffix
 
 
-def pmc_traffic(kernel):
+def pmc_counters(digest=None):
+    """(per-kernel SQ counters of the committed PMC pass, source) -- builder-side rocprofv3 --pmc passes of the same C3
+    workload ON THE SAME BUILD, not collected in this run; ({}, reason) otherwise."""
+    d, name = _profile('pmc', digest)
+    if d is None:
+        return {}, name
+    return d['kernels'], 'profiles/%s (%s; build %s = the loaded library; not collected in this run)' % (name, d.get('what', ''), digest)
+
+
+def pmc_traffic(kernel, digest=None):
     """(HBM bytes per launch of `kernel`, where the number comes from).  NOT measured in this run: read from the committed
     PMC passes (profiles/<round>_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs
-    of the same C3 workload by the builder); (None, None) if not available."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    for prefix in PROFILE_PREFIXES:
-        try:
-            name = prefix + '_hbm_traffic.json'
-            with open(os.path.join(here, 'profiles', name)) as f:
-                d = json.load(f)
-            return float(d['kernels'][kernel]['hbm_bytes']), \
-                'profiles/%s (builder-side rocprofv3 --pmc passes, %s; not collected in this run)' % (name, d.get('what', 'C3 view 0, exact mode'))
-        except Exception:  # noqa: BLE001
-            pass
-    return None, None
+    of the same C3 workload on the same build); (None, reason) otherwise."""
+    d, name = _profile('hbm_traffic', digest)
+    if d is None:
+        return None, name
+    try:
+        return float(d['kernels'][kernel]['hbm_bytes']), \
+            'profiles/%s (builder-side rocprofv3 --pmc passes, %s; build %s = the loaded library; not collected in this run)' % (
+                name, d.get('what', 'C3 view 0, exact mode'), digest)
+    except Exception as e:  # noqa: BLE001
+        return None, 'profiles/%s: %s' % (name, e)
 
 
-def rocprof_time(kernel):
-    """(average duration in us of `kernel` by rocprofv3 --kernel-trace --stats, source) from the committed profile of the
-    newest round that has one (builder-side, NOT measured in this run); None if unavailable."""
-    here = os.path.dirname(os.path.abspath(__file__))
-    for prefix in PROFILE_PREFIXES:
-        try:
-            name = prefix + '_kernel_stats.json'
-            with open(os.path.join(here, 'profiles', name)) as f:
-                d = json.load(f)
-            return float(d['kernels'][kernel]['avg_us']), 'profiles/%s (%s; not collected in this run)' % (name, d['what'])
-        except Exception:  # noqa: BLE001
-            pass
-    return None
+def rocprof_time(kernel, digest=None):
+    """(average duration in us of `kernel` by rocprofv3 --kernel-trace --stats, source) from the committed profile of the same
+    build (builder-side, NOT measured in this run); (None, reason) otherwise."""
+    d, name = _profile('kernel_stats', digest)
+    if d is None:
+        return None, name
+    try:
+        return float(d['kernels'][kernel]['avg_us']), 'profiles/%s (%s; build %s = the loaded library; not collected in this run)' % (
+            name, d['what'], digest)
+    except Exception as e:  # noqa: BLE001
+        return None, 'profiles/%s: %s' % (name, e)
 
 
 def other_config(cfg, args):
