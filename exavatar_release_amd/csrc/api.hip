@@ -101,7 +101,7 @@ int exa_raster_workspace_sizes(int32_t P, int32_t W, int32_t H, uint64_t capacit
     out->geom_bytes = align256(uint64_t(P) * sizeof(Splat));
     out->tile_bytes = tile_ws_bytes(g.cells, num_chunks(P));
     out->bin_bytes = bin_ws_bytes(capacity);
-    out->grad_bytes = grad_ws_bytes(capacity);
+    out->grad_bytes = grad_ws_bytes(capacity) + group_scratch_bytes((uint64_t)P);
     return 0;
 }
 
@@ -283,6 +283,8 @@ int backward_group(const ExaRasterBackwardJob* jobs, int K, int sum_shared, int 
         b.dL_dsh = j.dL_dsh; b.dL_dcov3D = j.dL_dcov3D;
         b.dens_accum = j.densify_grad_accum; b.dens_cnt = j.densify_track_cnt; b.dens_rmax = j.densify_radius_max;
         b.accumulate = j.accumulate;
+        // (a composite's grad workspace holds its partial records only: composites are never summed over views)
+        b.group_scratch = j.compose_geom_a ? nullptr : reinterpret_cast<float*>(static_cast<char*>(j.grad_ws) + grad_ws_bytes(j.capacity));
         b.grad_first = j.grad_first;            // (composite: 0 -- every Gaussian of B is trainable; partials / touched / header are the composite's)
         ++n;
     }

@@ -243,6 +243,9 @@ __host__ __device__ inline uint32_t cell_slots(uint32_t inst) {
 
 // backward scratch: one partial record per instance.
 __host__ __device__ inline uint64_t grad_ws_bytes(uint64_t cap) { return align256(cap * PARTIAL_BYTES); }
+// ... plus, behind them, the group scratch of a summed batch (preprocess_bwd.hip): 20 gradient floats + 3 statistics per Gaussian
+constexpr int GROUP_SCRATCH_FLOATS = 23;
+__host__ __device__ inline uint64_t group_scratch_bytes(uint64_t P) { return align256(P * GROUP_SCRATCH_FLOATS * sizeof(float)); }
 __host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t) {
     PartialWs w;
     w.rec = reinterpret_cast<float4*>(base);
@@ -436,6 +439,8 @@ struct PreprocessBwdArgs {
     float* dens_accum; float* dens_cnt; float* dens_rmax;       // optional fused densification statistics (per view)
     int grad_first;        // Gaussians below this index are constants: no work, no output rows (output row = idx - grad_first)
     int accumulate;        // != 0: the per-Gaussian outputs (all but dL_dmeans2D) hold values this call adds to
+    float* group_scratch;  // GROUP_SCRATCH_FLOATS x P floats behind this job's partial records (grad workspace): where the second
+    //                        workgroup row of a summed batch of more than four views leaves its sum (preprocess_bwd.hip)
 };
 // sum_shared != 0: the K jobs are K views of the SAME Gaussians (identical input pointers and P): one thread
 // per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).

@@ -19,10 +19,14 @@ namespace exa {
 // One thread per (job, Gaussian).  SUM = false: gridDim.y jobs, thread = (job blockIdx.y, Gaussian idx).
 // SUM = true: the K jobs are K views of the SAME Gaussians and job 0's outputs receive the summed gradient
 // (dL_dmeans2D stays per view: the densification statistics need per-view norms, reference
-// avatar/common/nets/module.py:155-157).  VW = 4: the four waves of a workgroup share 64 Gaussians and split the
-// views (wave w takes views w, w + 4), then add their sums through LDS -- a thread that walked all K views alone
-// paid 3 K dependent memory round trips.  VW = 1 (the SH path, whose 48-float dL_dsh rows are accumulated in
-// global memory by their single owner): one thread walks all views.  SH = false compiles the SH backward out (the
+// avatar/common/nets/module.py:155-157).  VW = 4 ("views over waves"): a workgroup of vw = min(K, 4) waves shares 64
+// Gaussians, every wave takes ONE view (no loop: wave w of workgroup row g = blockIdx.y takes view g * vw + w) and the
+// waves add their results through LDS (the staging area of the gather, dead by then).  K > 4: the second row of
+// workgroups writes ITS sum into a scratch behind the partial records of its first view (PreprocessBwdArgs.group_scratch)
+// and `sum_groups_kernel` adds it to the outputs.  Until round 6 the four waves of a 256-thread workgroup LOOPED over the
+// views (w, w + 4): K = 2 left half of every workgroup idle while it held 74 KB of LDS, 64-66 us against 2 x 19 us for
+// two single-view launches; now K views cost what K single launches cost, in one.  VW = 1 (the SH path, whose 48-float
+// dL_dsh rows are accumulated in global memory by their single owner): one thread walks all views.  SH = false compiles the SH backward out (the
 // colours-precomp path of ExAvatar's renderer, module.py:632-640): fewer registers, more waves per SIMD.
 // PREFIX = true: the job may have a constant prefix (grad_first > 0); its own instantiation so that the plain kernels
 // carry none of it.
@@ -178,14 +182,24 @@ __device__ __forceinline__ Cov2DGrad cov2d_conic_grad(float S00, float S01, floa
     return r;
 }
 
+template <int N> struct StaticGather {
+    __device__ static __forceinline__ GatherLds* get() { __shared__ GatherLds g[N]; return g; }
+};
+template <> struct StaticGather<0> {
+    __device__ static __forceinline__ GatherLds* get() { return nullptr; }
+};
+
 // (two waves per SIMD at least: the SUM kernels sit at the 256-register line, and one wave per SIMD costs the K = 8 batches 5-10 %)
 template <bool SUM, int VW, bool SH, bool PREFIX>
 __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<PreprocessBwdArgs> batch, int K, int dens_shared) {
     static_assert(VW == 1 || (SUM && VW == BLOCK / 64), "views are split over the waves of a workgroup in SUM mode only");
-    __shared__ float s_red[VW > 1 ? 23 * BLOCK : 1];
-    __shared__ GatherLds s_gather[BLOCK / 64];
+    // VW == 1: one staging area per wave of the 256-thread workgroup, static.  VW > 1: the workgroup has vw = blockDim.x / 64
+    // waves and as many staging areas, dynamic (K = 2 holds 26 KB instead of 51: four workgroups per CU by registers and LDS)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    GatherLds* const s_gather = VW > 1 ? reinterpret_cast<GatherLds*>(s_dyn) : StaticGather<(VW > 1 ? 0 : BLOCK / 64)>::get();
     const PreprocessBwdArgs& out = batch.v[SUM ? 0 : blockIdx.y];
-    constexpr int GPB = BLOCK / VW;                             // Gaussians per workgroup
+    const int vw = VW > 1 ? (int)(blockDim.x >> 6) : 1;         // views per workgroup row (VW > 1)
+    const int GPB = VW > 1 ? 64 : BLOCK;                        // Gaussians per workgroup
     if ((int)(blockIdx.x * GPB) >= out.P) return;               // workgroup-uniform
     // constant prefix (ExaRasterBackwardJob.grad_first): Gaussians below gf are inputs only -- no chain rule, no output
     // row (row = idx - gf).  A workgroup of constants leaves at once; in the boundary workgroup they stay in the wave
@@ -225,8 +239,12 @@ __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<Preproce
     //                                                             (or another render's: ExaRasterBackwardJob.accumulate)
     float dn_acc = 0.f, dn_cnt = 0.f, dn_rmax = 0.f;            // dens_shared: this thread's share of the K views' statistics
 
-    const int n_views = SUM ? K : 1;
-    for (int view = VW == 1 ? 0 : wave; view < n_views; view += VW) {
+    // VW == 1: this thread walks views 0 .. K - 1 (SUM) or its own job; VW > 1: this wave's ONE view (none past K)
+    const int view_first = VW > 1 ? (int)blockIdx.y * vw + wave : 0;
+    const int view_last = VW > 1 ? min(K, view_first + 1) : (SUM ? K : 1);
+    // (VW > 1: at most ONE trip, spelled so that the compiler sees it -- the sums below then are this view's values, not
+    //  loop-carried accumulators: 198 -> ~120 VGPRs, three waves per SIMD instead of two)
+    for (int view = view_first, trip = 0; view < view_last && (VW == 1 || trip == 0); ++view, ++trip) {
         const PreprocessBwdArgs& a = batch.v[SUM ? view : blockIdx.y];
         const float* __restrict__ v = a.viewmatrix;
         const float* __restrict__ p = a.projmatrix;
@@ -504,21 +522,29 @@ __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<Preproce
         for (int i = 0; i < 6; ++i) dcov[i] += vcov[i];
         dop += vop;
     }
-    if (VW > 1) {                                               // add the view subsets of the four waves
+    // where this workgroup row's sum goes: row 0 writes the outputs, a further row (views 4 ..) a scratch that sum_groups_kernel adds
+    float* o_mean = out.dL_dmeans3D; float* o_op = out.dL_dopacity; float* o_col = out.dL_dcolors; float* o_scale = out.dL_dscales;
+    float* o_q = out.dL_drotations; float* o_cov = out.dL_dcov3D;
+    float* o_dens = nullptr;                                    // (scratch rows only: acc, cnt, rmax of this row's views)
+    if (VW > 1) {                                               // add the views of the workgroup's waves
+        wave_lds_fence();
+        __syncthreads();                                        // every wave is done with its staging area: reuse it
+        float* s_red = reinterpret_cast<float*>(s_dyn);
+        const int B = vw * 64;
         float* r = s_red + threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { r[i * BLOCK] = dmean[i]; r[(3 + i) * BLOCK] = dscale[i]; r[(17 + i) * BLOCK] = dcol[i]; }
+        for (int i = 0; i < 3; ++i) { r[i * B] = dmean[i]; r[(3 + i) * B] = dscale[i]; r[(17 + i) * B] = dcol[i]; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[(6 + i) * BLOCK] = dq[i];
+        for (int i = 0; i < 4; ++i) r[(6 + i) * B] = dq[i];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) r[(10 + i) * BLOCK] = dcov[i];
-        r[16 * BLOCK] = dop;
-        r[20 * BLOCK] = dn_acc; r[21 * BLOCK] = dn_cnt; r[22 * BLOCK] = dn_rmax;
+        for (int i = 0; i < 6; ++i) r[(10 + i) * B] = dcov[i];
+        r[16 * B] = dop;
+        r[20 * B] = dn_acc; r[21 * B] = dn_cnt; r[22 * B] = dn_rmax;
         __syncthreads();
         if (wave != 0) return;
-        auto total = [&](int f) {
-            const float* q = s_red + f * BLOCK + lane;
-            return (q[0] + q[64]) + (q[128] + q[192]);
+        auto total = [&](int f) {                               // (the association of the four-wave workgroup of rounds 2-5)
+            const float* q = s_red + f * B + lane;
+            return vw == 4 ? (q[0] + q[64]) + (q[128] + q[192]) : vw == 3 ? (q[0] + q[64]) + q[128] : vw == 2 ? q[0] + q[64] : q[0];
         };
 #pragma unroll
         for (int i = 0; i < 3; ++i) { dmean[i] = total(i); dscale[i] = total(3 + i); dcol[i] = total(17 + i); }
@@ -529,12 +555,23 @@ __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<Preproce
         dop = total(16);
         dn_acc = total(20); dn_cnt = total(21);
         {
-            const float* q = s_red + 22 * BLOCK + lane;
-            dn_rmax = fmaxf(fmaxf(q[0], q[64]), fmaxf(q[128], q[192]));
+            const float* q = s_red + 22 * B + lane;
+            dn_rmax = q[0];
+            for (int w = 1; w < vw; ++w) dn_rmax = fmaxf(dn_rmax, q[64 * w]);
+        }
+        if (blockIdx.y > 0) {
+            float* sc = batch.v[blockIdx.y * vw].group_scratch;         // SoA, field f of Gaussian row at sc[f * P + row]
+            const size_t Pn = (size_t)out.P;
+            o_mean = out.dL_dmeans3D ? sc : nullptr; o_scale = out.dL_dscales ? sc + 3 * Pn : nullptr;
+            o_q = out.dL_drotations ? sc + 6 * Pn : nullptr; o_cov = out.dL_dcov3D ? sc + 10 * Pn : nullptr;
+            o_op = out.dL_dopacity ? sc + 16 * Pn : nullptr; o_col = out.dL_dcolors ? sc + 17 * Pn : nullptr;
+            o_dens = sc + 20 * Pn;
         }
     }
     if (!valid) return;
-    if (SUM && dens_shared && dn_cnt > 0.f) {                   // one read-modify-write per Gaussian for all K views
+    if (o_dens) {                                               // a further workgroup row: everything into its scratch rows
+        o_dens[3 * row + 0] = dn_acc; o_dens[3 * row + 1] = dn_cnt; o_dens[3 * row + 2] = dn_rmax;
+    } else if (SUM && dens_shared && dn_cnt > 0.f) {            // one read-modify-write per Gaussian for all views of this row
         if (out.dens_accum) out.dens_accum[row] += dn_acc;
         if (out.dens_cnt) out.dens_cnt[row] += dn_cnt;
         if (out.dens_rmax) out.dens_rmax[row] = fmaxf(out.dens_rmax[row], dn_rmax);
@@ -558,14 +595,14 @@ __global__ __launch_bounds__(BLOCK, 2) void preprocess_bwd_kernel(Batch<Preproce
             for (int i = 0; i < 6; ++i) dcov[i] += out.dL_dcov3D[row * 6 + i];
         }
     }
-    if (out.dL_dmeans3D) { out.dL_dmeans3D[row * 3 + 0] = dmean[0]; out.dL_dmeans3D[row * 3 + 1] = dmean[1]; out.dL_dmeans3D[row * 3 + 2] = dmean[2]; }
-    if (out.dL_dopacity) out.dL_dopacity[row] = dop;
-    if (out.dL_dcolors) { out.dL_dcolors[row * 3 + 0] = dcol[0]; out.dL_dcolors[row * 3 + 1] = dcol[1]; out.dL_dcolors[row * 3 + 2] = dcol[2]; }
-    if (out.dL_dscales) { out.dL_dscales[row * 3 + 0] = dscale[0]; out.dL_dscales[row * 3 + 1] = dscale[1]; out.dL_dscales[row * 3 + 2] = dscale[2]; }
-    if (out.dL_drotations) reinterpret_cast<float4*>(out.dL_drotations)[row] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-    if (out.dL_dcov3D) {
+    if (o_mean) { o_mean[row * 3 + 0] = dmean[0]; o_mean[row * 3 + 1] = dmean[1]; o_mean[row * 3 + 2] = dmean[2]; }
+    if (o_op) o_op[row] = dop;
+    if (o_col) { o_col[row * 3 + 0] = dcol[0]; o_col[row * 3 + 1] = dcol[1]; o_col[row * 3 + 2] = dcol[2]; }
+    if (o_scale) { o_scale[row * 3 + 0] = dscale[0]; o_scale[row * 3 + 1] = dscale[1]; o_scale[row * 3 + 2] = dscale[2]; }
+    if (o_q) reinterpret_cast<float4*>(o_q)[row] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+    if (o_cov) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) out.dL_dcov3D[row * 6 + i] = dcov[i];
+        for (int i = 0; i < 6; ++i) o_cov[row * 6 + i] = dcov[i];
     }
 #ifdef EXA_PROBE_PBWD
     PBWD_PHASE(3);
@@ -607,6 +644,27 @@ hipError_t launch_densify_stats(int P, const float* g2d, const int32_t* radii, f
     return hipGetLastError();
 }
 
+// Second pass of a summed batch of more than four views (preprocess_bwd_kernel<SUM, VW = 4>): the sums of the further
+// workgroup rows (views 4 ..), left in their scratch in the layout of the outputs, are added to the outputs of row 0 in row
+// order.  68 B read + 68 B read-modify-write per Gaussian.
+__global__ __launch_bounds__(BLOCK) void sum_groups_kernel(PreprocessBwdArgs out, const float* __restrict__ sc, int dens_shared) {
+    const int row = blockIdx.x * BLOCK + threadIdx.x;
+    if (row >= out.P) return;
+    const size_t Pn = (size_t)out.P;
+    auto add = [&](float* dst, const float* src, int n) {
+        if (!dst) return;
+        for (int i = 0; i < n; ++i) dst[(size_t)row * n + i] += src[(size_t)row * n + i];
+    };
+    add(out.dL_dmeans3D, sc, 3); add(out.dL_dscales, sc + 3 * Pn, 3); add(out.dL_drotations, sc + 6 * Pn, 4);
+    add(out.dL_dcov3D, sc + 10 * Pn, 6); add(out.dL_dopacity, sc + 16 * Pn, 1); add(out.dL_dcolors, sc + 17 * Pn, 3);
+    const float* dn = sc + 20 * Pn + 3 * (size_t)row;
+    if (dens_shared && dn[1] > 0.f) {
+        if (out.dens_accum) out.dens_accum[row] += dn[0];
+        if (out.dens_cnt) out.dens_cnt[row] += dn[1];
+        if (out.dens_rmax) out.dens_rmax[row] = fmaxf(out.dens_rmax[row], dn[2]);
+    }
+}
+
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, int dens_shared, hipStream_t s) {
     int P = 0;
     for (int k = 0; k < K; ++k) P = max(P, a[k].P);
@@ -615,9 +673,16 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shar
     bool prefix = false;
     for (int k = 0; k < K; ++k) { sh = sh || a[k].shs != nullptr; prefix = prefix || a[k].grad_first > 0; }
     const dim3 grid256((P + BLOCK - 1) / BLOCK, sum_shared ? 1 : K);
-    if (sum_shared && !sh)
-        preprocess_bwd_kernel<true, BLOCK / 64, false, false><<<dim3((P + 63) / 64, 1), BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
-    else if (sum_shared)
+    if (sum_shared && !sh) {
+        // one wave per view: workgroups of vw = min(K, 4) waves over 64 Gaussians, ceil(K / vw) rows of them
+        const int vw = K < BLOCK / 64 ? K : BLOCK / 64, rows = (K + vw - 1) / vw;
+        for (int r = 1; r < rows; ++r)
+            if (!a[r * vw].group_scratch) return hipErrorInvalidValue;
+        preprocess_bwd_kernel<true, BLOCK / 64, false, false><<<dim3((P + 63) / 64, rows), 64 * vw, (size_t)vw * sizeof(GatherLds), s>>>(
+            make_batch(a, K), K, dens_shared);
+        for (int r = 1; r < rows; ++r)
+            sum_groups_kernel<<<(P + BLOCK - 1) / BLOCK, BLOCK, 0, s>>>(a[0], a[r * vw].group_scratch, dens_shared);
+    } else if (sum_shared)
         preprocess_bwd_kernel<true, 1, true, false><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);
     else if (sh && prefix)
         preprocess_bwd_kernel<false, 1, true, true><<<grid256, BLOCK, 0, s>>>(make_batch(a, K), K, dens_shared);

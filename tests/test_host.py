@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 137
+    assert lib.exa_raster_version() == 138
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 
@@ -40,7 +40,7 @@ def test_settings_struct_layout_matches_c():
 def test_workspace_sizes():
     s = _lib.workspace_sizes(150_000, 1024, 1024, 1_000_000)
     assert s.geom_bytes == 150_000 * 64
-    assert s.bin_bytes >= 29 * 1_000_000 and s.grad_bytes >= 40 * 1_000_000
+    assert s.bin_bytes >= 29 * 1_000_000 and s.grad_bytes >= 40 * 1_000_000 + 92 * 150_000
     s2 = _lib.workspace_sizes(0, 0, 0, 0)
     assert s2.geom_bytes == 0
     with pytest.raises(RuntimeError):

@@ -19,7 +19,7 @@ G = torch.randn(3, H, W, device=dev)
 tanx, tany, vm, pm, cpos = make_raster_matrices(scenes.ring_camera(H, W, view, 200), (H, W))
 st = GaussianRasterizationSettings(H, W, tanx, tany, torch.ones(3, device=dev), 1.0, vm.to(dev), pm.to(dev), 0, cpos.to(dev), False, False)
 exa.config.mode = 'exact'
-for K in (1, 2, 4):
+for K in (1, 2, 3, 4, 8):
     m2 = [torch.zeros(P, 3, device=dev, requires_grad=True) for _ in range(K)]
     acc = {}
     for rep in range(5):
