@@ -1,6 +1,7 @@
 // C ABI of the rasterizer (include/exa_raster.h): argument validation, workspace carving, kernel
 // sequencing.  No torch types, no allocation, no hidden synchronisation (unless settings->debug).
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -87,6 +88,21 @@ int check_inputs(int32_t P, int32_t sh_M, const float* means3D, const float* shs
 }
 
 }  // namespace
+
+// The library's only environment reads (common.h, DevKnobs): developer knobs, read once.
+const exa::DevKnobs& exa::dev_knobs() {
+    static const DevKnobs k = [] {
+        DevKnobs d;
+        const char* e = getenv("EXA_FOOTPRINT");
+        d.footprint = !e || atoi(e) != 0;
+        e = getenv("EXA_BIN_SINGLE_CELLS");
+        d.single_cells = e ? atoi(e) : SINGLE_PART_CELLS;
+        e = getenv("EXA_SORT_SPLIT_SUBTILES");
+        d.split_subtiles = e ? atoi(e) : SPLIT_SORT_SUBTILES;
+        return d;
+    }();
+    return k;
+}
 
 extern "C" {
 

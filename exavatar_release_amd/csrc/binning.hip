@@ -490,7 +490,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
 // LDS, turns the counts into [begin, end) ranges (cell-major sub-tile order) and scatters the sort keys.
 // Entries are 16-byte records read coalesced; no gather from the splat array.
 constexpr int BIN_THREADS = 1024;
-constexpr int SINGLE_PART_CELLS = 1024;   // from this many cells on (2048 x 2048 px) one workgroup per cell
+// (SINGLE_PART_CELLS = 1024, common.h: from this many cells on (2048 x 2048 px) one workgroup per cell)
 // An avatar's instances sit in a few dozen cells, and both halves of this digit -- LDS counting atomics and the
 // scattered 8-byte key stores, one per instance -- are throughput limits of ONE CU.  Every cell is therefore
 // handled by BIN_PARTS workgroups in two launches:
@@ -762,11 +762,11 @@ hipError_t launch_subtile_bin(const BinArgs* a, int K, hipStream_t s) {
     int cells = 0;
     for (int k = 0; k < K; ++k) cells = max(cells, a[k].grid.cells);
     if (cells == 0) return hipSuccess;
-    static const bool footprint = [] { const char* e = getenv("EXA_FOOTPRINT"); return !e || atoi(e) != 0; }();   // developer knob
+    const bool footprint = dev_knobs().footprint;
     // Workgroups per cell: an avatar view fills a few dozen of its 256 cells, so every cell is split over BIN_PARTS
     // workgroups (two launches) to get the chip busy; a large image (C5: 1024 cells, content everywhere) has enough
     // cells already and takes one workgroup per cell that counts and scatters in ONE launch.
-    static const int single_cells = [] { const char* e = getenv("EXA_BIN_SINGLE_CELLS"); return e ? atoi(e) : SINGLE_PART_CELLS; }();
+    const int single_cells = dev_knobs().single_cells;
     if (cells >= single_cells || cells > 1024) {                  // (the part table maps one thread to one cell)
         if (footprint) subtile_count_bin_kernel<true><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);
         else subtile_count_bin_kernel<false><<<dim3(cells, K), BIN_THREADS, 0, s>>>(b);

@@ -446,6 +446,19 @@ struct PreprocessBwdArgs {
 // per Gaussian walks the K views and writes the SUM of their gradients to job 0's outputs (dL_dmeans2D stays per view).
 // dens_shared != 0 (with sum_shared): the K views accumulate into job 0's densification statistics (one write per Gaussian).
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs* a, int K, int sum_shared, int dens_shared, hipStream_t s);
+
+// The three RUN-TIME developer knobs of the library (environment, read once; api.hip): they exist because tests have to reach
+// code paths that only large images take (tests/test_gpu_parity.py) and switch the exact-footprint test off for an A/B.
+// Every other variant ever measured (render_bwd chunk size / slots per wave / waves per workgroup, LDS occupancy pads,
+// partial-record size, gather chunk) is a COMPILE-TIME macro: tools/build_variant.sh <rev> <name> -DEXA_...=...
+constexpr int SINGLE_PART_CELLS = 1024;      // default of DevKnobs.single_cells (2048 x 2048 px)
+constexpr int SPLIT_SORT_SUBTILES = 65536;   // default of DevKnobs.split_subtiles
+struct DevKnobs {
+    bool footprint;          // EXA_FOOTPRINT=0: sub-tile binning keeps the whole bounding rect of every splat
+    int single_cells;        // EXA_BIN_SINGLE_CELLS=<n>: images with at least n cells take the one-workgroup-per-cell binning
+    int split_subtiles;      // EXA_SORT_SPLIT_SUBTILES=<n>: images with at least n sub-tiles sort short lists in their own launch
+};
+const DevKnobs& dev_knobs();
 hipError_t launch_ssim_fwd(int N, int H, int W, const float* img1, const float* img2, float* map, float* dm_dmu1,
                            float* dm_dE11, float* dm_dE12, hipStream_t s);
 hipError_t launch_ssim_bwd(int N, int H, int W, const float* img1, const float* img2, const float* dL_dmap,

@@ -448,32 +448,34 @@ hipError_t launch_render_bwd(const RenderBwdArgs* a, int K, hipStream_t s) {
         prefix = prefix || a[k].grad_first > 0;
     }
     if (slots == 0) return hipSuccess;
-    // chunk size: 8 (default: 8 KB of LDS per wave = 5 waves per SIMD, DPP reductions) or 16 (13 KB, 3 waves per SIMD);
-    // C3 on MI355X: 52.5 vs 54.7 us (HIP events, eager), occupancy probe EXA_BWD_LDS_PAD: 2.25 waves / SIMD = 60.6 us
-    static const int gc = [] { const char* e = getenv("EXA_BWD_GC"); return e ? atoi(e) : 8; }();     // developer knobs
-    static const int spw = [] { const char* e = getenv("EXA_BWD_SPW"); return e ? atoi(e) : 1; }();
+    // Variants measured in rounds 2-5 and kept as BUILD-TIME macros (tools/build_variant.sh ... -DEXA_BWD_GC=16): chunk size 8
+    // (default: 8 KB of LDS per wave = 5 waves per SIMD, DPP reductions) or 16 (13 KB, 3 waves per SIMD; C3: 52.5 vs 54.7 us);
+    // EXA_BWD_SPW=2 batch slots per wave (with GC 16; 64.0 vs 55.6 us); EXA_BWD_WPB=2|4 independent waves per workgroup (slower);
+    // EXA_BWD_LDS_PAD=<bytes> of unused dynamic LDS per workgroup (occupancy probe: 2.25 waves / SIMD = 60.6 us).
+#ifndef EXA_BWD_GC
+#define EXA_BWD_GC 8
+#endif
+#ifndef EXA_BWD_SPW
+#define EXA_BWD_SPW 1
+#endif
+#ifndef EXA_BWD_WPB
+#define EXA_BWD_WPB 1
+#endif
+#ifndef EXA_BWD_LDS_PAD
+#define EXA_BWD_LDS_PAD 0
+#endif
+    constexpr int GC = EXA_BWD_GC, SPW = EXA_BWD_SPW, WPB = EXA_BWD_WPB;
     const Batch<RenderBwdArgs> b = make_batch(a, K);
-    // EXA_BWD_LDS_PAD (bytes, developer knob): unused dynamic LDS per workgroup = fewer resident waves per SIMD (occupancy probe)
-    static const int pad = [] { const char* e = getenv("EXA_BWD_LDS_PAD"); return e ? atoi(e) : 0; }();
-    // waves per workgroup (see the kernel): 1; EXA_BWD_WPB overrides (A/B)
-    static const int wpb_env = [] { const char* e = getenv("EXA_BWD_WPB"); return e ? atoi(e) : 0; }();
-#define EXA_LAUNCH_BWD(D, G, S, PFX, W) \
-    render_bwd_kernel<D, G, S, PFX, W><<<dim3((unsigned)((slots + (S) * (W) - 1) / ((S) * (W))), K), RBLOCK * (W), (size_t)pad, s>>>(b)
-#define EXA_LAUNCH_BWD_D(G, S, PFX, W) do { if (depth) EXA_LAUNCH_BWD(true, G, S, PFX, W); else EXA_LAUNCH_BWD(false, G, S, PFX, W); } while (0)
-    if (prefix) {
-        const int w = wpb_env ? wpb_env : 1;
-        if (gc == 8) { if (w >= 4) EXA_LAUNCH_BWD_D(8, 1, true, 4); else EXA_LAUNCH_BWD_D(8, 1, true, 1); }
-        else EXA_LAUNCH_BWD_D(16, 1, true, 1);
-    } else if (gc == 8) {
-        const int w = wpb_env ? wpb_env : 1;
-        if (w >= 4) EXA_LAUNCH_BWD_D(8, 1, false, 4); else if (w == 2) EXA_LAUNCH_BWD_D(8, 1, false, 2); else EXA_LAUNCH_BWD_D(8, 1, false, 1);
-    } else if (spw == 2) {
-        EXA_LAUNCH_BWD_D(16, 2, false, 1);
+    const dim3 grid((unsigned)((slots + SPW * WPB - 1) / (SPW * WPB)), K);
+    if (prefix) {                       // (the prefix-aware instantiation takes one slot per wave)
+        const dim3 g1((unsigned)((slots + WPB - 1) / WPB), K);
+        if (depth) render_bwd_kernel<true, GC, 1, true, WPB><<<g1, RBLOCK * WPB, (size_t)EXA_BWD_LDS_PAD, s>>>(b);
+        else render_bwd_kernel<false, GC, 1, true, WPB><<<g1, RBLOCK * WPB, (size_t)EXA_BWD_LDS_PAD, s>>>(b);
+    } else if (depth) {
+        render_bwd_kernel<true, GC, SPW, false, WPB><<<grid, RBLOCK * WPB, (size_t)EXA_BWD_LDS_PAD, s>>>(b);
     } else {
-        EXA_LAUNCH_BWD_D(16, 1, false, 1);
+        render_bwd_kernel<false, GC, SPW, false, WPB><<<grid, RBLOCK * WPB, (size_t)EXA_BWD_LDS_PAD, s>>>(b);
     }
-#undef EXA_LAUNCH_BWD_D
-#undef EXA_LAUNCH_BWD
     return hipGetLastError();
 }
 

@@ -28,8 +28,8 @@ namespace exa {
 constexpr int RBLOCK = 64;            // threads per workgroup of the per-pixel kernels: ONE wave
 
 constexpr int SORT_TILE = 2048;       // keys of the LDS buffer (16 KiB)
-constexpr int SBLOCK = 256;
-constexpr int SPLIT_SORT_SUBTILES = 65536;   // from this many sub-tiles on the short lists get their own launch           // threads of a sort workgroup: four waves co-operate on ONE list
+constexpr int SBLOCK = 256;           // threads of a sort workgroup: four waves co-operate on ONE list
+// (SPLIT_SORT_SUBTILES = 65536, common.h: from this many sub-tiles on the short lists get their own launch)
 
 // ---- sort of lists up to SORT_TILE keys: rank-sorted runs of 64 + rank-based merges, in place in LDS -----
 // A single wave issues roughly one VALU instruction per 5 cycles on gfx950 (probe: tools/probe/cmp_probe.hip),
@@ -679,7 +679,7 @@ static int max_subtiles(const RenderFwdArgs* a, int K) {
 hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
-    static const int split_at = [] { const char* e = getenv("EXA_SORT_SPLIT_SUBTILES"); return e ? atoi(e) : SPLIT_SORT_SUBTILES; }();
+    const int split_at = dev_knobs().split_subtiles;
     bool keep = false;                   // (all jobs of a call share the flag: the binding sets it per call)
     for (int k = 0; k < K; ++k) keep = keep || a[k].keep_sorted_keys != 0;
     const dim3 grid(subtiles + ORDER_WGS, K);
@@ -703,13 +703,16 @@ hipError_t launch_sort_subtiles(const RenderFwdArgs* a, int K, hipStream_t s) {
 //  bought 0.4 us on C3 (the per-SIMD end times stopped following the entry counts: correlation 0.89 -> 0.61) and cost the
 //  batched modes 5-7 % (8 330 -> 7 880 it/s at K = 8: four resident waves per SIMD instead of five, no overlap between the
 //  jobs of a batch).  Snaking the launch order alone (periods 256 .. 2048): +-1 us.  Not kept.)
-// All jobs of a batch share store_ctx (checked by the C ABI).  EXA_FWD_LDS_PAD (bytes, developer knob) adds unused
+// All jobs of a batch share store_ctx (checked by the C ABI).  -DEXA_FWD_LDS_PAD=<bytes> (build-time probe) adds unused
 // dynamic LDS per workgroup: fewer resident waves per CU, so that the tail of the length-sorted launch is dealt out
-// dynamically as earlier waves retire instead of all sub-tiles being placed at once.
+// dynamically as earlier waves retire instead of all sub-tiles being placed at once (measured: slower).
+#ifndef EXA_FWD_LDS_PAD
+#define EXA_FWD_LDS_PAD 0
+#endif
 hipError_t launch_render_fwd(const RenderFwdArgs* a, int K, hipStream_t s) {
     const int subtiles = max_subtiles(a, K);
     if (subtiles == 0) return hipSuccess;
-    static const int pad = [] { const char* e = getenv("EXA_FWD_LDS_PAD"); return e ? atoi(e) : 0; }();
+    constexpr int pad = EXA_FWD_LDS_PAD;
     if (a[0].splats2) {                 // composite renders (all jobs of such a call are composites)
         if (a[0].store_ctx) render_fwd_kernel<true, true><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));
         else render_fwd_kernel<false, true><<<dim3(subtiles, K), RBLOCK, (size_t)pad, s>>>(make_batch(a, K));

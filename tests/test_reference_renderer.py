@@ -24,6 +24,16 @@ def golden(golden_dir):
     return np.load(os.path.join(golden_dir, 'ref_renderer.npz'))
 
 
+@pytest.fixture(autouse=True)
+def _one_thread():
+    """The fixture was generated with one CPU thread (make_golden_renderer.py): the oracle's reductions round differently when
+    PyTorch splits them over threads, and the comparisons below are bitwise."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
 def _case(golden, name):
     p = name + '_'
     assets = {k[len(p) + 6:]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith(p + 'asset_')}
