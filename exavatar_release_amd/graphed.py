@@ -218,7 +218,17 @@ class GraphedIteration:
             if self._cap is not None:
                 warnings.warn('exavatar_release_amd: GraphedIteration was garbage-collected with a live capture; call close()',
                               ResourceWarning, stacklevel=2)
-                self.close()
+                if torch.cuda.is_current_stream_capturing():
+                    # collected in the middle of SOMEBODY ELSE's stream capture: the device wait of close() is illegal there and
+                    # would invalidate that capture.  Give the report slots back and let the graphs go with the object; the
+                    # replays they belong to were queued before the capture began.
+                    cap, self._cap = self._cap, None
+                    if rz._hdr_pool is not None:
+                        for s in (cap.slots or []) + (getattr(cap, 'slots_c', None) or []):
+                            if s is not None:
+                                rz._hdr_pool.release(s[0])
+                else:
+                    self.close()
         except Exception:  # noqa: BLE001 -- interpreter shutdown
             pass
 
@@ -270,7 +280,10 @@ class GraphedIteration:
         cap.dens = None if dens is None else [t for t in dens if t is not None]
         cap.loss_args = [t.detach().clone() for t in loss_args]          # static: the recorded loss reads these
         self._fill_inputs(cap, assets)
-        saved = (rz.config.mode, rz.config.fixed_capacity)
+        saved = (rz.config.mode, rz.config.fixed_capacity, rz.config.on_overflow)
+        # (the eager renders below run with capacities that may be estimates: an overflow there is repaired in place whatever the
+        #  user's policy says -- the captured graph has its own overflow path, _grow)
+        rz.config.on_overflow = 'retry'
         try:
             with torch.enable_grad():
                 # Capacities of the three plain renders (scene, human, refined human).  After an overflow: what the reports
@@ -314,18 +327,20 @@ class GraphedIteration:
                 # header reports of the plain renders go to reserved pinned-host slots (outside the ring eager calls use)
                 pool = rz._pool()
                 n_jobs = 3 if self.merge else 5
+                # (the composites report too -- {slots in use, overflow}, written by the first kernel of their forward: their backward
+                #  visits only the batch slots in use, ExaRasterBackwardJob.used_slots, _backward below)
                 cap.slots = [None] * n_jobs
-                if pool is not None:
-                    for k in range(n_jobs):
-                        got = pool.reserve()
-                        cap.slots[k] = None if got is None else (got[0], got[1])
-                # the composites report too ({slots in use, overflow}: written by the first kernel of their forward): their
-                # backward visits only the batch slots in use (ExaRasterBackwardJob.used_slots, _backward below)
                 cap.slots_c = [None, None] if self.merge else []
                 if pool is not None:
-                    for k in range(len(cap.slots_c)):
-                        got = pool.reserve()
-                        cap.slots_c[k] = None if got is None else (got[0], got[1])
+                    taken = []
+                    try:                # reserve() raises when the reserved region is exhausted: give back what this capture took
+                        for _ in range(n_jobs + len(cap.slots_c)):
+                            taken.append(pool.reserve()[:2])
+                    except Exception:
+                        for slot, _tag in taken:
+                            pool.release(slot)
+                        raise
+                    cap.slots, cap.slots_c = taken[:n_jobs], taken[n_jobs:]
                 if self._pool is None:
                     # a pool lives as long as a graph recorded into it: this one-kernel recording keeps it (and the memory
                     # earlier captures gave back to it) across re-captures
@@ -366,7 +381,7 @@ class GraphedIteration:
                 cap.bwd = {}
                 self.captures += 1
         finally:
-            rz.config.mode, rz.config.fixed_capacity = saved
+            rz.config.mode, rz.config.fixed_capacity, rz.config.on_overflow = saved
         # the backward graph of the usual case -- gradients for the five colour images only -- is
         # recorded right away; other patterns (depth / mask gradients, fewer images) on first use
         if self.loss_fn is None and not self.tight_backward:

@@ -412,7 +412,9 @@ class GraphedRenderer:
         """Release the captured graph, its static outputs and the reserved report slot (after waiting for the device: a graph
         must not be destroyed while one of its replays is still executing).  The object captures anew when called again."""
         from . import rasterizer as rz
-        if self._graph is not None:
+        if self._graph is not None and not torch.cuda.is_current_stream_capturing():
+            # (garbage-collected in the middle of somebody else's stream capture: a device wait is illegal there and would
+            #  invalidate that capture; the replays of this graph were queued before the capture began)
             torch.cuda.synchronize(self.device)
         self._graph, self._outs, self._tile, self._tan = None, None, None, None
         if self._slot is not None and rz._hdr_pool is not None:
@@ -455,7 +457,8 @@ class GraphedRenderer:
 
     def _capture(self, tan):
         from . import rasterizer as rz
-        saved = (rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug)
+        saved = (rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug, rz.config.on_overflow)
+        rz.config.on_overflow = 'retry'       # (the eager warm-up below repairs an overflow whatever the user's policy: the graph has its own path)
         try:
             with torch.no_grad():
                 if self._capacity is None:                    # measure this frame once with the two-stage protocol
@@ -494,7 +497,7 @@ class GraphedRenderer:
                 self._tan = tan
                 self.captures += 1
         finally:
-            rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug = saved
+            rz.config.mode, rz.config.fixed_capacity, rz.config.keep_debug, rz.config.on_overflow = saved
 
     def __call__(self, gaussian_assets, cam_param, bg=None):
         from . import rasterizer as rz

@@ -1,20 +1,36 @@
-"""gpurun_out/parity_stats.jsonl (written by tests/test_gpu_fullsize.py on the GPU box) -> profiles/<tag>_parity.md.
-Usage: python tools/make_parity_profile.py [tag=r02]   (the last record of every workload wins)"""
+"""<dir>/parity_stats.jsonl (written by the GPU suite of ONE lease: tools/profile_round.sh) -> profiles/<tag>_parity.md, stamped
+with the library build that lease ran.  Fails when any of the seven full-size workloads is missing (a stale or partial file
+must not turn into a summary) or when the lease's build is not this tree's.
+Usage: python tools/make_parity_profile.py <tag> [dir=gpurun_out/<tag>]   (the last record of every workload wins)"""
 import json
 import os
 import sys
 
+import subprocess
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r02'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r06'
+src = sys.argv[2] if len(sys.argv) > 2 else os.path.join(root, 'gpurun_out', tag)
+sys.path.insert(0, root)
+from exavatar_release_amd import build as _b      # noqa: E402
+digest = open(os.path.join(src, 'digest.txt')).read().strip()
+if digest != _b._digest()[:16]:
+    sys.exit('make_parity_profile: %s was measured on library build %s, this tree builds %s' % (src, digest, _b._digest()[:16]))
+head = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
 rows = {}
-for line in open(os.path.join(root, 'gpurun_out', 'parity_stats.jsonl')):
+for line in open(os.path.join(src, 'parity_stats.jsonl')):
     r = json.loads(line)
     rows[r['tag']] = r
-order = [t for t in ('c3_P150000_view0', 'c3_P150000_view37', 'c3_P167000_view113', 'c2', 'c2l', 'c3s', 'c5_fwd_sh3') if t in rows]
+FULL_SIZE = ('c3_P150000_view0', 'c3_P150000_view37', 'c3_P167000_view113', 'c2', 'c2l', 'c3s', 'c5_fwd_sh3')
+missing = [t for t in FULL_SIZE if t not in rows]
+if missing:
+    sys.exit('make_parity_profile: %s holds no record of %s -- the full-size tests of that lease did not run' % (src, missing))
+order = list(FULL_SIZE)
 order += [t for t in rows if t not in order and 'img' in rows[t]]
 fuzz = [rows[t] for t in sorted((t for t in rows if t.startswith('fuzz_')), key=lambda t: int(t.split('_')[1]))]
 two_rank = rows.get('two_rank_gradient')
 out = ['# %s: HIP path vs CPU oracle at BASELINE.json\'s full sizes (MI355X, `pytest -m gpu tests/test_gpu_fullsize.py`)' % tag, '',
+       'Library build %s (exavatar_release_amd.build._digest), sources at git %s; %d records of ONE GPU-suite run (tools/profile_round.sh).' % (digest, head, len(rows)), '',
        'Rows `*_vs_c_oracle` and `c5_fwd_sh3` are checked against the C restatement (oracle/c), the others against the PyTorch oracle; '
        'the two oracles agree with each other to 1e-6 on these workloads (tests/test_c_oracle.py).', '',
        'Written by the tests themselves (`tests/helpers.record_stats` -> gpurun_out/parity_stats.jsonl, turned into this file by '

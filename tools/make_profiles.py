@@ -3,8 +3,23 @@
    Usage: python tools/make_profiles.py gpurun_out/r01b r01_final"""
 import sys, os, csv, glob, json, collections
 
+import subprocess
+
 src, prefix = sys.argv[1], sys.argv[2]
-out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles')
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, 'profiles')
+# Every summary is stamped with the build it measured: the digest the lease itself recorded (tools/profile_round.sh ->
+# digest.txt) must be the digest of the sources in this tree -- a summary of another build is refused here, and bench.py quotes
+# a summary only when its digest equals the loaded library's.
+sys.path.insert(0, root)
+from exavatar_release_amd import build as _b      # noqa: E402
+DIGEST = open(os.path.join(src, 'digest.txt')).read().strip()
+if DIGEST != _b._digest()[:16]:
+    sys.exit('make_profiles: %s was measured on library build %s, this tree builds %s -- run tools/profile_round.sh on THIS build'
+             % (src, DIGEST, _b._digest()[:16]))
+HEAD = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+DIRTY = bool(subprocess.run(['git', '-C', root, 'status', '--porcelain', '--', 'exavatar_release_amd/csrc', 'include'], capture_output=True, text=True).stdout.strip())
+STAMP = 'library build %s (exavatar_release_amd.build._digest), sources at git %s%s' % (DIGEST, HEAD, ' + uncommitted changes' if DIRTY else '')
 SHORT = {'zero_kernel': 'zero', 'preprocess_fwd_kernel': 'preprocess_fwd', 'col_scan_kernel': 'col_scan', 'cell_scan_kernel': 'cell_scan',
          'subtile_count_kernel': 'subtile_count',
          'cell_scatter_kernel': 'cell_scatter', 'subtile_bin_kernel': 'subtile_bin', 'sort_subtiles_kernel': 'sort_subtiles',
@@ -30,6 +45,7 @@ def counters(d):
 
 
 bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
+bench['profile_stamp'] = {'library_digest': DIGEST, 'git_head': HEAD}
 with open(os.path.join(out, prefix + '_bench.json'), 'w') as f:
     json.dump(bench, f, indent=1)
 
@@ -42,7 +58,7 @@ if os.path.exists(_ks):
     if '\n## ' in _old:
         _tail = _old[_old.index('\n## '):]
 with open(_ks, 'w') as f:
-    f.write('# %s: rocprofv3 kernel statistics of the bench command\n\n' % prefix)
+    f.write('# %s: rocprofv3 kernel statistics of the bench command\n\n%s.\n\n' % (prefix, STAMP))
     f.write('Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --steps 100 --warmup 10 '
             '--no-cpu-baseline --no-concurrent` (C3, 1 x MI355X, launch protocol of that bench line (`config.launch`); includes the untimed calibration / warm-up '
             'launches of bench.py, hence more calls than steps).\n\n')
@@ -67,7 +83,8 @@ if stats:
                 kern[k] = {'avg_us': float(r['AverageNs']) / 1e3, 'calls': int(r['Calls'])}
     with open(os.path.join(out, prefix + '_kernel_stats.json'), 'w') as f:
         json.dump({'what': 'rocprofv3 --kernel-trace --stats of `python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-concurrent` '
-                           '(C3, the launch protocol of that bench line, ring average)', 'kernels': kern}, f, indent=1)
+                           '(C3, the launch protocol of that bench line, ring average)', 'library_digest': DIGEST, 'git_head': HEAD,
+                   'kernels': kern}, f, indent=1)
 
 # ---- HBM traffic -----------------------------------------------------------------------------------------
 fe, wr = counters('pmc_fetch'), counters('pmc_write')
@@ -93,9 +110,9 @@ tr = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | --pmc WRITE_SIZE (t
                 'WRITE_SIZE) * 1024; hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 = the gfx950 correction of '
                 'MI355X_MICROARCH.md applied to ALL reads (an upper bound: the calibration probe shows factor 2 for coalesced '
                 '4 / 12 / 16 B-per-lane streams but factor 1 for 64-byte record gathers, and these kernels mix both)',
-      'calibration_factors': factors, 'kernels': {}}
+      'calibration_factors': factors, 'library_digest': DIGEST, 'git_head': HEAD, 'kernels': {}}
 with open(os.path.join(out, prefix + '_hbm_traffic.md'), 'w') as f:
-    f.write('# %s: HBM-side traffic per kernel launch (PMC)\n\n' % prefix)
+    f.write('# %s: HBM-side traffic per kernel launch (PMC)\n\n%s.\n\n' % (prefix, STAMP))
     f.write('Two separate PMC passes (counters only, `--kernel-trace`, no other trace domains): `rocprofv3 --kernel-trace --pmc '
             'FETCH_SIZE --output-format csv -- python tools/gpu_kernel_times.py 0` and the same with `--pmc WRITE_SIZE`. Config '
             'C3, ring view 0 (exact mode: the two-stage protocol, so col_scan / cell_scan appear as launches).\n\n'
@@ -117,7 +134,7 @@ with open(os.path.join(out, prefix + '_hbm_traffic.json'), 'w') as f:
 # ---- SQ counters -----------------------------------------------------------------------------------------
 s1, s2 = counters('pmc_sq1'), counters('pmc_sq2')
 with open(os.path.join(out, prefix + '_pmc.md'), 'w') as f:
-    f.write('# %s: SQ counters per kernel (mean per dispatch; SQ_*_CYCLES / ACTIVE / WAIT in quad-cycles)\n\n' % prefix)
+    f.write('# %s: SQ counters per kernel (mean per dispatch; SQ_*_CYCLES / ACTIVE / WAIT in quad-cycles)\n\n%s.\n\n' % (prefix, STAMP))
     f.write('Two PMC passes of `python tools/gpu_kernel_times.py 0` (C3, ring view 0, eager), counters only with --kernel-trace.\n\n')
     for tab in (s1, s2):
         names = sorted({c for k in tab.values() for c in k})
@@ -139,5 +156,5 @@ with open(os.path.join(out, prefix + '_pmc.md'), 'w') as f:
 with open(os.path.join(out, prefix + '_pmc.json'), 'w') as f:
     merged = {k: dict(s1.get(k, {}), **s2.get(k, {})) for k in SHORT.values() if k in s1 or k in s2}
     json.dump({'what': 'rocprofv3 --kernel-trace --pmc SQ_* passes of `python tools/gpu_kernel_times.py 0` (C3, ring view 0, eager), '
-                       'mean per dispatch', 'kernels': merged}, f, indent=1)
+                       'mean per dispatch', 'library_digest': DIGEST, 'git_head': HEAD, 'kernels': merged}, f, indent=1)
 print('wrote profiles/%s_*' % prefix)
