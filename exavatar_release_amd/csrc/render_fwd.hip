@@ -497,38 +497,6 @@ __global__ __launch_bounds__(SBLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 #endif
 }
 
-// ---- operands through the SCALAR path (-DEXA_FWD_SGPR) --------------------------------------------------------
-// The operands of a splat are wave-uniform: every pixel of the sub-tile reads the same ten floats.  Broadcasting them through
-// LDS (stage SoA, six + four ds_read_b128 per group of four) puts an LDS round trip into the dependency chain of every group
-// and ~70 ns of the CU's LDS pipe per group next to ~96 ns of VALU issue.  Here they are fetched with SCALAR loads straight
-// from the splat records (uniform address = readlane of the id vector; s_load_dwordx2 + s_load_dwordx8 per entry, one group
-// ahead) and enter the VALU instructions as SGPR operands: no staging, no LDS at all in the blend.
-typedef float sv8 __attribute__((ext_vector_type(8)));
-typedef float sv2 __attribute__((ext_vector_type(2)));
-struct SOps { float px, py, ca, cb, cc, op, r, g, b, d; };
-__device__ __forceinline__ SOps sgpr_record(const Splat* base, uint32_t id, bool ok) {      // base, id, ok: wave-uniform
-    const unsigned long long addr = (unsigned long long)base + (unsigned long long)id * sizeof(Splat);
-    const sv2 a = *(const sv2 __attribute__((address_space(4)))*)(addr);
-    const sv8 b = *(const sv8 __attribute__((address_space(4)))*)(addr + 16ull);
-    SOps o;
-    o.px = a.x; o.py = a.y;
-    // an entry past the end of the list: all-zero conic and opacity -> falloff 1, alpha 0 (what the staged zero record gave)
-    o.ca = ok ? b.s0 : 0.f; o.cb = ok ? b.s1 : 0.f; o.cc = ok ? b.s2 : 0.f; o.op = ok ? b.s3 : 0.f;
-    o.r = b.s4; o.g = b.s5; o.b = b.s6; o.d = b.s7;
-    return o;
-}
-// splat_alpha2 (blend.h) for ONE splat, term by term the same arithmetic (the packed form computes these per component)
-__device__ __forceinline__ void sgpr_alpha(const SOps& o, float fx, float fy, float& alpha, float& G) {
-#pragma clang fp contract(off)
-    const float dx = o.px - fx, dy = o.py - fy;
-    const float p2 = __builtin_fmaf(o.ca * dx, dx, __builtin_fmaf(o.cc * dy, dy, (o.cb * dx) * dy));
-    G = __builtin_amdgcn_exp2f(p2);
-    const float og = o.op * G;
-    float a = fminf(ALPHA_MAX, og);
-    a = (a >= ALPHA_MIN) ? a : 0.0f;
-    alpha = (p2 <= 0.0f) ? a : 0.0f;
-}
-
 // ---- blend ---------------------------------------------------------------------------------------------
 // TWO = true: composite render (compose.hip).  The sorted list holds ids of TWO finished renders of this camera (bit 31 =
 // source B) and the launch records carry the sub-tile only (its range is read from tw.ranges); everything else -- batches,
@@ -575,74 +543,6 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         return reinterpret_cast<const float4*>(splats + id);
     };
 
-#ifdef EXA_FWD_SGPR
-    // ids one batch ahead (vector loads); records through the scalar path one GROUP ahead
-    uint32_t id_cur = 0, id_nxt = 0;
-    if (n > 0) {
-        id_cur = lane < n ? sorted[lane] : 0u;
-        if (64 + lane < n) id_nxt = sorted[64 + lane];
-    }
-    float* ckpt = a.bw.ckpt + (size_t)(range.x / BATCH) * (5 * 64) + lane;
-    int entered = 0;
-    for (int base = 0; base < n; base += 64) {
-        if (__all(live == 0.0f)) break;
-        if (STORE && base > 0) {
-            float* c = ckpt + (size_t)entered * (5 * 64);
-            c[0] = live != 0.0f ? T : -T; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
-        }
-        ++entered;
-        const uint32_t idv = id_cur;
-        id_cur = id_nxt;
-        if (base + 128 + lane < n) id_nxt = sorted[base + 128 + lane];
-        const int cnt = min(64, n - base);
-        unsigned long long blended = 0ull;
-        auto fetch4 = [&](SOps (&o)[4], int k) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool ok = k + u < cnt;
-                const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)idv, ok ? k + u : cnt - 1);
-                const Splat* rb = splats;
-                uint32_t idx = id;
-                if (TWO) { rb = (id & SRC_B) ? a.splats2 : splats; idx = id & ~SRC_B; }
-                o[u] = sgpr_record(rb, idx, ok);
-            }
-        };
-        auto group4 = [&](const SOps (&o)[4], int k) -> bool {
-            Alpha4 e;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sgpr_alpha(o[u], fx, fy, e.alpha[u], e.G[u]);
-            float aeff[4], Tb[4], w[4];
-            blend_group4(T, live, e.alpha, aeff, Tb, w);
-            if (STORE) {
-                auto vote_bit = [](bool p, uint32_t bit) -> uint32_t {
-                    const unsigned long long m = __ballot(p);
-                    uint32_t r;
-                    asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(r) : "s"(m), "s"(bit) : "scc");
-                    return r;
-                };
-                const uint32_t nib = vote_bit(aeff[0] > 0.0f, 1u) | vote_bit(aeff[1] > 0.0f, 2u) |
-                                     vote_bit(aeff[2] > 0.0f, 4u) | vote_bit(aeff[3] > 0.0f, 8u);
-                blended |= (unsigned long long)nib << k;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                Crg.x = __builtin_fmaf(o[u].r, w[u], Crg.x); Crg.y = __builtin_fmaf(o[u].g, w[u], Crg.y);
-                Cbd.x = __builtin_fmaf(o[u].b, w[u], Cbd.x); Cbd.y = __builtin_fmaf(o[u].d, w[u], Cbd.y);
-            }
-            return (k & 4) ? __all(live == 0.0f) : false;
-        };
-        SOps opsA[4], opsB[4];
-        fetch4(opsA, 0);
-        for (int k = 0; k < cnt; k += 8) {
-            fetch4(opsB, k + 4);
-            if (group4(opsA, k)) break;
-            if (k + 4 >= cnt) break;
-            fetch4(opsA, k + 8);
-            if (group4(opsB, k + 4)) break;
-        }
-        if (STORE && lane == 0) a.bw.bmask[range.x / BATCH + (uint32_t)(entered - 1)] = blended;
-    }
-#else
     // software pipeline: ids two batches ahead, records one batch ahead
     uint32_t id_next = 0;
     float2 r0 = make_float2(0.f, 0.f);
@@ -741,7 +641,6 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         wave_lds_fence();
     }
 
-#endif
     // ---- outputs ---------------------------------------------------------------------------------
     const size_t HW = (size_t)a.grid.W * a.grid.H;
     if (inside) {
