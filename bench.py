@@ -1157,27 +1157,6 @@ def batched_throughput(K, S, args, make_ctx, set_view, raster_step):
     return {'views_per_launch': K, 'launches_in_flight': S, 'value': val, 'unit': 'iters/s', 'ms_per_launch': ms}
 
 
-def concurrent_throughput(S, args, make_ctx, set_view, raster_step):
-    """Same step, S independent views in flight (one HIP stream + hipGraph each)."""
-    ctxs = []
-    for _ in range(S):
-        c = make_ctx(1)
-        c['stream'] = torch.cuda.Stream()
-        ctxs.append(c)
-    torch.cuda.synchronize()
-    for c in ctxs:
-        set_view(0, c)
-        with torch.cuda.stream(c['stream']):
-            raster_step(c)
-    torch.cuda.synchronize()
-    for c in ctxs:
-        c['graph'] = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(c['graph']):
-            raster_step(c)
-    val, ms = _timed_replays(ctxs, args, set_view, 1)
-    return {'views_in_flight': S, 'value': val, 'unit': 'iters/s', 'ms_per_step': ms}
-
-
 _RCCL_SMOKE = r"""
 import os, sys, time, json, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
