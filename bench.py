@@ -282,7 +282,7 @@ def main():
         for st_j in view_st:
             sr.add_view(st_j, dL_dcolor=dL_dimg if train else None)
         if train:
-            for b in range(2 if reducer is not None else 1):
+            for b in range(2 if (reducer is not None or S > 1) else 1):
                 if reducer is not None:
                     bv = reducer.buffer_views(b)       # order of `params`: means3D, scales, rotations, opacities, colour | SH
                     sr.add_grad_outputs(means3D=bv[0], scales=bv[1], rotations=bv[2], opacities=bv[3],
@@ -300,19 +300,27 @@ def main():
         if reduce and reducer is not None:
             reducer.reduce(k)
 
+    chain_done = [None, None]
+
     def step_abi_group(i, reduce=True):
-        """S views of the shard in flight; their gradients accumulated in slot order into ONE set (N > 1: one all-reduce)."""
+        """S views of the shard in flight; their gradients accumulated in slot order into ONE of two alternating sets of arrays
+        (N > 1: the all-reducer's two buffers, one all-reduce per group).  No barrier between groups: slot 0, which overwrites a
+        set, waits for whatever last read it -- the all-reduce of two groups ago, or that group's chain end -- and the consumer
+        of the sum (the all-reduce) is queued on the LAST slot's stream; everything else runs ahead into the next group."""
         k = i & 1
-        if reduce:
-            reducer_wait(k)
-        out = k if reducer is not None else 0
-        sr.begin()
+        if reduce and reducer is not None:
+            reducer_wait(k)                               # (slot 0's stream is the current stream)
+        elif chain_done[k] is not None:
+            sr.slot_stream(0).wait_event(chain_done[k])
         for s in range(S):
             sr.forward((i * S + s) % n_my, slot=s)
-            sr.backward(out, slot=s, accumulate=s > 0, after=s - 1 if s else None)
-        sr.end()
+            sr.backward(k, slot=s, accumulate=s > 0, after=s - 1 if s else None)
         if reduce and reducer is not None:
-            reducer.reduce(k)
+            with torch.cuda.stream(sr.slot_stream(S - 1)):
+                reducer.reduce(k)
+        else:
+            chain_done[k] = torch.cuda.Event()
+            chain_done[k].record(sr.slot_stream(S - 1))
 
     # ---- 'surface': the drop-in autograd surface call by call ----------------------------------------------------
     # One GaussianRasterizer module per view (the reference builds one per render, module.py:623: ~10 us of nn.Module
@@ -672,8 +680,19 @@ def abi_views_in_flight(S, args, exa, params, use_sh, shape, D_max, view_st, dL_
                 sr.forward((i * S + s) % n_v, slot=s)
                 sr.backward(sets[0], slot=s, accumulate=s > 0, after=s - 1 if s else None)
             sr.end()
+        done = [None, None]
+
+        def pipelined(i):
+            k = i & 1
+            if done[k] is not None:
+                sr.slot_stream(0).wait_event(done[k])           # the set this group overwrites was completed two groups ago
+            for s in range(S):
+                sr.forward((i * S + s) % n_v, slot=s)
+                sr.backward(sets[k], slot=s, accumulate=s > 0, after=s - 1 if s else None)
+            done[k] = torch.cuda.Event()
+            done[k].record(sr.slot_stream(S - 1))
         out = {'views_in_flight': S}
-        for name, fn, per in (('independent', independent, 1), ('grouped', grouped, S)):
+        for name, fn, per in (('independent', independent, 1), ('grouped', grouped, S), ('grouped_pipelined', pipelined, S)):
             n = max(args.steps // per, 8) if per > 1 else max(args.steps, 8 * S)
             for i in range(40 * S // per):
                 fn(i)
@@ -688,7 +707,9 @@ def abi_views_in_flight(S, args, exa, params, use_sh, shape, D_max, view_st, dL_
         out['repairs'] = sr.repairs
         out['what'] = ('exa.StaticRender(slots=%d): plain launches through the C ABI on %d HIP streams; independent = every view fwd + bwd '
                        'into its slot\'s own gradient arrays; grouped = groups of %d views whose gradients are accumulated in slot order '
-                       'into one set (backward(accumulate=True, after=previous slot))' % (S, S, S))
+                       'into one set (backward(accumulate=True, after=previous slot)) with a barrier at every group end (what an optimizer '
+                       'step per group forces); grouped_pipelined = the same chains into two alternating sets without barriers (gradient '
+                       'accumulation, or the all-reduce of a group overlapping the next group: bench.py --views-in-flight)' % (S, S, S))
         return out
 
 

@@ -13,7 +13,7 @@ Not autograd: gradients land in the arrays given to (or allocated by) the object
 **Slots** (``slots=S``): S renders in flight, each with its own workspaces, images and HIP stream, sharing the inputs.  The
 binning chain of a render is latency-bound and its blends throughput-bound, so the views of a rank's shard (25 of them per
 epoch in the reference's configuration) overlap well: S = 4 renders ~45 % more views per second than one at a
-time.  ``backward(..., accumulate=True, after=slot)`` chains the small per-Gaussian kernels of a group of slots so that
+time (7 200 -> 10 400-10 600 it/s on C3).  ``backward(..., accumulate=True, after=slot)`` chains the small per-Gaussian kernels of a group of slots so that
 their gradients are ADDED into one set of arrays in a fixed order (the sum a trainer with a batch of views needs, bit-identical
 to rendering the views one after the other) while the heavy blend backwards overlap freely.
 
@@ -83,9 +83,9 @@ class StaticRender:
     ``means3D [P, 3]``, ``opacities [P, 1]``, ``scales [P, 3]``, ``rotations [P, 4]`` and ONE of ``colors_precomp [P, 3]`` /
     ``shs [P, M, 3]``: contiguous float32 tensors on one GPU whose STORAGE stays (update them in place; :meth:`rebind` for new ones).
     ``image_size = (H, W)``; ``capacity``: instances a slot's buffer holds (:func:`required_capacity` measures what a set of
-    cameras needs).  ``train``: keep the context a backward needs.  ``stream``: the ``torch.cuda.Stream`` slot 0 queues its calls
-    on (default: the current stream at construction); further slots own a stream each (:meth:`begin` / :meth:`end` order them
-    against slot 0's).  ``on_overflow``: ``'repair'`` | ``'raise'`` (module docstring)."""
+    cameras needs).  ``train``: keep the context a backward needs.  ``stream``: the caller's ``torch.cuda.Stream`` (default: the
+    current stream at construction): slot 0 queues its calls there, every further slot owns a stream;
+    :meth:`begin` / :meth:`end` / :meth:`join` order them against the caller's, :meth:`slot_stream` hands them out.  ``on_overflow``: ``'repair'`` | ``'raise'`` (module docstring)."""
 
     GRAD_NAMES = ('means3D', 'means2D', 'opacities', 'scales', 'rotations', 'colors_precomp', 'shs')
 
@@ -117,7 +117,12 @@ class StaticRender:
         for s in range(int(slots)):
             sl = _Slot()
             sl.index = s
+            # slot 0 queues on the caller's stream, every further slot owns one.  (All slots on streams of their own -- the
+            # caller's only coordinating -- was measured: five streams on the four hardware queues a process gets by default
+            # cost the independent form 12 %: 10 530 -> 9 230 it/s at S = 4.)
             sl.stream = self.stream if s == 0 else torch.cuda.Stream(device=self.device)
+            if sl.stream is not self.stream:
+                sl.stream.wait_stream(self.stream)        # (the inputs were written on the caller's stream)
             sl.stream_ptr = ctypes.c_void_p(sl.stream.cuda_stream)
             sl.capacity = cap
             sl.last_view = sl.tag = sl.need = None
@@ -312,16 +317,31 @@ class StaticRender:
 
     # ---- the calls ----------------------------------------------------------------------------------------------
     def begin(self):
-        """Slots 1.. start behind everything queued on slot 0's stream so far (parameters written by an optimizer step,
+        """Every slot starts behind everything queued on the caller's stream so far (parameters written by an optimizer step,
         image gradients by a loss).  No-op with one slot."""
-        for sl in self._slots[1:]:
-            sl.stream.wait_stream(self.stream)
+        for sl in self._slots:
+            if sl.stream is not self.stream:
+                sl.stream.wait_stream(self.stream)
 
     def end(self):
-        """Slot 0's stream continues behind everything queued on the other slots (their images / gradients may then be read
+        """The caller's stream continues behind everything queued on the slots (their images / gradients may then be read
         there).  No-op with one slot."""
-        for sl in self._slots[1:]:
-            self.stream.wait_stream(sl.stream)
+        for sl in self._slots:
+            if sl.stream is not self.stream:
+                self.stream.wait_stream(sl.stream)
+
+    def join(self, slot):
+        """The caller's stream (= slot 0's) continues behind ``slot``'s LAST BACKWARD only -- e.g. the last slot of an accumulation
+        chain (``backward(..., after=...)``), where the group's summed gradients are complete.  A caller that wants NO barrier
+        between groups coordinates on the slots' own streams instead (:meth:`slot_stream`): whatever consumes the sum is queued on
+        the last slot's stream, whatever frees the arrays is waited for on slot 0's (``bench.py --views-in-flight``)."""
+        sl = self._slots[slot]
+        if sl.bwd_done is not None:
+            self.stream.wait_event(sl.bwd_done)
+
+    def slot_stream(self, slot=0):
+        """The ``torch.cuda.Stream`` a slot queues its calls on."""
+        return self._slots[slot].stream
 
     def forward(self, view=0, slot=0):
         """Queue the forward of camera ``view`` on ``slot``: images, ``radii``, ``is_vis`` of that slot (:meth:`outputs`)."""

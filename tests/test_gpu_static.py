@@ -197,6 +197,28 @@ def test_static_slots_keep_views_in_flight_and_accumulate_in_order(dev):
                 want = _sum_in_order([refs[base + s][4][k] for s in range(S)])
                 assert torch.equal(got[k].view_as(want), want), (k, base)
             assert torch.equal(got['means2D'], refs[base + S - 1][4]['means2D'])        # per render: the last one's
+        # the same chains WITHOUT barriers between the groups: two sets of arrays alternate (as the two buffers of an all-reducer
+        # do); the consumer of a sum (here: a clone) is queued on the LAST slot's stream, and slot 0 -- which overwrites a set --
+        # waits for the consumer of that set's previous sum; everything else runs ahead into the next group
+        totals = [total, sr.add_grad_outputs()]
+        snaps, consumed = [], [None, None]
+        for i, base in enumerate((0, 3, 0, 3, 3, 0)):
+            k = i & 1
+            if consumed[k] is not None:
+                sr.slot_stream(0).wait_event(consumed[k])
+            for s in range(S):
+                sr.forward(views[base + s], slot=s)
+                sr.backward(totals[k], slot=s, accumulate=s > 0, after=s - 1 if s else None)
+            with torch.cuda.stream(sr.slot_stream(S - 1)):
+                snaps.append((base, {n: v.clone() for n, v in sr.grad_outputs(totals[k]).items()}))
+                consumed[k] = torch.cuda.Event()
+                consumed[k].record()
+        sr.check()
+        sr.join(S - 1)
+        for base, got in snaps:
+            for k in ('means3D', 'opacities', 'scales', 'rotations', 'colors_precomp'):
+                want = _sum_in_order([refs[base + s][4][k] for s in range(S)])
+                assert torch.equal(got[k].view_as(want), want), (k, base, 'pipelined')
 
 
 def test_static_render_repairs_an_overflow_inside_the_call(dev):
