@@ -352,3 +352,18 @@ def test_header_compiles_as_plain_c_and_cxx_and_links_against_the_library(tmp_pa
     env = dict(os.environ, LD_LIBRARY_PATH='/opt/rocm/lib:' + os.environ.get('LD_LIBRARY_PATH', ''))
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True, env=env).stdout.split()
     assert int(out[0]) == len(names) and int(out[1]) == _lib.load().exa_raster_version()
+
+
+def test_native_host_example_compiles_and_links(tmp_path):
+    """examples/native_host.c (plain C99 + HIP runtime API over include/exa_raster.h; run on the GPU by
+    tests/test_gpu_native_host.py) must build with gcc against the in-tree library -- no compute here."""
+    import shutil
+    import subprocess
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    if shutil.which('gcc') is None or not os.path.exists(os.path.join(rocm, 'include', 'hip', 'hip_runtime_api.h')):
+        pytest.skip('no gcc / HIP headers')
+    lib = os.path.join(ROOT, 'exavatar_release_amd', 'libexa_raster.so')
+    subprocess.run(['gcc', '-std=c99', '-O1', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(ROOT, 'include'),
+                    '-I', os.path.join(rocm, 'include'), os.path.join(ROOT, 'examples', 'native_host.c'), lib,
+                    '-L', os.path.join(rocm, 'lib'), '-lamdhip64', '-Wl,-rpath,' + os.path.join(rocm, 'lib'),
+                    '-o', str(tmp_path / 'native_host')], check=True)
