@@ -208,3 +208,68 @@ def test_five_live_contexts_and_retain_graph(dev):
     assert rz.compiled_calls - n0 == 5
     for x, y in zip(grads['off'], grads['auto']):
         assert torch.equal(x, y)
+
+
+def test_training_loop_through_the_compiled_node_equals_the_python_node(dev):
+    """A loop shaped like ``avatar/main/train.py:41-57`` with the reference's own structure -- FIVE single renders per iteration
+    (``avatar/main/model.py:130-162``: scene, human, cat(scene.detach(), human), refined, cat(scene.detach(), refined)), one
+    backward through all five live contexts, Adam, the Gaussian count of the scene changing every 25 iterations, the capacity memo
+    forgotten now and then (overflows repaired inside the call), a ``no_grad`` evaluation render every 10th iteration -- once
+    through the compiled node, once through the Python node: the same parameters bit for bit."""
+    H, W, f = 96, 128, 170.0
+    keys = ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')
+    scene0 = scenes.dist_a_random(1200, H, W, seed=31, focal=f)
+    human0 = scenes.dist_a_random(900, H, W, seed=32, focal=f, z_range=(2.0, 4.0))
+    cams = [{k: v.to(dev) for k, v in scenes.ring_camera(H, W, 5 * v, 40, radius=3.2, center=(0.0, 0.0, 3.0), focal=f).items()} for v in range(4)]
+    bg = torch.tensor([0.2, 0.5, 0.3], device=dev)
+    g = torch.Generator().manual_seed(9)
+    Gs = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(5)]
+    rend = exa.GaussianRenderer()
+
+    def run(how):
+        exa.config.compiled_node = how
+        exa.config.mode, exa.config.capacity_growth, exa.config.min_capacity = 'auto', 1.05, 64
+        rz._seen_D.clear()
+        n_ev = len(rz.overflow_events)
+        n0 = rz.compiled_calls
+        sets = [{k: torch.nn.Parameter(d[k].to(dev).clone()) for k in keys} for d in (scene0, human0, human0)]
+        make_opt = lambda: torch.optim.Adam([p for s_ in sets for p in s_.values()], lr=1e-3, eps=1e-15)      # noqa: E731
+        opt = make_opt()
+        losses, evals = [], []
+        for i in range(80):
+            cam = cams[(i * 3) % len(cams)]
+            if i % 13 == 12:
+                for key in list(rz._seen_D):
+                    rz._seen_D[key] = int(rz._seen_D[key] * 0.6)
+            scene, human, refined = sets
+            cat = lambda a_, b_: {k: torch.cat((a_[k].detach(), b_[k])) for k in keys}      # noqa: E731
+            outs = [rend(scene, (H, W), cam), rend(human, (H, W), cam, bg), rend(cat(scene, human), (H, W), cam),
+                    rend(refined, (H, W), cam, bg), rend(cat(scene, refined), (H, W), cam)]
+            loss = sum((o['img'] * G).sum() for o, G in zip(outs, Gs)) * 1e-3
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            with torch.no_grad():
+                for s_ in sets:
+                    s_['opacity'].clamp_(0.01, 0.99); s_['scale'].clamp_(1e-4, 1.0); s_['rgb'].clamp_(0.0, 1.0)
+            losses.append(float(loss.detach()))
+            if i % 10 == 9:
+                with torch.no_grad():
+                    evals.append(float(rend(human, (H, W), cam, bg)['img'].mean()))
+            if i % 25 == 24:                       # the scene grows / shrinks: new tensors, new P, a new optimizer
+                P = scene['mean_3d'].shape[0]
+                keep = torch.arange(P, device=dev) % 7 != (i // 25)
+                top = torch.arange(0, P, 5, device=dev)
+                sets[0] = {k: torch.nn.Parameter(torch.cat((v.detach()[keep], v.detach()[top] + (0.01 if k == 'mean_3d' else 0.0))).contiguous())
+                           for k, v in scene.items()}
+                opt = make_opt()
+        torch.cuda.synchronize()
+        return ([p.detach().clone() for s_ in sets for p in s_.values()], losses, evals, rz.compiled_calls - n0,
+                [e[3] for e in rz.overflow_events[n_ev:]] if len(rz.overflow_events) >= n_ev else [])
+    ref = run('off')
+    got = run('auto')
+    assert ref[3] == 0 and got[3] >= 80 * 5
+    assert got[1] == ref[1] and got[2] == ref[2]
+    for x, y in zip(got[0], ref[0]):
+        assert x.shape == y.shape and torch.equal(x, y)
+    assert 'retried' in got[4] and set(got[4]) == {'retried'}
