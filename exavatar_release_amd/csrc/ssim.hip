@@ -176,17 +176,12 @@ struct PhotoArgs {
     float* dL_dx;                      // [B, C, H, W] (only the crop window is written)
 };
 
-__device__ __forceinline__ float crop_load(const float* __restrict__ p, const float* __restrict__ m, int lx, int ly,
-                                           const PhotoArgs& a) {
-    if (lx < 0 || lx >= a.cw || ly < 0 || ly >= a.ch) return 0.0f;
-    const size_t o = (size_t)(a.cy0 + ly) * a.W + (a.cx0 + lx);
-    const float v = p[o];
-    return m ? v * m[o] : v;
-}
-
 __global__ __launch_bounds__(PBLOCK2) void photo_stats_kernel(PhotoArgs a, SsimWindow win) {
+    // LDS: the two halo tiles (14.4 KB) + the horizontally filtered statistics of ONE GROUP at a time (round 6: {mu1, mu2}, then
+    // {E11, E22, E12}: 16.6 KB instead of 27.7 for all five) = 31 KB per workgroup: five workgroups per CU instead of three.  The
+    // kernel is a chain of barrier-separated phases (load, horizontal, vertical): what it lacked was waves to overlap them.
     __shared__ float s_x[PI][PI + 1], s_y[PI][PI + 1];
-    __shared__ float s_h[5][PI][PT + 1];
+    __shared__ float s_h[3][PI][PT + 1];
     __shared__ float s_red[2][PBLOCK2 / 64];
     const int tid = threadIdx.x;
     const int n = blockIdx.z;                                   // plane = image * C + channel
@@ -195,48 +190,84 @@ __global__ __launch_bounds__(PBLOCK2) void photo_stats_kernel(PhotoArgs a, SsimW
     const float* __restrict__ py = a.y + plane;
     const float* __restrict__ pm = a.smask ? a.smask + mplane : nullptr;
     const int ox = blockIdx.x * PT - SR, oy = blockIdx.y * PT - SR;
-    for (int i = tid; i < PI * PI; i += PBLOCK2) {
-        const int ly = i / PI, lx = i - ly * PI;
-        s_x[ly][lx] = crop_load(px, pm, ox + lx, oy + ly, a);
-        s_y[ly][lx] = crop_load(py, pm, ox + lx, oy + ly, a);
-    }
-    __syncthreads();
-    // horizontal pass: PI rows x PT columns, four adjacent columns per item (14 LDS values feed 4 x 11 taps)
-    for (int i = tid; i < PI * (PT / 4); i += PBLOCK2) {
-        const int ly = i / (PT / 4), c0 = (i - ly * (PT / 4)) * 4;
-        float xv[14], yv[14];
+    // The halo tile: ALL of a thread's loads leave before the first one is waited for (addresses clamped into the crop window, the
+    // value zeroed afterwards where the tap lies outside: conv2d's zero padding) -- a load and the LDS store of its result in one
+    // loop body had compiled to seven serial round trips per workgroup.
+    {
+        constexpr int NLD = (PI * PI + PBLOCK2 - 1) / PBLOCK2;
+        float vx[NLD], vy[NLD], vm[NLD];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) { xv[k] = s_x[ly][c0 + k]; yv[k] = s_y[ly][c0 + k]; }
+        for (int u = 0; u < NLD; ++u) {
+            const int i = min(tid + u * PBLOCK2, PI * PI - 1);
+            const int ly = i / PI, lx = i - ly * PI;
+            const int gx = min(max(ox + lx, 0), a.cw - 1), gy = min(max(oy + ly, 0), a.ch - 1);
+            const size_t o = (size_t)(a.cy0 + gy) * a.W + (a.cx0 + gx);
+            vx[u] = px[o]; vy[u] = py[o];
+            vm[u] = pm ? pm[o] : 1.0f;
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 2 * SR + 1; ++k) {
-                const float wk = win.g[k], xx = xv[j + k], yy = yv[j + k];
-                m1 = fmaf(wk, xx, m1); m2 = fmaf(wk, yy, m2);
-                e11 = fmaf(wk, xx * xx, e11); e22 = fmaf(wk, yy * yy, e22); e12 = fmaf(wk, xx * yy, e12);
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * PBLOCK2;
+            if (i < PI * PI) {
+                const int ly = i / PI, lx = i - ly * PI;
+                const bool in = ox + lx >= 0 && ox + lx < a.cw && oy + ly >= 0 && oy + ly < a.ch;
+                s_x[ly][lx] = in ? (pm ? vx[u] * vm[u] : vx[u]) : 0.0f;
+                s_y[ly][lx] = in ? (pm ? vy[u] * vm[u] : vy[u]) : 0.0f;
             }
-            s_h[0][ly][c0 + j] = m1; s_h[1][ly][c0 + j] = m2; s_h[2][ly][c0 + j] = e11; s_h[3][ly][c0 + j] = e22;
-            s_h[4][ly][c0 + j] = e12;
         }
     }
     __syncthreads();
-    // vertical pass: thread = (column tx, rows 4 ty .. 4 ty + 3)
-    const int tx = tid & (PT - 1), ty = tid / PT;
+    const int tx = tid & (PT - 1), ty = tid / PT;               // vertical pass: thread = (column tx, rows 4 ty .. 4 ty + 3)
     float acc[4][5];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 5; ++q) acc[j][q] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 5; ++q) {
-        float v[14];
+    for (int grp = 0; grp < 2; ++grp) {
+        // horizontal pass: PI rows x PT columns in ONE sweep of the workgroup -- thread = (row tid % 42, column chunk tid / 42): six
+        // chunks of 6, 6, 5, 5, 5, 5 columns, 16 LDS values feed up to 6 x 11 taps (four columns per item had left the second of two
+        // sweeps with 80 of 256 threads at work); lanes of a wave read different rows: stride 43 words, conflict-free
+        if (tid < 6 * PI) {
+            const int ly = tid % PI, ch = tid / PI;
+            const int c0 = ch < 2 ? 6 * ch : 12 + 5 * (ch - 2), nc = ch < 2 ? 6 : 5;
+            float xv[16], yv[16];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) v[k] = s_h[q][ty * 4 + k][tx];
+            for (int k = 0; k < 16; ++k) { xv[k] = s_x[ly][min(c0 + k, PI - 1)]; yv[k] = s_y[ly][min(c0 + k, PI - 1)]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 6; ++j) {
+                if (j >= nc) break;
+                if (grp == 0) {
+                    float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 2 * SR + 1; ++k) acc[j][q] = fmaf(win.g[k], v[j + k], acc[j][q]);
+                    for (int k = 0; k < 2 * SR + 1; ++k) {
+                        const float wk = win.g[k];
+                        m1 = fmaf(wk, xv[j + k], m1); m2 = fmaf(wk, yv[j + k], m2);
+                    }
+                    s_h[0][ly][c0 + j] = m1; s_h[1][ly][c0 + j] = m2;
+                } else {
+                    float e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 2 * SR + 1; ++k) {
+                        const float wk = win.g[k], xx = xv[j + k], yy = yv[j + k];
+                        e11 = fmaf(wk, xx * xx, e11); e22 = fmaf(wk, yy * yy, e22); e12 = fmaf(wk, xx * yy, e12);
+                    }
+                    s_h[0][ly][c0 + j] = e11; s_h[1][ly][c0 + j] = e22; s_h[2][ly][c0 + j] = e12;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (grp == 0 ? 2 : 3); ++q) {
+            float v[14];
+#pragma unroll
+            for (int k = 0; k < 14; ++k) v[k] = s_h[q][ty * 4 + k][tx];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 2 * SR + 1; ++k) acc[j][grp * 2 + q] = fmaf(win.g[k], v[j + k], acc[j][grp * 2 + q]);
+        }
+        if (grp == 0) __syncthreads();                          // the second group overwrites s_h
     }
     float sum_ssim = 0.f, sum_l1 = 0.f;
     const int lx = blockIdx.x * PT + tx;
@@ -273,37 +304,33 @@ __global__ __launch_bounds__(PBLOCK2) void photo_stats_kernel(PhotoArgs a, SsimW
 }
 
 __global__ __launch_bounds__(PBLOCK2) void photo_grad_kernel(PhotoArgs a, SsimWindow win) {
+    // (round 6) the horizontally filtered maps go through LDS ONE at a time: 21.7 + 5.5 KB instead of 21.7 + 16.6 per workgroup, five
+    // workgroups per CU instead of four
     __shared__ float s_in[3][PI][PI + 1];
-    __shared__ float s_h[3][PI][PT + 1];
+    __shared__ float s_h[PI][PT + 1];
     const int tid = threadIdx.x;
     const int n = blockIdx.z;
     const size_t plane = (size_t)n * a.H * a.W, mplane = (size_t)(n / a.C) * a.H * a.W;
     const size_t map_plane = (size_t)a.cw * a.ch, n_planes = (size_t)gridDim.z;
     const int ox = blockIdx.x * PT - SR, oy = blockIdx.y * PT - SR;
-    for (int i = tid; i < PI * PI; i += PBLOCK2) {
-        const int ly = i / PI, lx = i - ly * PI;
-        const int x = ox + lx, y = oy + ly;
-        float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-        if (x >= 0 && x < a.cw && y >= 0 && y < a.ch) {
+    {   // all loads of the halo tiles up front, unconditional (clamped addresses, zeroed outside the window): see photo_stats_kernel
+        constexpr int NLD = (PI * PI + PBLOCK2 - 1) / PBLOCK2;
+        float v0[NLD], v1[NLD], v2[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = min(tid + u * PBLOCK2, PI * PI - 1);
+            const int ly = i / PI, lx = i - ly * PI;
+            const int x = min(max(ox + lx, 0), a.cw - 1), y = min(max(oy + ly, 0), a.ch - 1);
             const size_t o = (size_t)n * map_plane + (size_t)y * a.cw + x;
-            m0 = a.maps[o]; m1 = a.maps[n_planes * map_plane + o]; m2 = a.maps[2 * n_planes * map_plane + o];
+            v0[u] = a.maps[o]; v1[u] = a.maps[n_planes * map_plane + o]; v2[u] = a.maps[2 * n_planes * map_plane + o];
         }
-        s_in[0][ly][lx] = m0; s_in[1][ly][lx] = m1; s_in[2][ly][lx] = m2;
-    }
-    __syncthreads();
-    for (int i = tid; i < PI * (PT / 4); i += PBLOCK2) {
-        const int ly = i / (PT / 4), c0 = (i - ly * (PT / 4)) * 4;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float v[14];
-#pragma unroll
-            for (int k = 0; k < 14; ++k) v[k] = s_in[q][ly][c0 + k];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < 2 * SR + 1; ++k) s = fmaf(win.g[k], v[j + k], s);
-                s_h[q][ly][c0 + j] = s;
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + u * PBLOCK2;
+            if (i < PI * PI) {
+                const int ly = i / PI, lx = i - ly * PI;
+                const bool in = ox + lx >= 0 && ox + lx < a.cw && oy + ly >= 0 && oy + ly < a.ch;
+                s_in[0][ly][lx] = in ? v0[u] : 0.f; s_in[1][ly][lx] = in ? v1[u] : 0.f; s_in[2][ly][lx] = in ? v2[u] : 0.f;
             }
         }
     }
@@ -314,13 +341,30 @@ __global__ __launch_bounds__(PBLOCK2) void photo_grad_kernel(PhotoArgs a, SsimWi
     for (int j = 0; j < 4; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
+        if (tid < 6 * PI) {                                     // one sweep: thread = (row, column chunk), as in photo_stats_kernel
+            const int ly = tid % PI, ch = tid / PI;
+            const int c0 = ch < 2 ? 6 * ch : 12 + 5 * (ch - 2), nc = ch < 2 ? 6 : 5;
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = s_in[q][ly][min(c0 + k, PI - 1)];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                if (j >= nc) break;
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * SR + 1; ++k) sum = fmaf(win.g[k], v[j + k], sum);
+                s_h[ly][c0 + j] = sum;
+            }
+        }
+        __syncthreads();
         float v[14];
 #pragma unroll
-        for (int k = 0; k < 14; ++k) v[k] = s_h[q][ty * 4 + k][tx];
+        for (int k = 0; k < 14; ++k) v[k] = s_h[ty * 4 + k][tx];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 2 * SR + 1; ++k) acc[j][q] = fmaf(win.g[k], v[j + k], acc[j][q]);
+        if (q < 2) __syncthreads();                             // the next map overwrites s_h
     }
     const int lx = blockIdx.x * PT + tx;
 #pragma unroll
