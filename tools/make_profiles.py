@@ -51,6 +51,9 @@ with open(os.path.join(out, prefix + '_bench.json'), 'w') as f:
 
 # ---- kernel stats ----------------------------------------------------------------------------------------
 stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
+if len(stats) > 1:
+    sys.exit('make_profiles: %s holds the output of more than one lease (%d kernel_stats files): gpurun MERGES into gpurun_out/ -- '
+             'remove the directory before running tools/profile_round.sh again' % (src, len(stats)))
 _ks = os.path.join(out, prefix + '_kernel_stats.md')
 _tail = ''            # hand-written sections ("## ...") of an existing summary survive a regeneration
 if os.path.exists(_ks):
