@@ -45,7 +45,7 @@ def _to(d, dev, grad=True):
     return {k: v.to(dev).requires_grad_(grad) for k, v in d.items()}
 
 
-# EXA_FUZZ_TRIALS=n widens the seeded fuzz (round 5 ran it once with 300 seeds: profiles/r05_fuzz_300.log)
+# EXA_FUZZ_TRIALS=n widens the seeded fuzz (rounds 5 and 6 ran it once with 300 seeds: profiles/r06_fuzz_300.log)
 @pytest.mark.parametrize('trial', range(int(os.environ.get('EXA_FUZZ_TRIALS', '16'))))
 def test_edge_case_fuzz_through_the_hip_path(dev, trial):
     """The 16 seeded trials of tests/test_c_oracle.py::test_edge_case_fuzz_* through GaussianRenderer: opacity 0 / 1 / at
