@@ -272,7 +272,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void cell_scan_kernel(Batch<BinArgs> 
         w.header->num_instances = (uint32_t)ti_tot;
         w.header->num_tile_instances = (uint32_t)tiles_tot;
     }
-    if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+    for (int i = tid; i < XCD_REGIONS * ORDER_CLASSES; i += SCAN_THREADS) w.cls_cur[i] = 0u;
             if (tid < 4) w.bwd_meta[tid] = 0u;
     __syncthreads();                                             // cell_off (all of it) visible to the whole workgroup
     write_cell_order(w, cells, [&](int c) { return (uint32_t)((c == tid ? v0 : w.cell_cnt[c]) >> 32); });
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(SC_BLOCK) void cell_scatter_kernel(Batch<BinArgs> b
                 w.header->num_tile_instances = (uint32_t)(vt >> 32);
                 if (a.host_hdr) report_header(a.host_hdr, D, (uint64_t)D > capacity ? 1u : 0u, vis_total, a.hdr_tag);
             }
-            if (tid < ORDER_CLASSES) w.cls_cur[tid] = 0u;
+            for (int i = tid; i < XCD_REGIONS * ORDER_CLASSES; i += SC_BLOCK) w.cls_cur[i] = 0u;
             if (tid < 4) w.bwd_meta[tid] = 0u;
             __syncthreads();                                     // cell_off (all of it) visible to the whole workgroup
             write_cell_order(w, cells, [&](int c) { return (uint32_t)(s_tot[c] >> 32); });
@@ -624,7 +624,10 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
     // process at its next runtime call) when it has not -- the round-4 GPUTEST abort.
     if (!cp.active || cp.overflow) {
         if (cp.part == 0) {
-            if (threadIdx.x < SUBS_PER_CELL) w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+            if (threadIdx.x < SUBS_PER_CELL) {
+                w.ranges[cp.cell * SUBS_PER_CELL + threadIdx.x] = make_uint2(0u, 0u);
+                w.cls_code[cp.cell * SUBS_PER_CELL + threadIdx.x] = (uint8_t)0;
+            }
             if (threadIdx.x == 0) w.cell_long[cp.rank] = 0u;
         }
         return;
@@ -653,6 +656,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_bin_kernel(Batch<BinArgs>
             const unsigned long long longer = __ballot(n > (uint32_t)BATCH);
             if (tid == 0) w.cell_long[cp.rank] = (uint32_t)__popcll(longer);
             w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
+            w.cls_code[cell * SUBS_PER_CELL + tid] = (uint8_t)length_class(n);
             for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
                 b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
         }
@@ -683,7 +687,10 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
     const CellPart cp = cell_part<1>(w, a.capacity);
     const int cell = cp.cell, tid = threadIdx.x;
     if (!cp.active) {                                                   // empty cell: 64 empty ranges
-        if (tid < SUBS_PER_CELL) w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(0u, 0u);
+        if (tid < SUBS_PER_CELL) {
+            w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(0u, 0u);
+            w.cls_code[cell * SUBS_PER_CELL + tid] = (uint8_t)0;
+        }
         if (tid == 0) w.cell_long[blockIdx.x] = 0u;
         return;
     }
@@ -711,6 +718,7 @@ __global__ __launch_bounds__(BIN_THREADS) void subtile_count_bin_kernel(Batch<Bi
         const unsigned long long longer = __ballot(n > (uint32_t)BATCH);
         if (tid == 0) w.cell_long[blockIdx.x] = (uint32_t)__popcll(longer);
         w.ranges[cell * SUBS_PER_CELL + tid] = make_uint2(begin, begin + n);
+        w.cls_code[cell * SUBS_PER_CELL + tid] = (uint8_t)length_class(n);
         for (uint32_t bq = 0; bq + 1 < nslot; ++bq)
             b.owner[begin / BATCH + bq] = make_uint4((uint32_t)(cell * SUBS_PER_CELL + tid) + 1u, begin, n, 0u);
     }

@@ -23,7 +23,7 @@ constexpr int SUBS_PER_CELL = CELL_SUBS * CELL_SUBS;   // 64
 constexpr int BLOCK = 256;                 // threads per workgroup (4 waves)
 constexpr int CHUNK = 1024;                // Gaussians per workgroup in the per-Gaussian binning kernels
 constexpr int MAX_CELLS = 4096;            // LDS histogram budget (48 KiB of counters) -> images up to 4096x4096
-constexpr int HEADER_BYTES = 512;      // ExaRasterHeader at 0, length-class cursors at 256
+constexpr int HEADER_BYTES = 2560;     // ExaRasterHeader at 0, backward-order words at 128, launch-order cursors [8 regions][64 classes] at 256
 
 // Batched launches: every kernel takes up to MAX_BATCH independent jobs (renders) by value in its kernel arguments and
 // picks its own with blockIdx.y -- K views / K renders of one training iteration cost ONE launch per stage instead
@@ -138,7 +138,7 @@ __host__ __device__ inline int num_chunks(int P) { return (P + CHUNK - 1) / CHUN
 constexpr int BIN_PARTS = EXA_BIN_PARTS;   // workgroups per cell in the sub-tile binning (binning.hip)
 struct TileWs {
     ExaRasterHeader* header;          // [1]          written by cell_scan_kernel
-    uint32_t* cls_cur;                // [64]  launch-order slots handed out per list-length class (zeroed by cell_scan)
+    uint32_t* cls_cur;                // [8][64]  launch-order slots handed out per (XCD region, list-length class) (zeroed by cell_scan)
     uint32_t* bwd_meta;               // [4]   launch order of the backward blend (render_fwd.hip order_slots writes it, in the
                                       //       sort launch: {batches in the main order, batches appended behind it, BWD_ORDER_MAGIC});
                                       //       the order itself lives in the bucket array of the bin workspace, dead by then
@@ -166,6 +166,8 @@ struct TileWs {
     uint4* part_desc;                 // [cells * BIN_PARTS]  work record of every such workgroup: {cell | rank << 12 |
                                       //              part << 24 | (parts - 1) << 28, first entry, end entry, first slot of the
                                       //              cell}; x = NO_PART for the workgroups beyond the sum (binning.hip)
+    uint8_t* cls_code;                // [subtiles]   length_class of every list, written next to `ranges`: what the ordering
+                                      //              workgroups of the sort launch histogram (16 lists per load, no indirection)
 };
 __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
     return HEADER_BYTES + align256(uint64_t(chunks) * cells * 8) + align256(uint64_t(cells) * 8) +
@@ -173,7 +175,7 @@ __host__ __device__ inline uint64_t tile_ws_bytes(int cells, int chunks) {
            align256(uint64_t(cells) * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * SUBS_PER_CELL * 16) + align256(uint64_t(cells) * SUBS_PER_CELL * 8) +
            align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4) + align256(uint64_t(cells) * 4) +
-           align256(uint64_t(cells) * BIN_PARTS * 16);
+           align256(uint64_t(cells) * BIN_PARTS * 16) + align256(uint64_t(cells) * SUBS_PER_CELL);
 }
 __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunks) {
     char* p = static_cast<char*>(base);
@@ -195,7 +197,8 @@ __host__ __device__ inline TileWs carve_tile_ws(void* base, int cells, int chunk
     w.fwd_exit = reinterpret_cast<uint2*>(p); p += align256(uint64_t(cells) * SUBS_PER_CELL * 8);
     w.part_cnt = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * BIN_PARTS * SUBS_PER_CELL * 4);
     w.cell_long = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(cells) * 4);
-    w.part_desc = reinterpret_cast<uint4*>(p);
+    w.part_desc = reinterpret_cast<uint4*>(p); p += align256(uint64_t(cells) * BIN_PARTS * 16);
+    w.cls_code = reinterpret_cast<uint8_t*>(p);
     return w;
 }
 
@@ -258,6 +261,17 @@ __host__ __device__ inline PartialWs carve_grad_ws(void* base, uint64_t) {
 // size class instead of a random draw (measured on C3: the busiest SIMD had 2.06x the mean work with a
 // cell-major order, and that SIMD set the kernel time).
 constexpr int ORDER_CLASSES = 64;
+// XCD region of a sub-tile (render_fwd.hip order_slots): `local` = its index inside the 8 x 8 sub-tiles of its cell.  A cell is
+// cut into eight blocks of 2 x 4 sub-tiles (16 x 32 px), one per region, the same pattern in every cell: eight sub-tiles per
+// region and cell exactly, so every region owns subtiles / 8 launch positions.  (Measured against 2 x 2 blocks dealt two per
+// region and cell: C3 render_fwd FETCH 21.2 -> 18.1 MB, render_bwd 27.4 -> 25.7 MB, times equal; larger blocks cannot keep the
+// per-cell balance.)
+#ifndef EXA_XCD_REGIONS
+#define EXA_XCD_REGIONS 8            // 1 (build-time, tools/build_variant.sh): ONE length-sorted stream, the order of rounds 2-5
+#endif
+constexpr int XCD_REGIONS = EXA_XCD_REGIONS;
+static_assert(XCD_REGIONS == 8 || XCD_REGIONS == 1, "eight XCDs, or no regions at all");
+__device__ __forceinline__ int xcd_region(int local) { return XCD_REGIONS == 8 ? ((local >> 1) & 3) | ((local >> 3) & 4) : 0; }
 constexpr uint32_t BWD_ORDER_MAGIC = 0xB07DE7EDu;
 constexpr int BWD_ORDER_DEPTH = 16;       // batches of a list that take part in the batch-major order (class 63 = 16 batches or more)
 __device__ __forceinline__ int length_class(uint32_t n) { return n ? min(ORDER_CLASSES - 1, (int)((n + 15) / 16)) : 0; }

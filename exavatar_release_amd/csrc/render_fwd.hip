@@ -279,73 +279,123 @@ __device__ __forceinline__ void rank_sort_list(const unsigned long long* __restr
         if (first + r * SBLOCK + tid < n) sorted[rank[r]] = (uint32_t)mine[r];
 }
 
-// ---- launch order of the forward blend (see length_class in common.h) ------------------------------------
+// ---- launch order of the forward blend (see length_class / xcd_region in common.h) -------------------------
 // Runs as the first ORDER_WGS workgroups of the sort launch, i.e. concurrently with the sorting and off the
-// critical path.  Every ordering workgroup histograms the list-length classes of the sub-tiles of all active cells,
-// then ranks its own share inside LDS, reserves one contiguous range per class with a single device atomic, and
+// critical path.  Every ordering workgroup histograms the (XCD region, list-length class) bins of the sub-tiles of all
+// active cells, then ranks its own share inside LDS, reserves one contiguous range per bin with a single device atomic, and
 // writes the records.
-constexpr int ORDER_WGS = 16;
-constexpr int ORDER_U = 8;       // ranges in flight per thread while counting (16 cost the KEEP sort 32 VGPRs = a wave per SIMD)
+//
+// XCD-AWARE ORDER.  Workgroup b of a launch runs on XCD b mod 8 and every XCD has its own L2.  A splat record is shared by the
+// ~4 neighbouring sub-tiles it reaches; one length-sorted sequence deals those neighbours to different XCDs, so the record
+// comes in from beyond L2 once per sub-tile (and the backward's 40-byte partial records and `touched` bytes, which neighbours
+// write into the same 32-byte sectors, are written back once per XCD).  The order is therefore EIGHT interleaved
+// length-sorted streams: sub-tile st belongs to region xcd_region(st) (blocks of 2 x 4 sub-tiles: every 64 x 64 cell gives
+// exactly eight sub-tiles to every region), and the k-th sub-tile of region x in descending list length sits at
+// position 8 k + x.  Every region owns exactly subtiles / 8 positions, so the records stay a permutation; heavy-first holds
+// inside every XCD, which is where it matters (an XCD's waves are dispatched in launch order).
+constexpr int ORDER_WGS = 32;
+constexpr int ORDER_BINS = XCD_REGIONS * ORDER_CLASSES;
+constexpr int ORDER_LDS_WORDS = 3 * ORDER_BINS + XCD_REGIONS * (BWD_ORDER_DEPTH + 1);
 // The same workgroups write the launch order of the BACKWARD blend (one wave per 64-entry batch, render_bwd.hip):
 // batch-major -- the first batches of all lists, longest list first, then all second batches, ... -- which is heavy first
 // without knowing the blended counts: the front batches of a list are the ones whose entries get blended, the deep ones
 // the forward often does not even enter.  In slot order the launch ended with whatever the last cells held (a full batch
 // takes 18 us at five waves per SIMD, started as late as 35 us in) and spent a third of its dispatches on slots without
-// work (end slots, padding: 14 k of 24 k).  Position of batch b of the list at descending position p: B_b + p, with
-// B_b = sum over b' < b of the number of lists with more than b' batches -- all from the class histogram, no sort.
-// Batches from BWD_ORDER_DEPTH on (lists of > 1024 entries) are appended behind through a counter.
+// work (end slots, padding: 14 k of 24 k).  Per region x: position of batch b of the list at descending rank k = 8 (B_b + k) + x,
+// with B_b = sum over b' < b of the number of the region's lists with more than b' batches -- all from the histogram, no
+// sort.  The regions' streams differ in length by a few per cent: row kb of the interleaved streams holds only the streams
+// longer than kb, i.e. batch kb of region x sits at sum over x' of min(M_x', kb) + (number of x' < x with M_x' > kb) -- 8 kb + x
+// while every stream is alive, a bijection onto [0, sum M) always (the rows behind the shortest stream's end lose the
+// alignment with the XCDs, nothing else).  Batches from BWD_ORDER_DEPTH on (lists of > 1024 entries) are appended behind
+// through a counter.
 template <typename RangeOf>       // RangeOf(st) -> [begin, end) of sub-tile st's list; the records hold what it returns
-__device__ __forceinline__ void order_slots(const TileWs& w, uint32_t* __restrict__ bwd_order, int subtiles, int part, int tid, RangeOf range_of) {
-    __shared__ uint32_t s_off[ORDER_CLASSES], s_cnt[ORDER_CLASSES], s_base[ORDER_CLASSES];
-    __shared__ uint32_t s_bbase[BWD_ORDER_DEPTH + 1];
+__device__ __forceinline__ void order_slots(const TileWs& w, uint32_t* __restrict__ bwd_order, int subtiles, int part, int tid,
+                                            uint32_t* __restrict__ lds, RangeOf range_of) {
+    // (LDS lent by the caller: the sort's own buffers -- arrays of its own would cost the sort kernel its sixth wave per SIMD)
+    uint32_t* const s_off = lds;                                  // [region][class] sub-tiles of the region in longer classes
+    uint32_t* const s_cnt = lds + ORDER_BINS;
+    uint32_t* const s_base = lds + 2 * ORDER_BINS;
+    uint32_t* const s_bbase = lds + 3 * ORDER_BINS;               // [region][BWD_ORDER_DEPTH + 1]
     const int lane = tid & 63;
-    // Histogram over the sub-tiles of the ACTIVE cells only (cell_desc lists them first; an avatar view: 70 of 256): the
-    // others are empty, the empty class comes last in the order and its count enters no offset.  (These workgroups used
-    // to walk all ranges of the image in eight dependent trips and were the longest of the launch.)
-    if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
+#ifdef EXA_PROBE_SORTLINE  // probe build only (tools/gpu_sort_timeline.py): the phases of every ordering workgroup, 100 MHz clock
+#define ORDER_STAMP(ph) do { if (tid == 0) w.part_cnt[2 * (subtiles + ORDER_WGS) + part * 8 + (ph)] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define ORDER_STAMP(ph) do {} while (0)
+#endif
+    ORDER_STAMP(0);
+    // Histogram over ALL sub-tiles from the class codes the binning left next to the ranges: sixteen lists per 16-byte load,
+    // one round trip per 16 384 sub-tiles.  (Until round 6: the ranges of the active cells, found through cell_desc -- two
+    // dependent loads per trip, three trips for an avatar view, 5.9 of the 9.5 us these workgroups ran.)
+    for (int i = tid; i < ORDER_BINS; i += SBLOCK) s_cnt[i] = 0u;
     __syncthreads();
-    const int counted = min(subtiles, (int)w.header->active_cells * SUBS_PER_CELL);
-    const bool every = counted == subtiles;                     // content everywhere (C5): no indirection through cell_desc
-    for (int base = 0; base < counted; base += SBLOCK * ORDER_U) {
-        uint32_t cell[ORDER_U];
-        uint2 r[ORDER_U];
+    const uint4* __restrict__ codes = reinterpret_cast<const uint4*>(w.cls_code);
+    const int n16 = subtiles / 16;
+    for (int base = 0; base < n16; base += SBLOCK * 4) {
+        uint4 v[4];
 #pragma unroll
-        for (int i = 0; i < ORDER_U; ++i) {
+        for (int i = 0; i < 4; ++i) {
             const int idx = base + i * SBLOCK + tid;
-            cell[i] = (uint32_t)(idx >> 6);
-            if (!every && idx < counted) cell[i] = w.cell_desc[idx >> 6].x;
+            v[i] = idx < n16 ? codes[idx] : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
-        for (int i = 0; i < ORDER_U; ++i) {
-            const int idx = base + i * SBLOCK + tid;
-            r[i] = idx < counted ? range_of((int)cell[i] * SUBS_PER_CELL + (idx & 63)) : make_uint2(0u, 0u);
-        }
+        for (int i = 0; i < 4; ++i) {
+            const int idx = base + i * SBLOCK + tid;                 // sub-tiles 16 idx .. 16 idx + 15: a quarter of a cell
+            const uint32_t word[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            if ((word[0] | word[1] | word[2] | word[3]) == 0u) continue;
 #pragma unroll
-        for (int i = 0; i < ORDER_U; ++i) {
-            const int cls = length_class(r[i].y - r[i].x);
-            if (cls) atomicAdd(&s_cnt[cls], 1u);
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t cls = (word[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                if (cls) atomicAdd(&s_cnt[xcd_region((idx & 3) * 16 + j) * ORDER_CLASSES + cls], 1u);
+            }
         }
     }
     __syncthreads();
-    if (tid < 64) {       // exclusive prefix of the histogram, longest class first, class 0 (empty) last
-        const int cls = tid == 63 ? 0 : 63 - tid;
-        uint32_t v = s_cnt[cls], incl = v;
+    ORDER_STAMP(1);
+    // per region: exclusive prefix of the histogram, longest class first, class 0 (empty) last; a wave takes two regions
+    // (side by side: the twelve shuffles of one region are a dependent chain)
+    {
+        constexpr int RPW = (XCD_REGIONS + SBLOCK / 64 - 1) / (SBLOCK / 64);       // regions per wave
+        const int cls = lane == 63 ? 0 : 63 - lane;
+        uint32_t v[RPW], incl[RPW];
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int x = (tid >> 6) + j * (SBLOCK / 64);
+            v[j] = incl[j] = x < XCD_REGIONS ? s_cnt[x * ORDER_CLASSES + cls] : 0u;
+        }
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const uint32_t o = __shfl_up(incl[j], d, 64);
+                if (lane >= d) incl[j] += o;
+            }
         }
-        s_off[cls] = incl - v;
-        s_cnt[cls] = 0u;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int x = (tid >> 6) + j * (SBLOCK / 64);
+            if (x < XCD_REGIONS) s_off[x * ORDER_CLASSES + cls] = incl[j] - v[j];
+        }
     }
     __syncthreads();
-    if (tid == 0) {       // lists with more than b batches = lists of a class above 4 b = s_off[4 b]
+    for (int i = tid; i < ORDER_BINS; i += SBLOCK) s_cnt[i] = 0u;
+    if (tid < XCD_REGIONS) {   // lists of the region with more than b batches = lists of a class above 4 b = s_off[4 b]
+        uint32_t more[BWD_ORDER_DEPTH];                           // (all loads first: a store in between would order them)
+#pragma unroll
+        for (int b = 0; b < BWD_ORDER_DEPTH; ++b) more[b] = s_off[tid * ORDER_CLASSES + 4 * b];
         uint32_t run = 0u;
-        for (int b = 0; b < BWD_ORDER_DEPTH; ++b) { s_bbase[b] = run; run += s_off[4 * b]; }
-        s_bbase[BWD_ORDER_DEPTH] = run;
-        if (part == 0) { w.bwd_meta[0] = run; w.bwd_meta[2] = bwd_order ? BWD_ORDER_MAGIC : 0u; }
+#pragma unroll
+        for (int b = 0; b < BWD_ORDER_DEPTH; ++b) { s_bbase[tid * (BWD_ORDER_DEPTH + 1) + b] = run; run += more[b]; }
+        s_bbase[tid * (BWD_ORDER_DEPTH + 1) + BWD_ORDER_DEPTH] = run;
     }
     __syncthreads();
+    uint32_t M[XCD_REGIONS];                                      // batches in every region's stream
+#pragma unroll
+    for (int x = 0; x < XCD_REGIONS; ++x) M[x] = s_bbase[x * (BWD_ORDER_DEPTH + 1) + BWD_ORDER_DEPTH];
+    uint32_t m_min = M[0], deep_base = M[0];                      // deep_base: first position behind the eight streams
+#pragma unroll
+    for (int x = 1; x < XCD_REGIONS; ++x) { m_min = min(m_min, M[x]); deep_base += M[x]; }
+    if (part == 0 && tid == 0) { w.bwd_meta[0] = deep_base; w.bwd_meta[2] = bwd_order ? BWD_ORDER_MAGIC : 0u; }
+    ORDER_STAMP(2);
     const int per = (subtiles + ORDER_WGS - 1) / ORDER_WGS;
     const int lo = part * per, hi = min(subtiles, lo + per);
     for (int base = lo; base < hi; base += SBLOCK * 4) {
@@ -358,44 +408,70 @@ __device__ __forceinline__ void order_slots(const TileWs& w, uint32_t* __restric
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const bool valid = base + i * SBLOCK + tid < hi;
-            const int cls = length_class(r[i].y - r[i].x);
-            const unsigned long long empty = __ballot(valid && cls == 0);
-            rank[i] = 0;
-            if (cls) rank[i] = atomicAdd(&s_cnt[cls], 1u);
-            else if (empty) {       // one LDS atomic per wave for the (many) empty sub-tiles
-                const int leader = __ffsll((long long)empty) - 1;
-                uint32_t b0 = 0;
-                if (lane == leader) b0 = atomicAdd(&s_cnt[0], (uint32_t)__popcll(empty));
-                b0 = (uint32_t)__shfl((int)b0, leader, 64);
-                rank[i] = b0 + (uint32_t)__popcll(empty & ((1ull << lane) - 1ull));
+            const int st = base + i * SBLOCK + tid;
+            const bool valid = st < hi;
+            const int cls = length_class(r[i].y - r[i].x), x = xcd_region(st & 63);
+            // the (many) empty sub-tiles: one LDS atomic per wave and region, all regions' leaders in the same instruction
+            const bool is_empty = valid && cls == 0;
+            unsigned long long mine = 0ull;                     // the empty lanes of this lane's region
+#pragma unroll
+            for (int xr = 0; xr < XCD_REGIONS; ++xr) {
+                const unsigned long long m = __ballot(is_empty && x == xr);
+                if (x == xr) mine = m;
             }
+            const int leader = is_empty ? __ffsll((long long)mine) - 1 : lane;
+            uint32_t b0 = 0u;
+            if (cls) b0 = atomicAdd(&s_cnt[x * ORDER_CLASSES + cls], 1u);
+            else if (is_empty && lane == leader) b0 = atomicAdd(&s_cnt[x * ORDER_CLASSES], (uint32_t)__popcll(mine));
+            b0 = (uint32_t)__shfl((int)b0, leader, 64);
+            rank[i] = b0 + (is_empty ? (uint32_t)__popcll(mine & ((1ull << lane) - 1ull)) : 0u);
+        }
+        ORDER_STAMP(3);
+        __syncthreads();
+        {   // one device atomic per bin this workgroup holds anything of (all of a thread's requests in flight together)
+            constexpr int BPT = (ORDER_BINS + SBLOCK - 1) / SBLOCK;
+            uint32_t c[BPT], got[BPT];
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) c[j] = j * SBLOCK + tid < ORDER_BINS ? s_cnt[j * SBLOCK + tid] : 0u;
+#pragma unroll
+            for (int j = 0; j < BPT; ++j) got[j] = c[j] ? atomicAdd(&w.cls_cur[j * SBLOCK + tid], c[j]) : 0u;
+#pragma unroll
+            for (int j = 0; j < BPT; ++j)
+                if (j * SBLOCK + tid < ORDER_BINS) s_base[j * SBLOCK + tid] = s_off[j * SBLOCK + tid] + got[j];
         }
         __syncthreads();
-        if (tid < ORDER_CLASSES) {
-            const uint32_t c = s_cnt[tid];
-            s_base[tid] = s_off[tid] + (c ? atomicAdd(&w.cls_cur[tid], c) : 0u);
-        }
-        __syncthreads();
+        ORDER_STAMP(4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int st = base + i * SBLOCK + tid;
             if (st < hi) {
-                const int cls = length_class(r[i].y - r[i].x);
-                const uint32_t pos = s_base[cls] + rank[i];
-                w.slots[pos] = make_uint4(r[i].x, r[i].y, (uint32_t)st, 0u);
+                const int cls = length_class(r[i].y - r[i].x), x = xcd_region(st & 63);
+                const uint32_t k = s_base[x * ORDER_CLASSES + cls] + rank[i];        // rank inside the region's stream
+                w.slots[k * XCD_REGIONS + x] = make_uint4(r[i].x, r[i].y, (uint32_t)st, 0u);
                 const uint32_t nb = (r[i].y - r[i].x + BATCH - 1) / BATCH, slot0 = r[i].x / BATCH;
                 for (uint32_t b = 0; bwd_order && b < nb; ++b) {
-                    const uint32_t q = b < (uint32_t)BWD_ORDER_DEPTH ? s_bbase[b] + pos
-                                                                     : s_bbase[BWD_ORDER_DEPTH] + atomicAdd(&w.bwd_meta[1], 1u);
+                    uint32_t q;
+                    if (b < (uint32_t)BWD_ORDER_DEPTH) {          // row kb of the interleaved streams, compacted over the ended ones
+                        const uint32_t kb = s_bbase[x * (BWD_ORDER_DEPTH + 1) + b] + k;
+                        q = kb * XCD_REGIONS + (uint32_t)x;       // every stream alive: the row is complete
+                        if (kb >= m_min) {
+                            q = 0u;
+#pragma unroll
+                            for (int xo = 0; xo < XCD_REGIONS; ++xo) q += min(M[xo], kb) + (xo < x && M[xo] > kb ? 1u : 0u);
+                        }
+                    } else {
+                        q = deep_base + atomicAdd(&w.bwd_meta[1], 1u);
+                    }
                     bwd_order[q] = slot0 + b;
                 }
             }
         }
         __syncthreads();
-        if (tid < ORDER_CLASSES) s_cnt[tid] = 0u;
+        for (int i = tid; i < ORDER_BINS; i += SBLOCK) s_cnt[i] = 0u;
         __syncthreads();
+        ORDER_STAMP(5);
     }
+#undef ORDER_STAMP
 }
 
 // Short lists of a LARGE image (>= SPLIT_SORT_SUBTILES sub-tiles, e.g. 2048 x 2048 px): one wave per sub-tile, four
@@ -438,8 +514,9 @@ __global__ __launch_bounds__(SBLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) 
 #endif
     if (blockIdx.x < ORDER_WGS) {
         // (the backward's order only for renders that keep their context: a no_grad frame has no backward)
+        static_assert(ORDER_LDS_WORDS <= SORT_TILE, "order_slots borrows the bucket counters of the sort");
         order_slots(a.tw, a.store_ctx ? reinterpret_cast<uint32_t*>(a.bw.bucket) : nullptr, a.grid.subtiles, (int)blockIdx.x, tid,
-                    [&](int st) { return a.tw.ranges[st]; });
+                    s_cnt, [&](int st) { return a.tw.ranges[st]; });
         return;
     }
 #ifdef EXA_PROBE_SORT

@@ -6,7 +6,7 @@ per-sub-tile list-length histogram that section asks for with every result.  Nee
 render (``rasterizer._debug_last`` then holds the workspaces of the most recent forward)."""
 import torch
 
-HEADER_BYTES, SUBS, BIN_PARTS, CHUNK, BATCH = 512, 64, 4, 1024, 64
+HEADER_BYTES, SUBS, BIN_PARTS, CHUNK, BATCH = 2560, 64, 4, 1024, 64
 
 
 def a256(v):
@@ -23,7 +23,7 @@ def tile_offsets(P, W, H):
                        ('chunk_off', (chunks + 1) * 4),
                        ('cell_desc', cells * 16), ('ranges', cells * SUBS * 8), ('slots', cells * SUBS * 16),
                        ('fwd_exit', cells * SUBS * 8), ('part_cnt', cells * BIN_PARTS * SUBS * 4), ('cell_long', cells * 4),
-                       ('part_desc', cells * BIN_PARTS * 16)):
+                       ('part_desc', cells * BIN_PARTS * 16), ('cls_code', cells * SUBS)):
         out[name] = (off, size)
         off += a256(size)
     out['cells'], out['chunks'], out['total'] = cells, chunks, off

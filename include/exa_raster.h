@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define EXA_RASTER_VERSION 138          /* 0.1.3.8: grad_bytes of exa_raster_workspace_sizes includes the 92 B x P group scratch of summed batches of more than four views; 0.1.3.7: ExaRasterComposeJob.radii_out / is_vis_out; 0.1.3.6: exa_raster_select_row; 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
+#define EXA_RASTER_VERSION 139          /* 0.1.3.9: tile_bytes of exa_raster_workspace_sizes grew (launch-order cursors per XCD region, one class code per sub-tile); no signature changed; 0.1.3.8: grad_bytes of exa_raster_workspace_sizes includes the 92 B x P group scratch of summed batches of more than four views; 0.1.3.7: ExaRasterComposeJob.radii_out / is_vis_out; 0.1.3.6: exa_raster_select_row; 0.1.3.5: EXA_RASTER_STAGE_* bits of store_ctx; 0.1.3.4: ExaRasterBackwardJob.used_slots; 0.1.3.3: ExaRasterForwardJob.is_vis, ExaRasterBackwardJob.accumulate; 0.1.3.2: ExaRasterBackwardJob.dL_dcolor_indirect, exa_raster_store_pointers, ExaRasterComposeJob.a_color .. a_bg; 0.1.3.1: composite renders (exa_raster_forward_compose_batch); 0.1.3: header.num_tile_instances, EXA_RASTER_E_OVERFLOW / _E_ALIAS, exa_raster_camera_block,
                                            exa_raster_header_status; 0.1.2: ExaRasterBackwardJob.grad_first; .1: exa_raster_read_header_async */
 #define EXA_RASTER_TILE 16              /* 16x16 pixel tiles (upstream BLOCK_X/BLOCK_Y) */
 

@@ -27,7 +27,7 @@ def test_library_exports_every_symbol_the_header_declares():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for ' + n
-    assert lib.exa_raster_version() == 138
+    assert lib.exa_raster_version() == 139
     assert [lib.exa_raster_timing_name(i) for i in range(_lib.TIMING_SLOTS)][1] == b'preprocess_fwd'
 
 

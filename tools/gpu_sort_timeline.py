@@ -1,5 +1,5 @@
 """Developer probe (library built with -DEXA_PROBE_SORTLINE): start / end of every workgroup of sort_subtiles_kernel (100 MHz
-clock) against the length of its list; the sixteen ordering workgroups come first.  C3, forward only."""
+clock) against the length of its list; the ordering workgroups come first.  C3, forward only."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, numpy as np
@@ -8,6 +8,7 @@ from exavatar_release_amd import scenes
 from exavatar_release_amd.rasterizer import GaussianRasterizationSettings, rasterize_gaussians, _debug_last
 from exavatar_release_amd.camera import make_raster_matrices
 from _layout import tile_offsets
+OW = 32          # ORDER_WGS of csrc/render_fwd.hip
 dev = torch.device('cuda:0'); H = W = 1024; P = 150000
 assets = scenes.dist_b_avatar(P, seed=0)
 params = [assets[k].to(dev) for k in ('mean_3d', 'scale', 'rotation', 'opacity', 'rgb')]
@@ -24,17 +25,21 @@ for k in [int(v) for v in (sys.argv[1:] or [0, 50])]:
     tile = _debug_last['tile']
     desc = tile[lay['cell_desc'][0]: lay['cell_desc'][0] + lay['cell_desc'][1]].view(torch.int32).view(-1, 4).cpu().numpy().astype(np.int64)
     rng = tile[lay['ranges'][0]: lay['ranges'][0] + nsub * 8].view(torch.int32).view(-1, 2).cpu().numpy().astype(np.int64)
-    tt = tile[lay['part_cnt'][0]: lay['part_cnt'][0] + (nsub + 16) * 8].view(torch.int32).view(-1, 2).cpu().numpy().astype(np.int64) & 0xffffffff
+    tt = tile[lay['part_cnt'][0]: lay['part_cnt'][0] + (nsub + OW) * 8].view(torch.int32).view(-1, 2).cpu().numpy().astype(np.int64) & 0xffffffff
     start, end = tt[:, 0] * 0.01, tt[:, 1] * 0.01
-    # sorting workgroup 16 + w handles sub-tile (w & 63) of the cell of rank (w >> 6)
+    # sorting workgroup OW + w handles sub-tile (w & 63) of the cell of rank (w >> 6)
     wg = np.arange(nsub)
     stile = desc[wg >> 6, 0] * 64 + (wg & 63)
     n = rng[stile, 1] - rng[stile, 0]
-    t0 = min(start[:16].min(), start[16:][n > 0].min())
+    t0 = min(start[:OW].min(), start[OW:][n > 0].min())
     start -= t0; end -= t0
-    so, eo = start[:16], end[:16]
+    so, eo = start[:OW], end[:OW]
     print('view %d: ordering workgroups start %.2f..%.2f end %.2f..%.2f us' % (k, so.min(), so.max(), eo.min(), eo.max()))
-    s_, e_ = start[16:], end[16:]
+    ph = tile[lay['part_cnt'][0] + (nsub + OW) * 8: lay['part_cnt'][0] + (nsub + OW) * 8 + OW * 8 * 4].view(torch.int32).view(OW, 8).cpu().numpy().astype(np.int64) & 0xffffffff
+    ph = ph[:, :6] * 0.01 - t0
+    print('   phases of the ordering workgroups (mean end, us after the first start): entry %.2f | histogram %.2f | prefixes %.2f | ranks %.2f | '
+          'reservations %.2f | records %.2f' % tuple(ph.mean(0)))
+    s_, e_ = start[OW:], end[OW:]
     work = n > 0
     d = e_ - s_
     print('   %d sorting workgroups with a list: starts p50 %.2f p90 %.2f max %.2f; ends p50 %.2f p90 %.2f p99 %.2f max %.2f us' % (
