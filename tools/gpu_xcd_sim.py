@@ -1,7 +1,7 @@
-"""What an XCD-aware launch order of the forward blend would buy and cost: for C3 ring views, the walked
+"""What the XCD-aware launch order of the forward blend buys and costs: for C3 ring views, the walked
 entries per XCD (balance: the launch ends with its slowest XCD) and the splat records each XCD's L2 has to fetch (64 B per
-distinct (record, XCD) pair among the walked entries) under (a) today's length-sorted order (block b -> XCD b mod 8), (b) whole
-64 x 64 cells hashed to XCDs, (c) 4 x 4 blocks of sub-tiles hashed to XCDs.  Reads the workspaces of real renders.
+distinct (record, XCD) pair among the walked entries) under (a) the launch order as built (block b -> XCD b mod 8), (b) one
+length-sorted sequence (rounds 2-5), (c) other ways of dealing sub-tiles to XCDs.  Reads the workspaces of real renders.
 python tools/gpu_xcd_sim.py [views...]"""
 import os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
@@ -38,7 +38,11 @@ for view in views:
     gsy = (cell // cx_n) * 8 + (sub % 64) // 8
     pos_of = torch.empty(nsub, dtype=torch.long, device=dev)
     pos_of[slots[:, 2]] = torch.arange(nsub, device=dev)
-    schemes = {'today (length-sorted, b mod 8)': pos_of % 8,
+    cls = torch.where(length > 0, torch.clamp((length + 15) // 16, max=63), torch.zeros_like(length))
+    one = torch.empty(nsub, dtype=torch.long, device=dev)
+    one[torch.argsort(-cls, stable=True)] = torch.arange(nsub, device=dev)
+    schemes = {'as built (position b -> XCD b mod 8)': pos_of % 8,
+               'one length-sorted sequence (rounds 2-5)': one % 8,
                'cells hashed (cx + 3 cy) mod 8': ((cell % cx_n) + 3 * (cell // cx_n)) % 8,
                '4x4 blocks hashed (bx + 3 by) mod 8': ((gsx // 4) + 3 * (gsy // 4)) % 8,
                '2x2 blocks hashed': ((gsx // 2) + 3 * (gsy // 2)) % 8}
