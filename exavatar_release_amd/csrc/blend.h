@@ -16,10 +16,8 @@
 //    issue slots), v_exp_f32 per ~8, and a broadcast ds_read_b128 costs 4 LDS cycles of the whole CU.  Hence
 //  * the staged batch is SoA (px[64], py[64], ...): four splats are ONE ds_read_b128 per field, and pairs of
 //    splats form packed operands;
-//  * per-pixel state is arithmetic (`live` = 1.0f / 0.0f), never boolean: boolean state becomes SGPR-mask
-//    traffic (v_cmp -> s_and/s_or -> v_cndmask) that doubled the instruction count of the blend;
-//  * the recurrence is advanced four splats at a time through partial products (blend_group4), so the
-//    loop-carried dependency is one multiply per group.
+//  * per-pixel state is arithmetic (a stopped pixel has T = 0.0f), never boolean: boolean state becomes SGPR-mask
+//    traffic (v_cmp -> s_and/s_or -> v_cndmask) that doubled the instruction count of the blend.
 #pragma once
 #include "common.h"
 
@@ -31,7 +29,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 // One batch of 64 splats staged in LDS, SoA so that splats (k, k + 1) form packed operands and four splats
 // are one ds_read_b128 (all lanes read the same address: broadcast).
 struct BatchLds {
-    float px[BATCH], py[BATCH], ca[BATCH], cb[BATCH], cc[BATCH], op[BATCH];
+    float px[BATCH], py[BATCH], ca[BATCH], cb[BATCH], cc[BATCH], op[BATCH];      // op: log2(opacity), see splat_alpha2
     float4 col[BATCH];                           // r, g, b, depth
 };
 
@@ -41,26 +39,32 @@ struct BatchLds {
 //  components as address temporaries right behind the prefetch and waited for the load to land before it could.)
 __device__ __forceinline__ void stage_splat(BatchLds& s, int lane, const float2& r0, const float4& r1, const float4& r2) {
     s.px[lane] = r0.x; s.py[lane] = r0.y;
-    s.ca[lane] = r1.x; s.cb[lane] = r1.y; s.cc[lane] = r1.z; s.op[lane] = r1.w;
+    s.ca[lane] = r1.x; s.cb[lane] = r1.y; s.cc[lane] = r1.z; s.op[lane] = __builtin_amdgcn_logf(r1.w);     // v_log_f32: log2; 0 -> -inf
     s.col[lane] = r2;
 }
 
-// alpha (0 when the splat is skipped at this pixel: power > 0 or alpha < 1/255) and falloff G of two splats
-struct Alpha2 { v2f alpha, G; };
-__device__ __forceinline__ Alpha2 splat_alpha2(v2f px, v2f py, v2f ca, v2f cb, v2f cc, v2f op, float fx, float fy) {
+// alpha (0 when the splat is skipped at this pixel: power > 0 or alpha < 1/255) and A = opacity x falloff (alpha before the
+// clamp to 0.99: what the backward pass differentiates, straight through the clamp) of two splats.
+// (ca, cb, cc) = (-A/2, -B, -C/2) log2(e) and lop = log2(opacity):  log2(opacity G) = dx (ca dx + cb dy) + (cc dy) dy + lop  in
+// three multiplies and two fmas per splat (rounds 2-5: four and two, and a multiply by the opacity behind the exponential),
+// and "power <= 0" is "that sum <= lop".
+// vis / neg: the two compares behind "NOT skipped at this pixel" -- SGPR masks; kept apart so that a ballot of each is the
+// compare's own result (a ballot of their AND is lowered through a VGPR: v_cndmask + v_cmp per vote)
+struct Alpha2 { v2f alpha, A; bool vis0, vis1, neg0, neg1; };
+__device__ __forceinline__ Alpha2 splat_alpha2(v2f px, v2f py, v2f ca, v2f cb, v2f cc, v2f lop, float fx, float fy) {
 #pragma clang fp contract(off)
     const v2f dx = px - fx, dy = py - fy;
-    // (ca, cb, cc) = (-A/2, -B, -C/2) log2(e): log2 of the falloff in four multiplies and two fmas
-    const v2f p2 = __builtin_elementwise_fma(ca * dx, dx, __builtin_elementwise_fma(cc * dy, dy, (cb * dx) * dy));
+    const v2f t = __builtin_elementwise_fma(cb, dy, ca * dx);
+    const v2f u = __builtin_elementwise_fma(cc * dy, dy, lop);
+    const v2f p2 = __builtin_elementwise_fma(t, dx, u);
     Alpha2 r;
-    r.G.x = __builtin_amdgcn_exp2f(p2.x);
-    r.G.y = __builtin_amdgcn_exp2f(p2.y);
-    const v2f og = op * r.G;
-    float a0 = fminf(ALPHA_MAX, og.x), a1 = fminf(ALPHA_MAX, og.y);
-    a0 = (a0 >= ALPHA_MIN) ? a0 : 0.0f;
-    a1 = (a1 >= ALPHA_MIN) ? a1 : 0.0f;
-    r.alpha.x = (p2.x <= 0.0f) ? a0 : 0.0f;
-    r.alpha.y = (p2.y <= 0.0f) ? a1 : 0.0f;
+    r.A.x = __builtin_amdgcn_exp2f(p2.x);
+    r.A.y = __builtin_amdgcn_exp2f(p2.y);
+    const float a0 = fminf(ALPHA_MAX, r.A.x), a1 = fminf(ALPHA_MAX, r.A.y);
+    r.vis0 = a0 >= ALPHA_MIN; r.neg0 = p2.x <= lop.x;
+    r.vis1 = a1 >= ALPHA_MIN; r.neg1 = p2.y <= lop.y;
+    r.alpha.x = (r.vis0 && r.neg0) ? a0 : 0.0f;
+    r.alpha.y = (r.vis1 && r.neg1) ? a1 : 0.0f;
     return r;
 }
 
@@ -76,51 +80,55 @@ __device__ __forceinline__ Ops4 load_ops4(const BatchLds& s, int k) {
     o.op = *reinterpret_cast<const v4f*>(&s.op[k]);
     return o;
 }
-// alphas (and falloffs) of four splats at pixel (fx, fy)
-struct Alpha4 { float alpha[4], G[4]; };
+// alphas (and unclamped opacity x falloff) of four splats at pixel (fx, fy)
+struct Alpha4 { float alpha[4], A[4]; bool vis[4], neg[4]; };
 __device__ __forceinline__ Alpha4 splat_alpha4(const Ops4& o, float fx, float fy) {
     const Alpha2 lo = splat_alpha2(o.px.xy, o.py.xy, o.ca.xy, o.cb.xy, o.cc.xy, o.op.xy, fx, fy);
     const Alpha2 hi = splat_alpha2(o.px.zw, o.py.zw, o.ca.zw, o.cb.zw, o.cc.zw, o.op.zw, fx, fy);
     Alpha4 r;
     r.alpha[0] = lo.alpha.x; r.alpha[1] = lo.alpha.y; r.alpha[2] = hi.alpha.x; r.alpha[3] = hi.alpha.y;
-    r.G[0] = lo.G.x; r.G[1] = lo.G.y; r.G[2] = hi.G.x; r.G[3] = hi.G.y;
+    r.A[0] = lo.A.x; r.A[1] = lo.A.y; r.A[2] = hi.A.x; r.A[3] = hi.A.y;
+    r.vis[0] = lo.vis0; r.vis[1] = lo.vis1; r.vis[2] = hi.vis0; r.vis[3] = hi.vis1;
+    r.neg[0] = lo.neg0; r.neg[1] = lo.neg1; r.neg[2] = hi.neg0; r.neg[3] = hi.neg1;
     return r;
 }
 
-// Four steps of the front-to-back recurrence at once.  `live` is 1.0f while the pixel accepts splats, 0.0f
-// after it stopped (or for a pixel outside the image).  Outputs per splat j: the effective alpha a[j], the
-// transmittance in front of it Tb[j] and the blend weight w[j] = a[j] Tb[j] (0 when nothing is blended).
+// Four steps of the front-to-back recurrence.  State per pixel: T = its transmittance while it accepts splats, 0.0f once it
+// has stopped (or for a pixel outside the image) -- a stopped pixel then takes w = alpha * 0 = 0 of everything that follows
+// without a `live` factor -- and Tdead = the transmittance it stopped with (what the image and the checkpoints report).
+// Outputs per splat j: the transmittance in front of it Tb[j] and the blend weight w[j] = alpha[j] Tb[j] (0 when nothing is
+// blended).  A splat CHANGES a pixel's state -- is blended, or stops it: what the backward pass has to replay -- exactly when its
+// alpha is not skipped (Alpha4::vis && neg) and the pixel was live at the start of the group: inside a group T_j > 0 <=> T > 0
+// (alpha <= 0.99), and entries behind the one that stops the pixel are flagged too, which is harmless.
 //
-// The sequential rule -- skip alpha == 0, and the splat that would push T (1 - a) under 1e-4 is NOT blended
-// and kills the pixel -- is evaluated through the partial products P_j = prod_{i <= j} (1 - a_i), which depend
-// on the alphas only: the loop-carried dependency is ONE multiply (T P_4) per four splats instead of a
-// mul / fma / compare / select chain per splat (the kernels are latency bound: ~3.7 waves per SIMD).  T P_j is
-// non-increasing in j, so "stopped at or before j" is simply T P_j < 1e-4; a dead pixel has a = 0, P = 1.
-// T >= 1e-4 is an invariant.
-__device__ __forceinline__ void blend_group4(float& T, float& live, const float (&alpha)[4], float (&a)[4],
-                                             float (&Tb)[4], float (&w)[4]) {
+// The sequential rule -- skip alpha == 0, and the splat that would push T (1 - alpha) under 1e-4 is NOT blended and kills the
+// pixel -- as  w_j = alpha_j T_j,  T_{j+1} = T_j - w_j:  two plain instructions per splat.  (Rounds 2-5 advanced four splats
+// through the partial products P_j = prod (1 - a_i) so that the loop-carried dependency was ONE multiply per group -- 19
+// instructions per group instead of 8, worth it at the 3.7 waves per SIMD of those rounds; at five the dependent chain of
+// eight hides behind the other waves: render_fwd 36.5 -> see DESIGN.md section 0.)  A skipped splat leaves T bit-for-bit
+// unchanged, so the backward pass, which replays the COMPACTED list (other groups of four), reproduces the forward's
+// transmittances exactly.  T_j is non-increasing in j, so "stopped at or before j" is simply T_{j+1} < 1e-4; alpha <= 0.99
+// keeps a live T above 1e-6 T_j > 0, and T >= 1e-4 is an invariant of a live pixel.
+__device__ __forceinline__ void blend_group4(float& T, float& Tdead, const float (&alpha)[4], float (&Tb)[4], float (&w)[4]) {
 #pragma clang fp contract(off)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] = alpha[j] * live;          // exact
-    const float P1 = 1.0f - a[0];
-    const float P2 = P1 * (1.0f - a[1]);
-    const float P3 = P2 * (1.0f - a[2]);
-    const float P4 = P3 * (1.0f - a[3]);
-    Tb[0] = T; Tb[1] = T * P1; Tb[2] = T * P2; Tb[3] = T * P3;
-    const float T4 = T * P4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = a[j] * Tb[j];
-    if (__any(T4 < T_EPS)) {                                     // some pixel stops inside this group (rare)
+    Tb[0] = T;
+    w[0] = alpha[0] * Tb[0]; Tb[1] = Tb[0] - w[0];
+    w[1] = alpha[1] * Tb[1]; Tb[2] = Tb[1] - w[1];
+    w[2] = alpha[2] * Tb[2]; Tb[3] = Tb[2] - w[2];
+    w[3] = alpha[3] * Tb[3];
+    const float T4 = Tb[3] - w[3];
+    if (__any(T4 < T_EPS && T > 0.0f)) {                         // some live pixel stops inside this group (rare)
         const float after[4] = {Tb[1], Tb[2], Tb[3], T4};
+        const bool dies = T4 < T_EPS && T > 0.0f;
         float Tn = T;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 4; ++j) {                            // (a pixel that was dead already: all of it 0)
             const bool stop = after[j] < T_EPS;
             w[j] = stop ? 0.0f : w[j];
             Tn = stop ? Tn : after[j];
         }
-        live = (T4 < T_EPS) ? 0.0f : live;
-        T = Tn;
+        Tdead = dies ? Tn : Tdead;
+        T = (T4 < T_EPS) ? 0.0f : T4;
     } else {
         T = T4;
     }

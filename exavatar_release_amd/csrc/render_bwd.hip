@@ -325,11 +325,10 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
     s_pslot[dst] = p0.pslot;
     s_pg[(lane >> 4) * 17 + (lane & 15)] = make_float4(gr, gg, gb, gd);
 
-    float T = 1.0f, live = inside ? 1.0f : 0.0f;
+    float T = inside ? 1.0f : 0.0f, Tdead = 1.0f;               // blend.h: T = 0 for a pixel that has stopped
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f;
     if (bq > 0) {
-        T = fabsf(p0.cs0);
-        live = p0.cs0 > 0.0f ? 1.0f : 0.0f;
+        T = fmaxf(p0.cs0, 0.0f);                                // (a stopped pixel is checkpointed as -T)
         sr = p0.cs1; sg = p0.cs2; sb = p0.cs3; sd = p0.cs4;
     }
     const float T_final = p0.cf0;
@@ -346,13 +345,13 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
     const float4* const xr_row = reinterpret_cast<const float4*>(s_x + XL::rbase(lane));                // phase B: my row
 
     for (int c0 = 0; c0 < cnt; c0 += GC) {
-        if (__all(live == 0.0f)) break;                         // (only after a 1e-7-probability stop flip, see header)
+        if (__all(T == 0.0f)) break;                            // (every pixel stopped inside this batch)
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
         {
             auto grad4 = [&](const Alpha4& e, const float4 (&col)[4], int k) {
-                float aeff[4], Tb[4], w[4];
-                blend_group4(T, live, e.alpha, aeff, Tb, w);
+                float Tb[4], w[4];
+                blend_group4(T, Tdead, e.alpha, Tb, w);
                 float2* x = xw_row + (k - c0) * (XL::WK / 2);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -360,9 +359,9 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
                     float cg = fmaf(c.z, gb, fmaf(c.y, gg, c.x * gr));
                     if (HAS_DEPTH) cg = fmaf(c.w, gd, cg);
                     R = fmaf(-cg, w[u], R);                                  // R_{i+1}
-                    const float inv = __builtin_amdgcn_rcpf(1.0f - aeff[u]);
+                    const float inv = __builtin_amdgcn_rcpf(1.0f - e.alpha[u]);
                     const float dLda = fmaf(Tb[u], cg, -(R * inv));
-                    x[u * (XL::WK / 2)] = make_float2(w[u] > 0.0f ? e.G[u] * dLda : 0.0f, w[u]);
+                    x[u * (XL::WK / 2)] = make_float2(w[u] > 0.0f ? e.A[u] * dLda : 0.0f, w[u]);
                 }
             };
             auto group4 = [&](const Ops4& ops, int k) {
@@ -417,12 +416,13 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
             XL::reduce9(mx, my, mxx, mxy, myy, dop, dr, dg, db);
             if (HAS_DEPTH) dz = XL::reduce(dz);
             if (h == 0 && kk < cend) {
-                const float o = s_b.op[kk];                     // s = dL/dG * G = opacity * aG
+                // aG = (opacity G) dL/dalpha = dL/dG * G already (blend.h: A); dL/dopacity = sum of it / opacity
+                const float inv_o = __builtin_amdgcn_exp2f(-s_b.op[kk]);
                 const uint32_t ps = s_pslot[kk];
                 if (!PREFIX || ps != NO_SLOT) {
                     char* dst = partial_at(prec, ps);
-                    *reinterpret_cast<partial_v4*>(dst) = partial_v4{o * mx, o * my, o * mxx, o * mxy};
-                    *reinterpret_cast<partial_v4*>(dst + 16) = partial_v4{o * myy, dop, dr, dg};
+                    *reinterpret_cast<partial_v4*>(dst) = partial_v4{mx, my, mxx, mxy};
+                    *reinterpret_cast<partial_v4*>(dst + 16) = partial_v4{myy, dop * inv_o, dr, dg};
                     if (PARTIAL_BYTES == 40) *reinterpret_cast<partial_v2*>(dst + 32) = partial_v2{db, dz};
                     else *reinterpret_cast<partial_v4*>(dst + 32) = partial_v4{db, dz, 0.f, 0.f};
                     if (PARTIAL_BYTES == 64) *reinterpret_cast<partial_v4*>(dst + 48) = partial_v4{0.f, 0.f, 0.f, 0.f};      // (the whole line: no partial sector)

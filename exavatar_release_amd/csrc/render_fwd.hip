@@ -611,7 +611,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         return;
     }
 
-    float T = 1.0f, live = inside ? 1.0f : 0.0f;
+    float T = inside ? 1.0f : 0.0f, Tdead = 1.0f;              // blend.h: T = 0 once the pixel has stopped, Tdead = what it stopped with
     v2f Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};                     // (r, g) and (b, depth) accumulators
     const Splat* __restrict__ splats = a.splats;
     const uint32_t* __restrict__ sorted = a.bw.sorted + range.x;
@@ -637,10 +637,10 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
     float* ckpt = a.bw.ckpt + (size_t)(range.x / BATCH) * (5 * 64) + lane;
     int entered = 0;
     for (int base = 0; base < n; base += 64) {
-        if (__all(live == 0.0f)) break;
+        if (__all(T == 0.0f)) break;
         if (STORE && base > 0) {
             float* c = ckpt + (size_t)entered * (5 * 64);
-            c[0] = live != 0.0f ? T : -T; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
+            c[0] = T > 0.0f ? T : -Tdead; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
         }
         ++entered;
         stage_splat(s_b, lane, r0, r1, r2);
@@ -666,24 +666,27 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             // (no wave-wide vote on "does any live pixel take any of the four": with exact-footprint lists nearly every
             //  group is taken by some pixel, and the vote cost more than the blends it skipped: 42.8 -> 41.8 us on C3)
 #ifdef EXA_FWD_SKIP_VOTE
-            const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * live;
+            const float amax = fmaxf(fmaxf(e.alpha[0], e.alpha[1]), fmaxf(e.alpha[2], e.alpha[3])) * T;
             if (!__any(amax > 0.0f)) return false;
 #endif
-            float aeff[4], Tb[4], w[4];
-            blend_group4(T, live, e.alpha, aeff, Tb, w);
-            if (STORE) {                                         // wave-uniform bits: v_cmp into an SGPR pair + scalar ops
-                // four votes -> one nibble, on the scalar unit: left to the compiler the nibble is assembled in a VGPR (a
-                // v_cndmask, three v_or and a v_readfirstlane per group of four)
-                auto vote_bit = [](bool p, uint32_t bit) -> uint32_t {
-                    const unsigned long long m = __ballot(p);
+            const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(T > 0.0f);      // before the group
+            if (STORE) {
+                // (BEFORE the blend: in the basic block of the compares -- behind the blend's rare branch the masks come back
+                //  through VGPRs.)  Four votes -> one nibble, all of it on the scalar unit: the blend needs the compares behind "not skipped" and
+                // "was live" anyway, a ballot of a compare IS its SGPR mask, and the rest is s_and / s_cmp / s_cselect.  (HIP's
+                // __ballot compares an int against 0, i.e. takes the mask through a VGPR; left to the compiler the nibble was
+                // assembled in a VGPR: a v_cndmask, three v_or and a v_readfirstlane per group of four.)
+                auto vote_bit = [&](int j, uint32_t bit) -> uint32_t {
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(e.vis[j]) & __builtin_amdgcn_ballot_w64(e.neg[j]) & live_mask;
                     uint32_t r;
                     asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(r) : "s"(m), "s"(bit) : "scc");
                     return r;
                 };
-                const uint32_t nib = vote_bit(aeff[0] > 0.0f, 1u) | vote_bit(aeff[1] > 0.0f, 2u) |
-                                     vote_bit(aeff[2] > 0.0f, 4u) | vote_bit(aeff[3] > 0.0f, 8u);
+                const uint32_t nib = vote_bit(0, 1u) | vote_bit(1, 2u) | vote_bit(2, 4u) | vote_bit(3, 8u);
                 blended |= (unsigned long long)nib << k;
             }
+            float Tb[4], w[4];
+            blend_group4(T, Tdead, e.alpha, Tb, w);
             Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
             Cbd = __builtin_elementwise_fma(v2f{c0.z, c0.w}, v2f{w[0], w[0]}, Cbd);
             Crg = __builtin_elementwise_fma(v2f{c1.x, c1.y}, v2f{w[1], w[1]}, Crg);
@@ -692,12 +695,12 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             Cbd = __builtin_elementwise_fma(v2f{c2.z, c2.w}, v2f{w[2], w[2]}, Cbd);
             Crg = __builtin_elementwise_fma(v2f{c3.x, c3.y}, v2f{w[3], w[3]}, Crg);
             Cbd = __builtin_elementwise_fma(v2f{c3.z, c3.w}, v2f{w[3], w[3]}, Cbd);
-            // "every pixel of the sub-tile dead" is looked for once per EIGHT splats (a dead pixel takes alpha * live = 0,
+            // "every pixel of the sub-tile dead" is looked for once per EIGHT splats (a dead pixel takes alpha * 0 = 0,
             // so walking four more splats changes nothing): one vote less per group, 42.3 vs 42.8 us on C3
 #ifdef EXA_FWD_EXIT4
-            return __all(live == 0.0f);
+            return __all(T == 0.0f);
 #else
-            return (k & 4) ? __all(live == 0.0f) : false;
+            return (k & 4) ? __all(T == 0.0f) : false;
 #endif
         };
         // two groups per trip with ping-pong operand registers: the operands of the next group are in flight during the
@@ -723,11 +726,12 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
     if (inside) {
         const size_t pix = (size_t)pyi * a.grid.W + pxi;
         const float* __restrict__ bg = a.bg;
-        a.out_color[pix] = Crg.x + T * bg[0];
-        a.out_color[HW + pix] = Crg.y + T * bg[1];
-        a.out_color[2 * HW + pix] = Cbd.x + T * bg[2];
+        const float Tf = T > 0.0f ? T : Tdead;
+        a.out_color[pix] = Crg.x + Tf * bg[0];
+        a.out_color[HW + pix] = Crg.y + Tf * bg[1];
+        a.out_color[2 * HW + pix] = Cbd.x + Tf * bg[2];
         a.out_depth[pix] = Cbd.y;
-        a.out_alpha[pix] = 1.0f - T;
+        a.out_alpha[pix] = 1.0f - Tf;
     }
     if (STORE) {
         if (lane == 0) a.tw.fwd_exit[st] = make_uint2((uint32_t)n, (uint32_t)entered);
@@ -742,7 +746,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
 #endif
         if (n > 0) {   // exit state -> the sub-tile's END slot (a fixed place the backward finds without `entered`)
             float* c = ckpt + (size_t)((n + BATCH - 1) / BATCH) * (5 * 64);
-            c[0] = T; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
+            c[0] = T > 0.0f ? T : Tdead; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
         }
     }
 }
