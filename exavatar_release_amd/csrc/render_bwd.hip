@@ -337,6 +337,8 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
     float R = (p0.cf1 - sr) * gr + (p0.cf2 - sg) * gg + (p0.cf3 - sb) * gb - tail;
     if (HAS_DEPTH) R = fmaf(p0.cf4 - sd, gd, R);
     wave_lds_fence();
+    // blend.h, conic_safe: the staged entries (compacted order) whose groups keep upstream's "power > 0" guard
+    const unsigned long long unsafe = __builtin_amdgcn_ballot_w64(!conic_safe(s_b.ca[lane], s_b.cb[lane], s_b.cc[lane]));
     // staged entries (compacted order) that are trainable; a chunk without any skips phase B
     const unsigned long long need = PREFIX ? __ballot(lane < cnt && s_pslot[lane] != NO_SLOT) : ~0ull;
 
@@ -349,9 +351,11 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
         {
-            auto grad4 = [&](const Alpha4& e, const float4 (&col)[4], int k) {
+            auto grad4 = [&](Alpha4& e, const float4 (&col)[4], int k) {
+                // e.Ag = A where this (live) pixel takes the splat: the product with dL/dalpha needs no `w > 0` compare and
+                // select behind it.  (A pixel stopped BY one of the four: blend_group4 zeroes the gate with the weight.)
                 float Tb[4], w[4];
-                blend_group4(T, Tdead, e.alpha, Tb, w);
+                blend_group4(T, Tdead, e.alpha, Tb, w, e.Ag);
                 float2* x = xw_row + (k - c0) * (XL::WK / 2);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -361,13 +365,15 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
                     R = fmaf(-cg, w[u], R);                                  // R_{i+1}
                     const float inv = __builtin_amdgcn_rcpf(1.0f - e.alpha[u]);
                     const float dLda = fmaf(Tb[u], cg, -(R * inv));
-                    x[u * (XL::WK / 2)] = make_float2(w[u] > 0.0f ? e.A[u] * dLda : 0.0f, w[u]);
+                    x[u * (XL::WK / 2)] = make_float2(e.Ag[u] * dLda, w[u]);
                 }
             };
             auto group4 = [&](const Ops4& ops, int k) {
                 float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
                 if (!HAS_DEPTH) { keep_b128(col[0]); keep_b128(col[1]); keep_b128(col[2]); keep_b128(col[3]); }
-                grad4(splat_alpha4(ops, fx, fy), col, k);
+                Alpha4 e = splat_alpha4(ops, fx, fy, T > 0.0f);
+                if ((unsafe >> k) & 0xfull) power_guard4(e, ops);
+                grad4(e, col, k);
             };
             // two groups per trip, ping-pong operand registers (next group's operands in flight, no register rotation)
             Ops4 opsA = load_ops4(s_b, c0);

@@ -643,6 +643,8 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
             c[0] = T > 0.0f ? T : -Tdead; c[64] = Crg.x; c[128] = Crg.y; c[192] = Cbd.x; c[256] = Cbd.y;
         }
         ++entered;
+        // blend.h, conic_safe: the entries whose groups keep upstream's "power > 0" guard (none, in any sane scene)
+        const unsigned long long unsafe = __builtin_amdgcn_ballot_w64(!conic_safe(r1.x, r1.y, r1.z));
         stage_splat(s_b, lane, r0, r1, r2);
         // issue the next batch's gathers and the ids of the batch after it; lanes past the end of the list
         // stage an all-zero record (opacity 0 -> alpha 0), so the blend below always runs whole groups of four
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
                 // __ballot compares an int against 0, i.e. takes the mask through a VGPR; left to the compiler the nibble was
                 // assembled in a VGPR: a v_cndmask, three v_or and a v_readfirstlane per group of four.)
                 auto vote_bit = [&](int j, uint32_t bit) -> uint32_t {
-                    const unsigned long long m = __builtin_amdgcn_ballot_w64(e.vis[j]) & __builtin_amdgcn_ballot_w64(e.neg[j]) & live_mask;
+                    const unsigned long long m = e.took[j] & live_mask;
                     uint32_t r;
                     asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, %2, 0" : "=s"(r) : "s"(m), "s"(bit) : "scc");
                     return r;
@@ -707,7 +709,9 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
         // current one, and no register-to-register rotation is needed (a `cur = nxt` copy cost 12 v_mov_b64 per group)
         auto group4 = [&](const Ops4& ops, int k) -> bool {
             const float4 c0 = s_b.col[k], c1 = s_b.col[k + 1], c2 = s_b.col[k + 2], c3 = s_b.col[k + 3];
-            return blend4(splat_alpha4(ops, fx, fy), c0, c1, c2, c3, k);
+            Alpha4 e = splat_alpha4(ops, fx, fy, true);
+            if ((unsafe >> k) & 0xfull) power_guard4(e, ops);
+            return blend4(e, c0, c1, c2, c3, k);
         };
         Ops4 opsA = load_ops4(s_b, 0);
         for (int k = 0; k < cnt; k += 8) {

@@ -600,3 +600,36 @@ def test_composite_render_agrees_with_the_oracle(dev):
                            abs_scale=rotation_grad_scale(h3['scale'], h3['scale'].grad) if k == 'rotation' else 0.0)
     assert_grads_close(o['mean_2d'].grad, ref['mean_2d'].grad[nS:], 'mean_2d', near)
     assert all(s[k].grad is None for k in KEYS)          # only the composite was differentiated: the scene is a constant of it
+
+
+def test_needle_conics_keep_the_power_guard(dev):
+    """csrc/blend.h conic_safe: a conic with lambda_min / lambda_max below ~2.5e-6 (a needle of > 600 : 1 behind the 0.3 px^2
+    low-pass floor) is the one kind of splat whose groups keep upstream's `power > 0 -> skip` compare, as a fix-up behind
+    the evaluation; every other group runs without it.  Needles of 350 .. 3 000 px among ordinary splats, against the C
+    oracle at the usual bar (measured: 1.3e-5)."""
+    H, W, f = 40, 56, 100.0
+    a = scenes.dist_a_random(60, H, W, seed=5, focal=f, z_range=(2.0, 4.0))
+    g = torch.Generator().manual_seed(77)
+    for i, s in enumerate((12.0, 30.0, 100.0, 40.0)):
+        a['scale'][i] = torch.tensor([s, 1e-4, 1e-4])
+        a['mean_3d'][i] = torch.tensor([0.1 * i - 0.2, 0.05 * i - 0.1, 3.0])
+        q = torch.randn(4, generator=g)
+        a['rotation'][i] = q / q.norm()
+        a['opacity'][i] = 0.6
+    cam, bg = scenes.neutral_camera(H, W, focal=f), torch.rand(3, generator=g)
+    G = torch.randn(3, H, W, generator=g)
+    ag = _to(a, dev)
+    out = exa.GaussianRenderer()(ag, (H, W), {k: v.to(dev) for k, v in cam.items()}, bg.to(dev))
+    (out['img'] * G.to(dev)).sum().backward()
+    c = co.render(a, (H, W), cam, bg, dL_dimg=G)
+    t = {k: v.clone().requires_grad_(True) for k, v in a.items()}
+    r = ro.render(t, (H, W), cam, bg, return_aux=True)
+    assert torch.equal(out['radius'].cpu(), c['radius'])
+    assert int((c['radius'][:4] > 300).sum()) >= 3, 'the needles must be on screen as needles'
+    amb = ro.ambiguous_pixel_mask(r['aux'], H, W) | (c['pixel_margin'] < 1e-4)
+    d_hip = (out['img'].detach().cpu() - c['img']).abs().amax(0)
+    d_cpu = (r['img'].detach() - c['img']).abs().amax(0)
+    record_stats('needles', {'hip_vs_c': float(d_hip[~amb].max()), 'torch_vs_c': float(d_cpu[~amb].max()), 'n_ambiguous': int(amb.sum())})
+    assert float(d_hip[~amb].max()) <= IMG_TOL, (float(d_hip[~amb].max()), float(d_cpu[~amb].max()))
+    for k in KEYS:
+        assert bool(torch.isfinite(ag[k].grad).all()), k
