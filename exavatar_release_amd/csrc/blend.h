@@ -138,8 +138,10 @@ __device__ __forceinline__ void power_guard4(Alpha4& e, const Ops4& o) {
 // transmittances exactly.  T_j is non-increasing in j, so "stopped at or before j" is simply T_{j+1} < 1e-4; alpha <= 0.99
 // keeps a live T above 1e-6 T_j > 0, and T >= 1e-4 is an invariant of a live pixel.
 // gate[j]: a per-splat factor of the caller's that has to vanish with w[j] when the stop rule zeroes it (render_bwd.hip).
-__device__ __forceinline__ void blend_group4(float& T, float& Tdead, const float (&alpha)[4], float (&Tb)[4], float (&w)[4],
-                                             float (&gate)[4]) {
+// live_mask: the caller's ballot of T > 0 at the start of the group (taken in the block of that compare: as a bool it
+// would cross the guard's branch and come back through a VGPR).
+__device__ __forceinline__ void blend_group4(float& T, float& Tdead, unsigned long long live_mask, const float (&alpha)[4],
+                                             float (&Tb)[4], float (&w)[4], float (&gate)[4]) {
 #pragma clang fp contract(off)
     Tb[0] = T;
     w[0] = alpha[0] * Tb[0]; Tb[1] = Tb[0] - w[0];
@@ -147,7 +149,7 @@ __device__ __forceinline__ void blend_group4(float& T, float& Tdead, const float
     w[2] = alpha[2] * Tb[2]; Tb[3] = Tb[2] - w[2];
     w[3] = alpha[3] * Tb[3];
     const float T4 = Tb[3] - w[3];
-    if (__any(T4 < T_EPS && T > 0.0f)) {                         // some live pixel stops inside this group (rare)
+    if ((__builtin_amdgcn_ballot_w64(T4 < T_EPS) & live_mask) != 0ull) {      // some live pixel stops inside this group (rare)
         const float after[4] = {Tb[1], Tb[2], Tb[3], T4};
         const bool dies = T4 < T_EPS && T > 0.0f;
         float Tn = T;
@@ -164,9 +166,10 @@ __device__ __forceinline__ void blend_group4(float& T, float& Tdead, const float
         T = T4;
     }
 }
-__device__ __forceinline__ void blend_group4(float& T, float& Tdead, const float (&alpha)[4], float (&Tb)[4], float (&w)[4]) {
+__device__ __forceinline__ void blend_group4(float& T, float& Tdead, unsigned long long live_mask, const float (&alpha)[4],
+                                             float (&Tb)[4], float (&w)[4]) {
     float none[4] = {0.f, 0.f, 0.f, 0.f};
-    blend_group4(T, Tdead, alpha, Tb, w, none);
+    blend_group4(T, Tdead, live_mask, alpha, Tb, w, none);
 }
 
 }  // namespace exa

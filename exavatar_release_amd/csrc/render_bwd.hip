@@ -351,11 +351,11 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
         const int cend = min(cnt, c0 + GC);
         // ---- phase A ---------------------------------------------------------------------------------
         {
-            auto grad4 = [&](Alpha4& e, const float4 (&col)[4], int k) {
+            auto grad4 = [&](Alpha4& e, unsigned long long live_mask, const float4 (&col)[4], int k) {
                 // e.Ag = A where this (live) pixel takes the splat: the product with dL/dalpha needs no `w > 0` compare and
                 // select behind it.  (A pixel stopped BY one of the four: blend_group4 zeroes the gate with the weight.)
                 float Tb[4], w[4];
-                blend_group4(T, Tdead, e.alpha, Tb, w, e.Ag);
+                blend_group4(T, Tdead, live_mask, e.alpha, Tb, w, e.Ag);
                 float2* x = xw_row + (k - c0) * (XL::WK / 2);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -371,9 +371,11 @@ __global__ __launch_bounds__(RBLOCK * WPB) void render_bwd_kernel(Batch<RenderBw
             auto group4 = [&](const Ops4& ops, int k) {
                 float4 col[4] = {s_b.col[k], s_b.col[k + 1], s_b.col[k + 2], s_b.col[k + 3]};
                 if (!HAS_DEPTH) { keep_b128(col[0]); keep_b128(col[1]); keep_b128(col[2]); keep_b128(col[3]); }
-                Alpha4 e = splat_alpha4(ops, fx, fy, T > 0.0f);
+                const bool live = T > 0.0f;
+                const unsigned long long live_mask = __builtin_amdgcn_ballot_w64(live);
+                Alpha4 e = splat_alpha4(ops, fx, fy, live);
                 if ((unsafe >> k) & 0xfull) power_guard4(e, ops);
-                grad4(e, col, k);
+                grad4(e, live_mask, col, k);
             };
             // two groups per trip, ping-pong operand registers (next group's operands in flight, no register rotation)
             Ops4 opsA = load_ops4(s_b, c0);

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(RBLOCK) void render_fwd_kernel(Batch<RenderFwdArgs>
                 blended |= (unsigned long long)nib << k;
             }
             float Tb[4], w[4];
-            blend_group4(T, Tdead, e.alpha, Tb, w);
+            blend_group4(T, Tdead, live_mask, e.alpha, Tb, w);
             Crg = __builtin_elementwise_fma(v2f{c0.x, c0.y}, v2f{w[0], w[0]}, Crg);
             Cbd = __builtin_elementwise_fma(v2f{c0.z, c0.w}, v2f{w[0], w[0]}, Cbd);
             Crg = __builtin_elementwise_fma(v2f{c1.x, c1.y}, v2f{w[1], w[1]}, Crg);
