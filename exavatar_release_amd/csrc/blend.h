@@ -10,8 +10,8 @@
 //
 // Why it looks the way it does (measured on MI355X: tools/probe/valu_probe.hip, EXA_PROBE_FWD builds, SQ PMC
 // passes in profiles/):
-//  * the render kernels are bound by per-wave LATENCY and VALU issue, not by memory: only ~3.7 waves per SIMD
-//    exist (one per non-empty 8x8 sub-tile), VALU-active is 55-60 % of the wave cycles.  One SIMD retires a
+//  * the render kernels are bound by VALU issue (and, below ~4 waves per SIMD, by per-wave latency), not by memory: only
+//    ~3.7 waves per SIMD exist in the forward (one per non-empty 8x8 sub-tile).  One SIMD retires a
 //    plain fp32 VALU op per ~2.5 cycles, a packed v_pk_*_f32 per ~5 (two results: same throughput, half the
 //    issue slots), v_exp_f32 per ~8, and a broadcast ds_read_b128 costs 4 LDS cycles of the whole CU.  Hence
 //  * the staged batch is SoA (px[64], py[64], ...): four splats are ONE ds_read_b128 per field, and pairs of
@@ -133,7 +133,7 @@ __device__ __forceinline__ void power_guard4(Alpha4& e, const Ops4& o) {
 // pixel -- as  w_j = alpha_j T_j,  T_{j+1} = T_j - w_j:  two plain instructions per splat.  (Rounds 2-5 advanced four splats
 // through the partial products P_j = prod (1 - a_i) so that the loop-carried dependency was ONE multiply per group -- 19
 // instructions per group instead of 8, worth it at the 3.7 waves per SIMD of those rounds; at five the dependent chain of
-// eight hides behind the other waves: render_fwd 36.5 -> see DESIGN.md section 0.)  A skipped splat leaves T bit-for-bit
+// eight hides behind the other waves: with the Horner power and the scalar votes, render_fwd 37.2 -> 31.2 us on C3.)  A skipped splat leaves T bit-for-bit
 // unchanged, so the backward pass, which replays the COMPACTED list (other groups of four), reproduces the forward's
 // transmittances exactly.  T_j is non-increasing in j, so "stopped at or before j" is simply T_{j+1} < 1e-4; alpha <= 0.99
 // keeps a live T above 1e-6 T_j > 0, and T >= 1e-4 is an invariant of a live pixel.

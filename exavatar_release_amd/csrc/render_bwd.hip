@@ -11,12 +11,12 @@
 // LDS (rank = mbcnt of the mask) and everything below runs on that shorter list.  On avatar-like scenes (opaque,
 // small splats) only ~60 % of the entries of the batches the forward enters survive, ~46 % of all instances
 // (C3, ring view 0: 893 k instances, 690 k in entered batches, 409 k blended).  Skip decisions depend on alpha only and
-// stay bit-identical to the forward's; the transmittance is re-multiplied in a different grouping of four, i.e. may
-// differ from the forward's by an ulp, which can move a `T < 1e-4` stop only when T (1 - alpha) lies within ~1e-7
-// (relative) of the threshold, with an effect of <= 1e-4 on that pixel's weights -- far inside the 1e-3 bar.
+// stay bit-identical to the forward's, and so does the transmittance: the recurrence T_{j+1} = T_j - alpha_j T_j (blend.h)
+// leaves T untouched by a skipped entry, so the replay on the compacted list walks through exactly the forward's values
+// (rounds 2-5 multiplied partial products in groups of four, which the compaction regrouped: an ulp apart).
 //
 // The kernel is bound by VALU issue (profiles/r04_pmc.md: the VALU pipes are busy 81 % of the launch incl. its ramp and tail,
-// five waves per SIMD at 91 VGPRs / 8 128 B of LDS per wave; 14 % of the HBM roofline), so the design minimises instructions
+// five waves per SIMD at 83 VGPRs / 8 128 B of LDS per wave; 13-16 % of the HBM roofline), so the design minimises instructions
 // per (pixel, splat) pair.  Two phases per chunk of GC = 8 splats (GC = 16: the round-2 layout, EXA_BWD_GC=16):
 //
 //  Phase A  (lane = pixel, splats in list order): REPLAY the forward recurrence from the checkpoint with the
@@ -25,7 +25,8 @@
 //               R_i = (C_fin - C_i) . g - tail,      tail = T_fin (g_alpha - bg . g)
 //               dL/d(alpha_i) = T_i (c_i . g) - R_{i+1} / (1 - alpha_i)
 //           ("." also runs over the depth channel).  Two numbers per pair go to LDS as one 8-byte store:
-//           aG = G dL/dalpha and the blend weight w = alpha T.  236 VALU instructions per chunk.
+//           aG = (opacity G) dL/dalpha and the blend weight w = alpha T.  ~160 VALU instructions per chunk (236 in round 5:
+//           blend.h's two-instruction recurrence, Horner power, gated product instead of a `w > 0` select).
 //  Phase B  (lane = (splat g, pixel row h), XLayout<8>): the transposed read (ds_read_b128, entry stride 132 floats:
 //           conflict-free in gfx950's lane groups) turns the per-splat sums over the 64 pixels into per-lane accumulation.
 //           The screen-space moments are accumulated against COMPILE-TIME pixel coordinates (x - 4 in -4..3):
